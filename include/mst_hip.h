@@ -1,0 +1,317 @@
+/*
+ * mst_hip.h — C-ABI of libmst_hip.so: the MI355X (gfx950) kernels behind the
+ * VarAutoEncoder training step of slyforce/MusicStyleTransfer.
+ *
+ * Every entry point takes raw DEVICE pointers, explicit sizes / leading
+ * dimensions and a hipStream_t (passed as void*), returns 0 on success or a
+ * negative mst_status, never allocates, never synchronises, and may be
+ * captured into a hipGraph. mst_last_error() returns a thread-local message
+ * for the last non-zero status.
+ *
+ * The reference has no native code (it is Python on MXNet 1.3); each function
+ * below replaces the MXNet operator call site(s) cited next to it. Paths are
+ * relative to /root/reference/music_style_transfer/.
+ *
+ * Conventions
+ *   - "act" tensors (activations) are 16-bit: MST_BF16 or MST_F16, selected by
+ *     the `dtype` argument. Parameters / gradients / optimizer state are fp32.
+ *   - Row-major everywhere. ld* are leading dimensions in ELEMENTS.
+ *   - Dense weights keep MXNet's [units, in_units] layout (y = x W^T + b).
+ */
+#ifndef MST_HIP_H
+#define MST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mst_stream_t; /* hipStream_t */
+
+enum mst_status {
+  MST_OK = 0,
+  MST_ERR_INVALID = -1, /* bad argument (shape/alignment/dtype)             */
+  MST_ERR_LAUNCH = -2,  /* hip launch / runtime error (see mst_last_error)  */
+  MST_ERR_UNSUPPORTED = -3
+};
+
+enum mst_dtype { MST_BF16 = 0, MST_F16 = 1, MST_F32 = 2 };
+
+/* epilogue activation for mst_gemm_nt */
+enum mst_act { MST_ACT_NONE = 0, MST_ACT_RELU = 1 };
+
+int mst_version(void);
+const char* mst_last_error(void);
+/* number of HIP devices visible, or negative status (used by the loader to fail loudly) */
+int mst_device_count(void);
+
+/* ---- stream-capture helpers (hipGraph instead of a tracing compiler) ---- */
+int mst_graph_begin(mst_stream_t stream);
+int mst_graph_end(mst_stream_t stream, void** graph_exec_out);
+int mst_graph_launch(void* graph_exec, mst_stream_t stream);
+int mst_graph_destroy(void* graph_exec);
+
+/* ---- hip events on an explicit stream (bench.py times kernels with these) ---- */
+int mst_event_create(void** ev_out);
+int mst_event_record(void* ev, mst_stream_t stream);
+int mst_event_sync(void* ev);
+int mst_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
+int mst_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------------
+ * K3/K7/K8/K10/K12 + piano-roll in/out Dense: C[M,N] = epi(A[M,K] · B[N,K]^T)
+ * Replaces gluon.nn.Dense(flatten=False) at transformer.py:36-40,65-68,
+ * model.py:70-71,214-227 and, with B = W^T shadow, their dgrad.
+ *
+ *   A, B      : act dtype; K must be a multiple of 8; lda, ldb multiples of 8
+ *   C         : act dtype (c_f32 = 0) or fp32 (c_f32 = 1); ldc multiple of 4.
+ *               Columns N..min(roundup4(N),ldc) are written as exact zeros.
+ *   bias      : fp32 [N] or NULL
+ *   resid     : act dtype [M, ldr] or NULL (residual branch, added after dropout)
+ *   act       : mst_act applied to alpha*(acc+bias+grpadd)
+ *   gate      : act dtype [M, ldg] or NULL; result is zeroed where gate <= 0
+ *               (ReLU backward fused into the FFN2 dgrad, transformer.py:36-38)
+ *   alpha     : scalar applied to (acc + bias + grpadd)  (sqrt(D), transformer.py:237,270)
+ *   rowadd    : fp32 [rowadd_period, ldra] or NULL; rowadd[(m % rowadd_period)] added
+ *               AFTER alpha·(acc+bias+grpadd) (positional table, transformer.py:204-211)
+ *   grpadd    : fp32 table [*, ldga] gathered by grp_index[m / rowadd_period] (int32) or NULL;
+ *               added BEFORE alpha (class embedding, model.py:89-91)
+ *   a_rows_per_group/a_group_stride/a_group_offset : if a_rows_per_group > 0, logical row m of A
+ *               lives at physical row (m / rpg)*stride + offset + (m % rpg)   (model.py:253 drops row 0)
+ *   c_rows_per_group/...: same remap for C rows (model.py:244 concat after the initial state)
+ *   dropout   : p in [0,1); if p > 0 the epilogue applies inverted dropout with the
+ *               counter-based mask mst_dropout_keep(seed, site, m*N+n) (transformer.py:35,149,182)
+ *   self_resid: out = t + dropout(t) (decoder LN3(ff + dropout(ff)), transformer.py:199-200)
+ * Epilogue order: t = alpha*(acc + bias + grpadd) -> act -> [u = dropout(t); self_resid: u += t]
+ *                 -> + rowadd -> + resid -> gate.
+ * ------------------------------------------------------------------------ */
+typedef struct mst_gemm_args {
+  int32_t dtype;
+  int32_t c_f32;
+  int64_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;
+  const void* resid; int64_t ldr;
+  int32_t act;
+  const void* gate; int64_t ldg;
+  float alpha;
+  const float* rowadd; int64_t ldra; int64_t rowadd_period;
+  const float* grpadd; int64_t ldga; const int32_t* grp_index;
+  int64_t a_rows_per_group, a_group_stride, a_group_offset;
+  int64_t c_rows_per_group, c_group_stride, c_group_offset;
+  float dropout_p; uint64_t dropout_seed; uint32_t dropout_site;
+  int32_t self_resid;
+} mst_gemm_args;
+
+int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Weight gradient: dW[N,K] (+)= sum_m A[m,n] * B[m,k]   (A = dY [M,N], B = X [M,K])
+ * plus optional bias gradient db[n] += sum_m A[m,n].
+ * Autograd counterpart of the Dense call sites above (trainer.py:176).
+ * dW, db are fp32 and are ACCUMULATED INTO (callers zero the flat gradient
+ * bucket once per step); ldw in elements. N, K multiples of 8; lda, ldb multiples of 8.
+ * Row remaps as in mst_gemm_args apply to A (a_*) and B (b_*).
+ * beta_scale multiplies the contribution (sqrt(D) for embedding-side GEMMs).
+ * ------------------------------------------------------------------------ */
+typedef struct mst_wgrad_args {
+  int32_t dtype;
+  int64_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  float* dW; int64_t ldw;
+  float* db;
+  float scale;
+  int64_t a_rows_per_group, a_group_stride, a_group_offset;
+  int64_t b_rows_per_group, b_group_stride, b_group_offset;
+} mst_wgrad_args;
+
+int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream);
+/* up to 8 problems (host array) in ONE launch: keeps the M-split, and with it the atomic traffic, small */
+int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K1/K2: token path input. out[b, s_off + t, :] = alpha*(table[tok[b,t]] + cls[classes[b]]) + pos[s_off+t]
+ * (model.py:86-91, transformer.py:270; decoder: model.py:241-245 with cls = NULL, s_off = 1).
+ * Also emits keymask[b, s_off + t] = (tok != 0) if keymask != NULL (model.py:81-83).
+ * table, cls, pos fp32; tokens/classes int32; out act dtype [B, S_out, ld].
+ * ------------------------------------------------------------------------ */
+int mst_embed_fwd(int dtype, int64_t B, int64_t T, int64_t D,
+                  const int32_t* tokens, const float* table, int64_t ldt,
+                  const int32_t* classes, const float* cls_table, int64_t ldc,
+                  const float* pos, int64_t ldp, float alpha,
+                  void* out, int64_t ld_out, int64_t S_out, int64_t s_off,
+                  uint8_t* keymask, mst_stream_t stream);
+
+/* scatter-add of alpha*dX rows into dtable (fp32, accumulated) and dcls (fp32, accumulated) */
+int mst_embed_bwd(int dtype, int64_t B, int64_t T, int64_t D,
+                  const int32_t* tokens, float* dtable, int64_t ldt,
+                  const int32_t* classes, float* dcls, int64_t ldc, float alpha,
+                  const void* dX, int64_t ld_dx, int64_t S_out, int64_t s_off,
+                  mst_stream_t stream);
+
+/* dst[idx[b], :] += alpha * sum_{t<T} X[b, s_off+t, :]  (fp32 dst, accumulated): gradient of the class
+ * embedding that the piano-roll input GEMM's epilogue added to every frame (model.py:89-91) */
+int mst_group_colsum(int dtype, int64_t B, int64_t T, int64_t D, const void* X, int64_t ldx,
+                     int64_t S_out, int64_t s_off, const int32_t* idx, float* dst, int64_t ldd,
+                     float alpha, mst_stream_t stream);
+
+/* key-validity mask from lengths: keymask[b,s] = s < lens[b] + add (model.py:246-247 SequenceMask) */
+int mst_mask_from_lengths(int64_t B, int64_t S, const int32_t* lens, int32_t add,
+                          uint8_t* keymask, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K4/K11: MultiHeadDotAttention with the reference's key-row softmax
+ * (transformer.py:85-126): logits[k,q] = K[k]·Q[q]/sqrt(dh) + (keymask[k] ? 0 : -1e9),
+ * P = softmax over q, O[q] = sum_k P[k,q] V[k].
+ *   qkv   : act dtype [B*S, ld_qkv]; K at column k_off + h*dh, Q at q_off + h*dh, V at v_off + h*dh
+ *   lse   : fp32 [B, H, S] (written by fwd, read by bwd)
+ *   out   : act dtype [B*S, ld_out], head h at column h*dh
+ * dh in {16, 32, 64}.
+ * ------------------------------------------------------------------------ */
+int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh,
+                            const void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                            const uint8_t* keymask, float* lse,
+                            void* out, int64_t ld_out, mst_stream_t stream);
+
+/* dqkv has the same layout as qkv; delta is fp32 scratch [B, H, S]. */
+int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh,
+                            const void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                            const uint8_t* keymask, const float* lse,
+                            const void* dout, int64_t ld_dout,
+                            void* dqkv, int64_t ld_dqkv, float* delta, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K6: y = LayerNorm(x) * gamma + beta over the last axis (eps, biased variance;
+ * gluon.nn.LayerNorm at transformer.py:142,147,175,180). The residual add is fused
+ * into the producing GEMM's epilogue, so x is the pre-norm sum.
+ *   x, y : act dtype [M, ld]; mean, rstd : fp32 [M] (saved for backward)
+ * bwd: dx (act dtype) and dgamma/dbeta (fp32, ACCUMULATED INTO). The gradient arriving through the
+ *   residual branch is added by the consuming dgrad GEMM's `resid` epilogue, not here.
+ *   mask_mode 0: dx only. 1: also dx_masked = dx * keep/(1-p), the gradient of the dropped-out
+ *   GEMM output feeding this norm (transformer.py:155,158,197). 2: dx <- dx * (1 + keep/(1-p)),
+ *   the decoder's LN3(ff + dropout(ff)) (transformer.py:200). The keep mask is regenerated from
+ *   (dropout_seed, dropout_site, m*D + d), the same counter RNG the forward GEMM epilogue used.
+ * ------------------------------------------------------------------------ */
+int mst_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ldx,
+                      const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, float* mean, float* rstd, mst_stream_t stream);
+
+int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ldx,
+                      const float* gamma, const float* mean, const float* rstd,
+                      const void* dy, int64_t ldy, void* dx, int64_t ld_dx,
+                      void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
+                      int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
+                      mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K8/K9/K10 latent block (model.py:97-103,292,229-232; loss.py:8-12), fp32 math:
+ *   fwd: h0 = enc_out[b, 0, :]                     (act dtype, row stride ld_enc*S)
+ *        [mu | sigma] = h0 · Wl^T + bl              (Wl fp32 [2Z, De])
+ *        z = mu + eps * sigma ; kl[b] = 0.5 * sum_z (sigma^2 + mu^2 - 1 - log(sigma^2))
+ *        dec_in[b, 0, :] = alpha_d*(z · Wh^T + bh + cls_d[classes[b]]) + pos_d[0]   (Wh fp32 [Dd, Z])
+ *   bwd: given d(dec_in[b,0,:]) and beta (KL weight): all parameter grads (accumulated, fp32),
+ *        d(enc_out[b,0,:]) written (act dtype) into denc row 0 of each sample.
+ * ------------------------------------------------------------------------ */
+int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
+                   const void* enc_out, int64_t enc_sample_stride,
+                   const float* Wl, const float* bl, const float* eps,
+                   const float* Wh, const float* bh,
+                   const int32_t* classes, const float* cls_d, int64_t ld_cls,
+                   const float* pos_d, float alpha_d,
+                   float* mu, float* sigma, float* z, float* kl,
+                   void* dec_in, int64_t dec_sample_stride, mst_stream_t stream);
+
+int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
+                   const void* enc_out, int64_t enc_sample_stride,
+                   const float* Wl, const float* eps, const float* Wh,
+                   const int32_t* classes,
+                   const float* mu, const float* sigma, const float* z,
+                   const void* d_dec_in, int64_t dec_sample_stride, float alpha_d,
+                   float kl_weight, float gscale,
+                   float* dWl, float* dbl, float* dWh, float* dbh, float* dcls_d, int64_t ld_cls,
+                   void* d_enc_out, int64_t denc_sample_stride, float* scratch /* fp32 [B*(Dd+2Z)] */,
+                   mst_stream_t stream);
+
+/* standalone reparameterisation + KL (loss.VariationalKLLoss, loss.py:4-12; model.py:292) */
+int mst_reparam_kl_fwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,
+                       float* z, float* kl, mst_stream_t stream);
+int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,
+                       const float* dz, float kl_weight, float* dmu, float* dsigma, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K12/K13: softmax over V + SoftmaxCrossEntropy (model.py:256; loss.py:15-23).
+ *   logits : act dtype [M = B*T, ld]; labels int32 [M]
+ *   loss[b] = (1/T) * sum_t -log p[b,t,label] * (label != 0)     (fp32 [B], written)
+ *   probs  : optional fp32 [M, ldp] output (reconstruction)
+ *   dlogits: optional act dtype [M, ld]: (p - onehot) * (label != 0) / T * gscale; pad cols zero
+ * ------------------------------------------------------------------------ */
+int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V,
+                   const void* logits, int64_t ld, const int32_t* labels,
+                   float* loss, float* probs, int64_t ldp,
+                   void* dlogits, int64_t ldd, float gscale, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K14: sigmoid + BinaryCrossEntropy (loss.py:27-80), piano-roll head.
+ *   logits : act dtype [B, T*P] viewed as [B*T, ld] with P valid columns
+ *   labels : uint8 {0,1} [B*T, P]
+ *   loss[b] = mean_{t,p} bce ; bce = -(s log(1e-12+p) + (1-s) log(1e-12+1-p)), s = (1-ls)*y + 0.5*ls
+ *   negative down-weighting (downweight != 0): where y == 0, bce <- w_b * bce^2,
+ *   w_b = n_pos_b / (n_neg_b + 1e-12) (loss.py:50-54,58-81); npos is int32 [B] scratch.
+ *   probs  : optional act dtype [B*T, ldp] (sigmoid output = reconstructed piano-roll)
+ *   dlogits: optional act dtype, d(sum_b loss_b)/dlogit * gscale
+ * ------------------------------------------------------------------------ */
+int mst_sigmoid_bce(int dtype, int64_t B, int64_t T, int64_t P,
+                    const void* logits, int64_t ld, const uint8_t* labels,
+                    float label_smoothing, int downweight, int32_t* npos,
+                    float* loss, void* probs, int64_t ldp,
+                    void* dlogits, int64_t ldd, float gscale, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K15/K21: total[b] = recon[b] + kl_weight * kl[b]; metric_acc[0] += sum_b kl, [1] += sum_b total,
+ * [2] += B (running sums kept on device: trainer.py:107-120,172,181-186).
+ * ------------------------------------------------------------------------ */
+int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_weight,
+                     float* total, float* metric_acc, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * K16: multi-tensor Adam over one flat fp32 bucket with MXNet's update rule
+ * (gluon.Trainer.step → optimizer.Adam → adam_update; trainer.py:94-101,177):
+ *   g = clip(grad * rescale + wd * w, ±clip)  (clip < 0: no clipping)
+ *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g² ; w -= lr_t * m / (sqrt(v) + eps)
+ *   lr_t = lr * sqrt(1-b2^t)/(1-b1^t); t lives in step_state[0] on the device and is advanced by a
+ *   1-thread kernel issued ahead of the update in the same stream, so a captured graph replays
+ *   with the right bias correction.
+ * Also refreshes the 16-bit shadow copy w16 (act dtype, same offsets).
+ * ------------------------------------------------------------------------ */
+int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
+                  void* w16, float lr, float beta1, float beta2, float eps, float wd,
+                  float rescale, float clip, int32_t* step_state /* device int32[2]: {t, bits(lr_t)} */,
+                  mst_stream_t stream);
+
+/* 16-bit shadow + transposed shadow refresh for a list of matrices.
+ * desc: int64 [n_mat, 4] on device = {src_offset, dst_offset, rows, cols}; dst is [cols, ld_t] with
+ * ld_t = roundup8(rows), pad columns zeroed. tiles: int64 prefix sums [n_mat+1] of 32x32 tile counts. */
+int mst_transpose_shadows(int dtype, const float* w, void* wt16, const int64_t* desc,
+                          const int64_t* tile_prefix, int64_t n_mat, int64_t total_tiles,
+                          mst_stream_t stream);
+
+/* fp32 -> act dtype cast of a flat range (initial shadow fill) */
+int mst_cast_f32_to_act(int dtype, int64_t n, const float* src, void* dst, mst_stream_t stream);
+
+/* counter-based dropout keep-mask materialisation (for the oracle comparison): keep[i] in {0,1} */
+int mst_dropout_mask(int64_t n, float p, uint64_t seed, uint32_t site, uint8_t* keep, mst_stream_t stream);
+
+/* elementwise act-dtype helpers used on gradient joins: y = a + b */
+int mst_add_act(int dtype, int64_t n, const void* a, const void* b, void* y, mst_stream_t stream);
+
+/* hardware layout self-test (MFMA fragment maps + ds_read_tr16_b64); out: int32[4] pass flags */
+int mst_selftest(int32_t* out_flags_device, mst_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_HIP_H */

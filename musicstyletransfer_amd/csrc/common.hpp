@@ -1,0 +1,129 @@
+// common.hpp — shared device/host helpers for libmst_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mst_hip.h"
+
+namespace mst {
+
+// ---------------------------------------------------------------- host side
+void set_error(const char* fmt, ...);
+
+#define MST_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::mst::set_error(__VA_ARGS__);             \
+      return MST_ERR_INVALID;                    \
+    }                                            \
+  } while (0)
+
+#define MST_CHECK_LAUNCH(what)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      ::mst::set_error("%s: %s", what, hipGetErrorString(e__));                  \
+      return MST_ERR_LAUNCH;                                                     \
+    }                                                                            \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t roundup(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// -------------------------------------------------------------- device side
+constexpr int WAVE = 64;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(8))) short i16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// 16-bit activation element traits
+template <typename T> struct Act;
+template <> struct Act<__bf16> {
+  typedef bf16x8 vec8;
+  typedef bf16x4 vec4;
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Act<_Float16> {
+  typedef f16x8 vec8;
+  typedef f16x4 vec4;
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// 16-byte vector of 8 act elements, viewed as raw bits
+union Pack8 {
+  u32x4 u;
+  uint16_t h[8];
+};
+
+template <typename T> __device__ __forceinline__ float bits_to_f32(uint16_t b) {
+  T t;
+  __builtin_memcpy(&t, &b, 2);
+  return (float)t;
+}
+template <typename T> __device__ __forceinline__ uint16_t f32_to_bits(float f) {
+  T t = (T)f;
+  uint16_t b;
+  __builtin_memcpy(&b, &t, 2);
+  return b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// logical → physical row remap (see mst_gemm_args)
+__device__ __forceinline__ int64_t remap_row(int64_t m, int64_t rpg, int64_t stride, int64_t off) {
+  return rpg > 0 ? (m / rpg) * stride + off + (m % rpg) : m;
+}
+
+// Counter-based dropout RNG: one 64-bit mix per element → keep decision.
+// Both forward and backward regenerate the mask from (seed, site, index); nothing is stored.
+__host__ __device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint32_t site, uint64_t idx) {
+  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx * 0xD1B54A32D192ED03ull);
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+__host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+  // keep with probability 1-p
+  uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  return dropout_hash(seed, site, idx) >= thr;
+}
+
+template <typename F> static inline int dispatch_act(int dtype, F&& f) {
+  if (dtype == MST_BF16) return f((__bf16)0);
+  if (dtype == MST_F16) return f((_Float16)0);
+  set_error("unsupported activation dtype %d (want MST_BF16 or MST_F16)", dtype);
+  return MST_ERR_UNSUPPORTED;
+}
+
+}  // namespace mst

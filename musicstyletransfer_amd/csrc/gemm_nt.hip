@@ -1,0 +1,247 @@
+// gemm_nt.hip — C[M,N] = epilogue(A[M,K] · B[N,K]^T), 16-bit operands, fp32 accumulate on MFMA.
+//
+// Replaces gluon.nn.Dense(flatten=False) (y = x W^T + b, W stored [units, in_units]) at
+// VarAutoEncoder/transformer.py:36-40,65-68 and model.py:214-227, and — called with the W^T
+// shadow as B — the data-gradient of the same layers.
+//
+// Design (gfx950): both operands are K-contiguous, so every MFMA fragment is one 16-byte LDS
+// read. The product is formed "swapped" (MFMA A-operand = weight rows n, B-operand = activation
+// rows m) so an accumulator register quad is 4 consecutive n of one output row: the epilogue
+// reads bias/residual/gate and writes C with 8-byte (16-bit C) or 16-byte (fp32 C) accesses.
+// Tiles are staged global → registers → LDS (XOR-swizzled 16-byte chunks, conflict-free
+// ds_read_b128), double-buffered with one barrier per 64-deep K tile; the global loads of tile
+// t+1 are issued before the MFMAs of tile t and written to LDS after them.
+#include "common.hpp"
+
+namespace mst {
+
+constexpr int BK = 64;           // K depth of one LDS tile (elements)
+constexpr int CHUNKS = BK / 8;   // 16-byte chunks per tile row
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
+  constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 sub-tiles per wave
+  constexpr int A_CH = BM * CHUNKS / NT, B_CH = BN * CHUNKS / NT;
+  static_assert(BM * CHUNKS % NT == 0 && BN * CHUNKS % NT == 0, "tile/threads mismatch");
+  typedef typename Act<T>::vec8 vec8;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* sA = reinterpret_cast<u32x4*>(smem);                    // [2][BM*CHUNKS]
+  u32x4* sB = sA + 2 * BM * CHUNKS;                              // [2][BN*CHUNKS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware tile order: blocks sharing an XCD (blockIdx % 8) walk neighbouring M tiles of one
+  // N panel, so the weight panel and the A rows they share stay in that XCD's L2.
+  const int64_t tiles_n = (a.N + BN - 1) / BN;
+  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  const int64_t nwg = tiles_m * tiles_n;
+  int64_t bid = blockIdx.x;
+  {
+    const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int64_t m0 = (bid / tiles_n) * BM;
+  const int64_t n0 = (bid % tiles_n) * BN;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
+
+  // per-thread staging assignment: chunk c -> (row = c / CHUNKS, ch = c % CHUNKS)
+  const T* a_ptr[A_CH];
+  bool a_ok[A_CH];
+  int a_lds[A_CH], a_ch[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
+    int64_t m = m0 + row;
+    a_ok[i] = m < a.M;
+    int64_t pm = remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
+    a_ptr[i] = A + pm * a.lda + ch * 8;
+    a_ch[i] = ch * 8;
+    a_lds[i] = row * CHUNKS + (ch ^ (row & 7));
+  }
+  const T* b_ptr[B_CH];
+  bool b_ok[B_CH];
+  int b_lds[B_CH], b_ch[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
+    int64_t n = n0 + row;
+    b_ok[i] = n < a.N;
+    b_ptr[i] = B + (b_ok[i] ? n : 0) * a.ldb + ch * 8;
+    b_ch[i] = ch * 8;
+    b_lds[i] = row * CHUNKS + (ch ^ (row & 7));
+  }
+
+  u32x4 ra[A_CH], rb[B_CH];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      ra[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      rb[i] = (b_ok[i] && (k0 + b_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(b_ptr[i] + k0) : zero4;
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) sA[buf * BM * CHUNKS + a_lds[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int64_t nk = (a.K + BK - 1) / BK;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int64_t t = 0; t < nk; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nk) load_tile((t + 1) * BK);
+    const u32x4* cA = sA + cur * BM * CHUNKS;
+    const u32x4* cB = sB + cur * BN * CHUNKS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      vec8 xf[TM], wf[TN];
+      const int kc = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = wm * WTM + i * 16 + frow;
+        u32x4 v = cA[row * CHUNKS + (kc ^ (row & 7))];
+        xf[i] = __builtin_bit_cast(vec8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int row = wn * WTN + j * 16 + frow;
+        u32x4 v = cB[row * CHUNKS + (kc ^ (row & 7))];
+        wf[j] = __builtin_bit_cast(vec8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf[j], xf[i], acc[j][i]);
+    }
+    if (t + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int64_t n_store = ((a.N + 3) / 4 * 4) < a.ldc ? ((a.N + 3) / 4 * 4) : a.ldc;
+  const float inv_keep = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= a.M) continue;
+    const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+    const float* ra_row = nullptr;
+    const float* ga_row = nullptr;
+    if (a.rowadd) ra_row = a.rowadd + (m % a.rowadd_period) * a.ldra;
+    if (a.grpadd) ga_row = a.grpadd + (int64_t)a.grp_index[m / a.rowadd_period] * a.ldga;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t nb = n0 + wn * WTN + j * 16 + fq * 4;
+      if (nb >= n_store) continue;
+      float v[4];
+      float res[4] = {0.f, 0.f, 0.f, 0.f};
+      float gt[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.resid) {
+        u32x2 r2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(a.resid) + m * a.ldr + nb);
+        res[0] = bits_to_f32<T>((uint16_t)(r2[0] & 0xffff)); res[1] = bits_to_f32<T>((uint16_t)(r2[0] >> 16));
+        res[2] = bits_to_f32<T>((uint16_t)(r2[1] & 0xffff)); res[3] = bits_to_f32<T>((uint16_t)(r2[1] >> 16));
+      }
+      if (a.gate) {
+        u32x2 g2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(a.gate) + m * a.ldg + nb);
+        gt[0] = bits_to_f32<T>((uint16_t)(g2[0] & 0xffff)); gt[1] = bits_to_f32<T>((uint16_t)(g2[0] >> 16));
+        gt[2] = bits_to_f32<T>((uint16_t)(g2[1] & 0xffff)); gt[3] = bits_to_f32<T>((uint16_t)(g2[1] >> 16));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = nb + r;
+        float t = acc[j][i][r];
+        if (n < a.N) {
+          if (a.bias) t += a.bias[n];
+          if (ga_row) t += ga_row[n];
+          t *= a.alpha;
+          if (a.act == MST_ACT_RELU) t = fmaxf(t, 0.f);
+          if (a.dropout_p > 0.f || a.self_resid) {
+            float u = t;
+            if (a.dropout_p > 0.f)
+              u = dropout_keep(a.dropout_seed, a.dropout_site, (uint64_t)(m * a.N + n), a.dropout_p) ? t * inv_keep : 0.f;
+            t = a.self_resid ? t + u : u;
+          }
+          if (ra_row) t += ra_row[n];
+          t += res[r];
+          if (a.gate && !(gt[r] > 0.f)) t = 0.f;
+        } else {
+          t = 0.f;
+        }
+        v[r] = t;
+      }
+      if (C_F32) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + pm * a.ldc + nb) = o;
+      } else {
+        u32x2 o;
+        o[0] = (uint32_t)f32_to_bits<T>(v[0]) | ((uint32_t)f32_to_bits<T>(v[1]) << 16);
+        o[1] = (uint32_t)f32_to_bits<T>(v[2]) | ((uint32_t)f32_to_bits<T>(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(a.C) + pm * a.ldc + nb) = o;
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
+  const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+  dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
+  if (a.c_f32)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, true>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, false>), grid, block, lds, s, a);
+  MST_CHECK_LAUNCH("gemm_nt_kernel");
+  return MST_OK;
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr, "mst_gemm_nt: null args");
+  const mst_gemm_args& a = *args;
+  MST_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "mst_gemm_nt: M,N,K must be positive (got %lld,%lld,%lld)",
+                (long long)a.M, (long long)a.N, (long long)a.K);
+  MST_CHECK_ARG(a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0,
+                "mst_gemm_nt: K, lda, ldb must be multiples of 8 (got %lld,%lld,%lld)", (long long)a.K,
+                (long long)a.lda, (long long)a.ldb);
+  MST_CHECK_ARG(a.ldc % 4 == 0 && a.ldc >= a.N, "mst_gemm_nt: ldc must be a multiple of 4 and >= N");
+  MST_CHECK_ARG(a.A && a.B && a.C, "mst_gemm_nt: null operand");
+  MST_CHECK_ARG(!a.resid || (a.ldr % 4 == 0 && a.ldr >= a.N), "mst_gemm_nt: ldr must be a multiple of 4 and >= N");
+  MST_CHECK_ARG(!a.gate || (a.ldg % 4 == 0 && a.ldg >= a.N), "mst_gemm_nt: ldg must be a multiple of 4 and >= N");
+  MST_CHECK_ARG((!a.rowadd && !a.grpadd) || a.rowadd_period > 0, "mst_gemm_nt: rowadd_period must be > 0");
+  MST_CHECK_ARG(!a.grpadd || a.grp_index, "mst_gemm_nt: grpadd needs grp_index");
+  MST_CHECK_ARG(a.dropout_p >= 0.f && a.dropout_p < 1.f, "mst_gemm_nt: dropout_p must be in [0,1)");
+  MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.C % 16 == 0),
+                "mst_gemm_nt: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    const int64_t big_tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
+    if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
+    return launch_gemm<T, 64, 64, 2, 2>(a, s);
+  });
+}

@@ -1,0 +1,265 @@
+// gemm_wgrad.hip — weight gradients: dW[N,K] += scale * sum_m A[m,n] * B[m,k], db[n] += sum_m A[m,n].
+//
+// Autograd counterpart (trainer.py:176 loss.backward()) of every Dense call site in
+// VarAutoEncoder/transformer.py:36-40,65-68 and model.py:70-71,214-227: A = dY [M,N], B = X [M,K].
+//
+// Design (gfx950): the contraction index m is the row index of BOTH operands, i.e. both MFMA
+// operands are needed "transposed". The tiles are staged row-major exactly as they sit in HBM
+// (coalesced 16-byte loads) and consumed through ds_read_tr16_b64, which hands each lane 4
+// consecutive m of one column — two of them form one 16x16x32 fragment. M is split across
+// workgroups (≫256 of them) and partial tiles are accumulated with fp32 atomics into the flat
+// gradient bucket, which the step zeroes once. Several layers' problems go into ONE launch
+// (mst_wgrad_batch) so the split factor, and with it the atomic traffic, stays small.
+#include "common.hpp"
+
+namespace mst {
+
+constexpr int WG_MAXP = 8;
+struct WgradBatch {
+  int n;
+  int split;                      // M split factor shared by all problems
+  mst_wgrad_args p[WG_MAXP];
+  int64_t tile_prefix[WG_MAXP + 1];  // prefix sums of (tiles_n * tiles_k) per problem
+};
+
+constexpr int BMR = 64;  // m rows per LDS stage
+
+__device__ __forceinline__ i16x4 tr_read(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
+}
+
+template <typename T, int BN, int BKO, int WGN, int WGK>
+__global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
+  constexpr int NT = WGN * WGK * 64;
+  constexpr int WTN = BN / WGN, WTK = BKO / WGK;
+  constexpr int TN = WTN / 16, TK = WTK / 16;
+  constexpr int A_CPR = BN / 8, B_CPR = BKO / 8;          // 16-byte chunks per tile row
+  constexpr int A_CH = BMR * A_CPR / NT, B_CH = BMR * B_CPR / NT;
+  static_assert(BMR * A_CPR % NT == 0 && BMR * B_CPR % NT == 0, "tile/threads mismatch");
+  static_assert(NT % A_CPR == 0 && NT % B_CPR == 0, "column ownership must be loop-invariant");
+  typedef typename Act<T>::vec8 vec8;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sA = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
+  T* sB = sA + 2 * BMR * BN;                   // [2][BMR][BKO]
+  __shared__ float colsum[BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WGK, wk = wave % WGK;
+
+  // locate (problem, tile, split)
+  const int64_t total_tiles = b.tile_prefix[b.n];
+  const int64_t tile_lin = blockIdx.x % total_tiles;
+  const int split_id = (int)(blockIdx.x / total_tiles);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < b.n && tile_lin >= b.tile_prefix[i]) pi = i;
+  const mst_wgrad_args& a = b.p[pi];
+  const int64_t local = tile_lin - b.tile_prefix[pi];
+  const int64_t tiles_k = (a.K + BKO - 1) / BKO;
+  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * BKO;
+
+  const int64_t m_chunk = ((a.M + b.split - 1) / b.split + BMR - 1) / BMR * BMR;
+  const int64_t m_begin = (int64_t)split_id * m_chunk;
+  const int64_t m_end = (m_begin + m_chunk < a.M) ? m_begin + m_chunk : a.M;
+  if (m_begin >= m_end) return;  // uniform for the whole workgroup
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
+  const bool do_bias = (a.db != nullptr) && (k0 == 0);
+
+  int a_row[A_CH], a_col[A_CH], b_row[B_CH], b_col[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) { int c = tid + i * NT; a_row[i] = c / A_CPR; a_col[i] = (c % A_CPR) * 8; }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) { int c = tid + i * NT; b_row[i] = c / B_CPR; b_col[i] = (c % B_CPR) * 8; }
+
+  u32x4 ra[A_CH], rb[B_CH];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  auto load_tile = [&](int64_t mb) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int64_t m = mb + a_row[i], n = n0 + a_col[i];
+      if (m < m_end && n < a.N) {
+        int64_t pm = remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
+        ra[i] = *reinterpret_cast<const u32x4*>(A + pm * a.lda + n);
+      } else {
+        ra[i] = zero4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int64_t m = mb + b_row[i], k = k0 + b_col[i];
+      if (m < m_end && k < a.K) {
+        int64_t pm = remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset);
+        rb[i] = *reinterpret_cast<const u32x4*>(B + pm * a.ldb + k);
+      } else {
+        rb[i] = zero4;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      *reinterpret_cast<u32x4*>(sA + (buf * BMR + a_row[i]) * BN + a_col[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      *reinterpret_cast<u32x4*>(sB + (buf * BMR + b_row[i]) * BKO + b_col[i]) = rb[i];
+    if (do_bias) {
+      // every chunk this thread owns covers the same 8 columns (NT % A_CPR == 0)
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        Pack8 p; p.u = ra[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += bits_to_f32<T>(p.h[e]);
+      }
+    }
+  };
+
+  f32x4 acc[TN][TK];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TK; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // tr-read lane roles: 16-lane group g = lane>>4 covers m rows 8g..8g+7 of a 32-row k-step;
+  // lane i = lane&15 supplies the address of row (i>>2), columns 4*(i&3).. and receives column i.
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pcol = (li & 3) * 4;
+
+  const int64_t nsteps = (m_end - m_begin + BMR - 1) / BMR;
+  load_tile(m_begin);
+  store_tile(0);
+  __syncthreads();
+  for (int64_t t = 0; t < nsteps; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nsteps) load_tile(m_begin + (t + 1) * BMR);
+    const T* cA = sA + cur * BMR * BN;
+    const T* cB = sB + cur * BMR * BKO;
+#pragma unroll
+    for (int ms = 0; ms < BMR / 32; ++ms) {
+      vec8 af[TN], bf[TK];
+      const int r_lo = ms * 32 + 8 * g + q;  // block rows r..r+3 → elements 0..3; +4 → elements 4..7
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = wn * WTN + j * 16 + pcol;
+        i16x4 lo = tr_read(cA + (r_lo)*BN + c);
+        i16x4 hi = tr_read(cA + (r_lo + 4) * BN + c);
+        i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[j] = __builtin_bit_cast(vec8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < TK; ++i) {
+        const int c = wk * WTK + i * 16 + pcol;
+        i16x4 lo = tr_read(cB + (r_lo)*BKO + c);
+        i16x4 hi = tr_read(cB + (r_lo + 4) * BKO + c);
+        i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf[i] = __builtin_bit_cast(vec8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TK; ++i) acc[j][i] = Act<T>::mfma16(af[j], bf[i], acc[j][i]);
+    }
+    if (t + 1 < nsteps) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[row = n (4*(lane>>4)+r)][col = k (lane&15)] → atomically accumulate into dW[n][k]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int i = 0; i < TK; ++i) {
+      const int64_t k = k0 + wk * WTK + i * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + wn * WTN + j * 16 + 4 * g + r;
+        if (n < a.N && k < a.K) atomicAdd(a.dW + n * a.ldw + k, acc[j][i][r] * a.scale);
+      }
+    }
+  }
+
+  if (do_bias) {
+    for (int i = tid; i < BN; i += NT) colsum[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&colsum[a_col[0] + e], bsum[e]);
+    __syncthreads();
+    for (int i = tid; i < BN; i += NT)
+      if (n0 + i < a.N) atomicAdd(a.db + n0 + i, colsum[i] * a.scale);
+  }
+}
+
+template <typename T>
+static int launch_wgrad(const WgradBatch& b, bool big, hipStream_t s) {
+  const int64_t total = b.tile_prefix[b.n] * b.split;
+  if (big) {
+    constexpr int BN = 128, BKO = 128;
+    size_t lds = (size_t)2 * BMR * (BN + BKO) * 2;
+    hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 2, 2>), dim3((unsigned)total), dim3(256), lds, s, b);
+  } else {
+    constexpr int BN = 64, BKO = 64;
+    size_t lds = (size_t)2 * BMR * (BN + BKO) * 2;
+    hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 2, 2>), dim3((unsigned)total), dim3(256), lds, s, b);
+  }
+  MST_CHECK_LAUNCH("wgrad_kernel");
+  return MST_OK;
+}
+
+static int check_wgrad(const mst_wgrad_args& a) {
+  MST_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "mst_gemm_wgrad: M,N,K must be positive");
+  MST_CHECK_ARG(a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0,
+                "mst_gemm_wgrad: N, K, lda, ldb must be multiples of 8 (got N=%lld K=%lld lda=%lld ldb=%lld)",
+                (long long)a.N, (long long)a.K, (long long)a.lda, (long long)a.ldb);
+  MST_CHECK_ARG(a.A && a.B && a.dW, "mst_gemm_wgrad: null operand");
+  MST_CHECK_ARG(a.ldw >= a.K, "mst_gemm_wgrad: ldw < K");
+  MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0), "mst_gemm_wgrad: operands must be 16-byte aligned");
+  return MST_OK;
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream) {
+  MST_CHECK_ARG(list != nullptr && n >= 1 && n <= WG_MAXP, "mst_gemm_wgrad_batch: need 1..%d problems", WG_MAXP);
+  WgradBatch b;
+  b.n = n;
+  int64_t out_elems = 0, maxM = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = check_wgrad(list[i]);
+    if (rc) return rc;
+    MST_CHECK_ARG(list[i].dtype == list[0].dtype, "mst_gemm_wgrad_batch: mixed dtypes");
+    b.p[i] = list[i];
+    out_elems += list[i].N * list[i].K;
+    if (list[i].M > maxM) maxM = list[i].M;
+  }
+  // tile size: 128x128 when that still leaves enough tiles to fill the chip at a modest split
+  const bool big = out_elems >= (int64_t)128 * 128 * 96;
+  const int bn = big ? 128 : 64;
+  b.tile_prefix[0] = 0;
+  for (int i = 0; i < n; ++i)
+    b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bn);
+  for (int i = n + 1; i <= WG_MAXP; ++i) b.tile_prefix[i] = b.tile_prefix[n];
+  const int64_t tiles = b.tile_prefix[n];
+  // aim for >= 1024 workgroups, at least 2 LDS stages (128 rows) per workgroup
+  int64_t split = cdiv(1024, tiles);
+  int64_t max_split = cdiv(maxM, 2 * BMR);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  b.split = (int)split;
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(list[0].dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    return launch_wgrad<T>(b, big, s);
+  });
+}
+
+extern "C" int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr, "mst_gemm_wgrad: null args");
+  return mst_gemm_wgrad_batch(args, 1, stream);
+}

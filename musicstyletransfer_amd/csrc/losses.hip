@@ -1,0 +1,280 @@
+// losses.hip — fused loss heads, wavefront reductions, fp32 math on 16-bit logits.
+//
+//   mst_softmax_ce    : softmax over the vocabulary + SoftmaxCrossEntropy
+//                       (VarAutoEncoder/model.py:256, loss.py:15-23)
+//   mst_sigmoid_bce   : sigmoid + BinaryCrossEntropy with label smoothing and the reference's
+//                       negative-label down-weighting w_b * bce^2 (loss.py:27-80)
+//   mst_reparam_kl_*  : z = mu + eps*sigma and VariationalKLLoss (model.py:292, loss.py:4-12)
+//   mst_loss_combine  : loss = recon + kl_weight * kl and the running metric sums
+//                       (trainer.py:107-120,172,181-186)
+//
+// All are HBM-bound: one read of logits (+labels), optional writes of probabilities and of the
+// logit gradient in the same pass, per-sample sums reduced in-wave then with one atomic per wave.
+#include <math.h>
+#include "common.hpp"
+
+namespace mst {
+
+// ------------------------------------------------------------------ softmax + CE
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_kernel(int64_t M, int64_t T_len, int V, const T* __restrict__ logits,
+                                                         int64_t ld, const int32_t* __restrict__ labels,
+                                                         float* __restrict__ loss, float* __restrict__ probs,
+                                                         int64_t ldp, T* __restrict__ dlogits, int64_t ldd,
+                                                         float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_T = 1.f / (float)T_len;
+  for (int64_t m = wave_global; m < M; m += nwaves) {
+    const T* row = logits + m * ld;
+    const int label = labels[m];
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, to_f32(row[v]));
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int v = lane; v < V; v += 64) se += __expf(to_f32(row[v]) - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    const float inv = 1.f / se;
+    const float maskv = (label != 0) ? 1.f : 0.f;
+    if (lane == 0) {
+      const float lp = to_f32(row[label]) - lse;  // log p[label]
+      atomicAdd(loss + m / T_len, -lp * maskv * inv_T);
+    }
+    if (probs || dlogits) {
+      const float gs = maskv * inv_T * gscale;
+      const int vend = dlogits ? (int)((V + 3) / 4 * 4 < ldd ? (V + 3) / 4 * 4 : ldd) : V;
+      for (int v = lane; v < vend; v += 64) {
+        float p = 0.f;
+        if (v < V) p = __expf(to_f32(row[v]) - mx) * inv;
+        if (probs && v < V) probs[m * ldp + v] = p;
+        if (dlogits) dlogits[m * ldd + v] = from_f32<T>(v < V ? (p - (v == label ? 1.f : 0.f)) * gs : 0.f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ sigmoid + BCE
+__global__ __launch_bounds__(256) void count_pos_kernel(int64_t per_sample, const uint8_t* __restrict__ labels,
+                                                        int32_t* __restrict__ npos) {
+  // grid = (blocks_per_sample, B); labels are {0,1} bytes
+  const int64_t b = blockIdx.y;
+  const uint8_t* base = labels + b * per_sample;
+  int cnt = 0;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < per_sample; i += (int64_t)gridDim.x * 256 * 8) {
+    if (i + 8 <= per_sample) {
+      uint64_t w = *reinterpret_cast<const uint64_t*>(base + i);
+      cnt += __popcll(w & 0x0101010101010101ull);
+    } else {
+      for (int64_t j = i; j < per_sample; ++j) cnt += (base[j] == 1);
+    }
+  }
+  float c = wave_sum((float)cnt);
+  if ((threadIdx.x & 63) == 0 && c != 0.f) atomicAdd(npos + b, (int)c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_bce_kernel(int64_t rows_per_sample, int P, const T* __restrict__ logits,
+                                                          int64_t ld, const uint8_t* __restrict__ labels, float ls,
+                                                          int downweight, const int32_t* __restrict__ npos,
+                                                          float* __restrict__ loss, T* __restrict__ probs, int64_t ldp,
+                                                          T* __restrict__ dlogits, int64_t ldd, float gscale) {
+  // grid = (blocks_per_sample, B). A thread handles 4 consecutive pitches of one frame.
+  const int64_t b = blockIdx.y;
+  const int vec_per_row = (P + 3) / 4;
+  const int64_t nvec = rows_per_sample * vec_per_row;
+  const float inv_n = 1.f / ((float)rows_per_sample * (float)P);
+  float w = 0.f;
+  if (downweight) {
+    const float np = (float)npos[b];
+    const float nn = (float)rows_per_sample * (float)P - np;
+    w = np / (nn + 1e-12f);
+  }
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = b * rows_per_sample + i / vec_per_row;
+    const int c0 = (int)(i % vec_per_row) * 4;
+    float x[4];
+    {
+      u32x2 raw = *reinterpret_cast<const u32x2*>(logits + r * ld + c0);
+      x[0] = bits_to_f32<T>((uint16_t)(raw[0] & 0xffff)); x[1] = bits_to_f32<T>((uint16_t)(raw[0] >> 16));
+      x[2] = bits_to_f32<T>((uint16_t)(raw[1] & 0xffff)); x[3] = bits_to_f32<T>((uint16_t)(raw[1] >> 16));
+    }
+    float pv[4], gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      pv[e] = 0.f; gv[e] = 0.f;
+      if (c < P) {
+        const float y = (float)labels[r * P + c];
+        const float p = 1.f / (1.f + __expf(-x[e]));
+        const float omp = 1.f - p;
+        const float s = (1.f - ls) * y + 0.5f * ls;
+        const float lp = __logf(1e-12f + p), lq = __logf(1e-12f + omp);
+        float bce = -(s * lp + (1.f - s) * lq);
+        // d bce / d logit = d bce/dp * p(1-p)
+        float dbce = -(s / (1e-12f + p) - (1.f - s) / (1e-12f + omp)) * p * omp;
+        if (downweight && y == 0.f) {  // loss.py:52-54: (w*bce)*bce where label == 0
+          dbce = 2.f * w * bce * dbce;
+          bce = w * bce * bce;
+        }
+        acc += bce;
+        pv[e] = p;
+        gv[e] = dbce * inv_n * gscale;
+      }
+    }
+    if (probs) {
+      u32x2 o;
+      o[0] = (uint32_t)f32_to_bits<T>(pv[0]) | ((uint32_t)f32_to_bits<T>(pv[1]) << 16);
+      o[1] = (uint32_t)f32_to_bits<T>(pv[2]) | ((uint32_t)f32_to_bits<T>(pv[3]) << 16);
+      *reinterpret_cast<u32x2*>(probs + r * ldp + c0) = o;
+    }
+    if (dlogits) {
+      u32x2 o;
+      o[0] = (uint32_t)f32_to_bits<T>(gv[0]) | ((uint32_t)f32_to_bits<T>(gv[1]) << 16);
+      o[1] = (uint32_t)f32_to_bits<T>(gv[2]) | ((uint32_t)f32_to_bits<T>(gv[3]) << 16);
+      *reinterpret_cast<u32x2*>(dlogits + r * ldd + c0) = o;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss + b, acc * inv_n);
+}
+
+// ------------------------------------------------------------------ reparameterisation + KL
+__global__ __launch_bounds__(64) void reparam_kl_fwd_kernel(int Z, const float* __restrict__ mu,
+                                                            const float* __restrict__ sigma,
+                                                            const float* __restrict__ eps, float* __restrict__ z,
+                                                            float* __restrict__ kl) {
+  const int64_t b = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < Z; i += 64) {
+    const float m = mu[b * Z + i], s = sigma[b * Z + i];
+    z[b * Z + i] = m + eps[b * Z + i] * s;
+    const float s2 = s * s;
+    acc += 0.5f * (s2 + m * m - 1.f - logf(s2));
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) kl[b] = acc;
+}
+
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(int64_t n, const float* __restrict__ mu,
+                                                             const float* __restrict__ sigma,
+                                                             const float* __restrict__ eps,
+                                                             const float* __restrict__ dz, float kl_weight,
+                                                             float* __restrict__ dmu, float* __restrict__ dsigma) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = dz ? dz[i] : 0.f;
+    const float s = sigma[i];
+    dmu[i] = kl_weight * mu[i] + g;
+    dsigma[i] = kl_weight * (s - 1.f / s) + eps[i] * g;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_combine_kernel(int64_t B, const float* __restrict__ recon,
+                                                           const float* __restrict__ kl, float kl_weight,
+                                                           float* __restrict__ total, float* __restrict__ metric) {
+  __shared__ float red[2][4];
+  float skl = 0.f, stot = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float t = recon[b] + kl_weight * kl[b];
+    if (total) total[b] = t;
+    skl += kl[b];
+    stot += t;
+  }
+  skl = wave_sum(skl);
+  stot = wave_sum(stot);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = skl; red[1][threadIdx.x >> 6] = stot; }
+  __syncthreads();
+  if (threadIdx.x == 0 && metric) {
+    metric[0] += red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    metric[1] += red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    metric[2] += (float)B;
+  }
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V, const void* logits, int64_t ld,
+                              const int32_t* labels, float* loss, float* probs, int64_t ldp, void* dlogits,
+                              int64_t ldd, float gscale, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && T > 0 && V > 0, "mst_softmax_ce: B,T,V must be positive");
+  MST_CHECK_ARG(logits && labels && loss, "mst_softmax_ce: null pointer");
+  MST_CHECK_ARG(ld >= V && (!probs || ldp >= V) && (!dlogits || ldd >= V), "mst_softmax_ce: leading dim < V");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * B, s);
+  if (e != hipSuccess) { set_error("mst_softmax_ce: memset: %s", hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+  const int64_t M = B * T;
+  const unsigned grid = (unsigned)(cdiv(M, 4) < 4096 ? cdiv(M, 4) : 4096);
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) TT;
+    hipLaunchKernelGGL((softmax_ce_kernel<TT>), dim3(grid), dim3(256), 0, s, M, T, (int)V, (const TT*)logits, ld, labels,
+                       loss, probs, ldp, (TT*)dlogits, ldd, gscale);
+    MST_CHECK_LAUNCH("softmax_ce_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_sigmoid_bce(int dtype, int64_t B, int64_t T, int64_t P, const void* logits, int64_t ld,
+                               const uint8_t* labels, float label_smoothing, int downweight, int32_t* npos,
+                               float* loss, void* probs, int64_t ldp, void* dlogits, int64_t ldd, float gscale,
+                               mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && T > 0 && P > 0, "mst_sigmoid_bce: B,T,P must be positive");
+  MST_CHECK_ARG(logits && labels && loss, "mst_sigmoid_bce: null pointer");
+  MST_CHECK_ARG(ld % 4 == 0 && ld >= P, "mst_sigmoid_bce: ld must be a multiple of 4 and >= P");
+  MST_CHECK_ARG(!probs || (ldp % 4 == 0 && ldp >= P), "mst_sigmoid_bce: bad ldp");
+  MST_CHECK_ARG(!dlogits || (ldd % 4 == 0 && ldd >= P), "mst_sigmoid_bce: bad ldd");
+  MST_CHECK_ARG(!downweight || npos, "mst_sigmoid_bce: down-weighting needs the npos scratch");
+  MST_CHECK_ARG(B <= 65535, "mst_sigmoid_bce: B too large for grid.y");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * B, s);
+  if (e != hipSuccess) { set_error("mst_sigmoid_bce: memset: %s", hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+  const int64_t per_sample = T * P;
+  if (downweight) {
+    e = hipMemsetAsync(npos, 0, sizeof(int32_t) * B, s);
+    if (e != hipSuccess) { set_error("mst_sigmoid_bce: memset: %s", hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+    unsigned gx = (unsigned)(cdiv(per_sample, 256 * 8 * 4) < 64 ? cdiv(per_sample, 256 * 8 * 4) : 64);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(count_pos_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, per_sample, labels, npos);
+    MST_CHECK_LAUNCH("count_pos_kernel");
+  }
+  const int64_t nvec = T * ((P + 3) / 4);
+  unsigned gx = (unsigned)cdiv(nvec, 256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) TT;
+    hipLaunchKernelGGL((sigmoid_bce_kernel<TT>), dim3(gx, (unsigned)B), dim3(256), 0, s, T, (int)P, (const TT*)logits,
+                       ld, labels, label_smoothing, downweight, npos, loss, (TT*)probs, ldp, (TT*)dlogits, ldd, gscale);
+    MST_CHECK_LAUNCH("sigmoid_bce_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_reparam_kl_fwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,
+                                  float* z, float* kl, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && Z > 0 && mu && sigma && eps && z && kl, "mst_reparam_kl_fwd: bad argument");
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, (int)Z, mu, sigma, eps, z, kl);
+  MST_CHECK_LAUNCH("reparam_kl_fwd_kernel");
+  return MST_OK;
+}
+
+extern "C" int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,
+                                  const float* dz, float kl_weight, float* dmu, float* dsigma, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && Z > 0 && mu && sigma && eps && dmu && dsigma, "mst_reparam_kl_bwd: bad argument");
+  const int64_t n = B * Z;
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, mu, sigma,
+                     eps, dz, kl_weight, dmu, dsigma);
+  MST_CHECK_LAUNCH("reparam_kl_bwd_kernel");
+  return MST_OK;
+}
+
+extern "C" int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_weight, float* total,
+                                float* metric_acc, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && recon && kl, "mst_loss_combine: bad argument");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, recon, kl, kl_weight, total, metric_acc);
+  MST_CHECK_LAUNCH("loss_combine_kernel");
+  return MST_OK;
+}

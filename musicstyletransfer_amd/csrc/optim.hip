@@ -1,0 +1,182 @@
+// optim.hip — multi-tensor Adam over one flat fp32 bucket + 16-bit shadow maintenance.
+//
+// Replaces gluon.Trainer.step(batch_size) → mxnet.optimizer.Adam → adam_update, called once per
+// parameter tensor in the reference (58 launches; trainer.py:94-101,177), by ONE launch over the
+// flat parameter / gradient / moment buffers (the same flat gradient buffer RCCL all-reduces):
+//   g   = clip(grad * rescale + wd * w, ±clip)            (clip < 0: no clipping)
+//   m   = b1*m + (1-b1)*g ;  v = b2*v + (1-b2)*g*g
+//   w  -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+// HBM-bound: 16 B/param read (w,g,m,v) + 12 B/param written (w,m,v) + 2 B/param 16-bit shadow.
+// The step counter lives on the device and is advanced by a 1-thread kernel in the same stream,
+// so a captured graph replays with the right bias correction.
+#include <math.h>
+#include "common.hpp"
+
+namespace mst {
+
+// state[0] = step count t (int32), state[1] = bits of lr_t (float)
+__global__ void adam_tick_kernel(int32_t* state, float lr, float beta1, float beta2) {
+  const int t = state[0] + 1;
+  state[0] = t;
+  const float c1 = 1.f - powf(beta1, (float)t);
+  const float c2 = 1.f - powf(beta2, (float)t);
+  reinterpret_cast<float*>(state)[1] = lr * sqrtf(c2) / c1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ grad,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        T* __restrict__ w16, const int32_t* __restrict__ state,
+                                                        float beta1, float beta2, float eps, float wd, float rescale,
+                                                        float clip) {
+  const float lr_t = reinterpret_cast<const float*>(state)[1];
+  const int64_t nvec = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(grad)[i];
+    f32x4 mv = reinterpret_cast<const f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = gv[e] * rescale + wd * wv[e];
+      if (clip >= 0.f) g = fminf(fmaxf(g, -clip), clip);
+      mv[e] = beta1 * mv[e] + (1.f - beta1) * g;
+      vv[e] = beta2 * vv[e] + (1.f - beta2) * g * g;
+      wv[e] = wv[e] - lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+    }
+    reinterpret_cast<f32x4*>(w)[i] = wv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (w16) {
+      u32x2 o;
+      o[0] = (uint32_t)f32_to_bits<T>(wv[0]) | ((uint32_t)f32_to_bits<T>(wv[1]) << 16);
+      o[1] = (uint32_t)f32_to_bits<T>(wv[2]) | ((uint32_t)f32_to_bits<T>(wv[3]) << 16);
+      reinterpret_cast<u32x2*>(w16)[i] = o;
+    }
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) {
+      float g = grad[i] * rescale + wd * w[i];
+      if (clip >= 0.f) g = fminf(fmaxf(g, -clip), clip);
+      const float mm = beta1 * m[i] + (1.f - beta1) * g;
+      const float vv = beta2 * v[i] + (1.f - beta2) * g * g;
+      const float ww = w[i] - lr_t * mm / (sqrtf(vv) + eps);
+      m[i] = mm; v[i] = vv; w[i] = ww;
+      if (w16) w16[i] = from_f32<T>(ww);
+    }
+  }
+}
+
+// transposed 16-bit shadows: for matrix i, src fp32 [rows, cols] at w + desc[4i], dst [cols, ld_t] at
+// wt16 + desc[4i+1] with ld_t = roundup8(rows); pad columns rows..ld_t are zeroed.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_shadows_kernel(const float* __restrict__ w, T* __restrict__ wt16,
+                                                                const int64_t* __restrict__ desc,
+                                                                const int64_t* __restrict__ tile_prefix, int n_mat) {
+  __shared__ float tile[32][33];
+  const int64_t tb = blockIdx.x;
+  int mi = 0;
+  for (int i = 1; i < n_mat; ++i)
+    if (tb >= tile_prefix[i]) mi = i;
+  const int64_t src_off = desc[4 * mi], dst_off = desc[4 * mi + 1], rows = desc[4 * mi + 2], cols = desc[4 * mi + 3];
+  const int64_t ld_t = (rows + 7) / 8 * 8;
+  const int64_t local = tb - tile_prefix[mi];
+  const int64_t tiles_c = (cols + 31) / 32;
+  const int64_t r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? w[src_off + r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t c = c0 + j, r = r0 + tx;  // dst row = c, dst col = r
+    if (c < cols && r < ld_t) wt16[dst_off + c * ld_t + r] = from_f32<T>(tile[tx][j]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(int64_t n, const float* __restrict__ src, T* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float p, uint64_t seed, uint32_t site, uint8_t* keep) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    keep[i] = dropout_keep(seed, site, (uint64_t)i, p) ? 1 : 0;
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+static unsigned grid_for(int64_t n, int per_thread) {
+  int64_t g = cdiv(n, 256 * (int64_t)per_thread);
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (unsigned)g;
+}
+
+extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, float lr,
+                             float beta1, float beta2, float eps, float wd, float rescale, float clip,
+                             int32_t* step_state, mst_stream_t stream) {
+  MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
+  MST_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                "mst_adam_flat: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_state, lr, beta1, beta2);
+  MST_CHECK_LAUNCH("adam_tick_kernel");
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,
+                       beta1, beta2, eps, wd, rescale, clip);
+    MST_CHECK_LAUNCH("adam_flat_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_transpose_shadows(int dtype, const float* w, void* wt16, const int64_t* desc,
+                                     const int64_t* tile_prefix, int64_t n_mat, int64_t total_tiles,
+                                     mst_stream_t stream) {
+  MST_CHECK_ARG(w && wt16 && desc && tile_prefix && n_mat > 0 && total_tiles > 0, "mst_transpose_shadows: bad argument");
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL((transpose_shadows_kernel<T>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, w, (T*)wt16,
+                       desc, tile_prefix, (int)n_mat);
+    MST_CHECK_LAUNCH("transpose_shadows_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_cast_f32_to_act(int dtype, int64_t n, const float* src, void* dst, mst_stream_t stream) {
+  MST_CHECK_ARG(n > 0 && src && dst, "mst_cast_f32_to_act: bad argument");
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL((cast_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, n, src, (T*)dst);
+    MST_CHECK_LAUNCH("cast_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_add_act(int dtype, int64_t n, const void* a, const void* b, void* y, mst_stream_t stream) {
+  MST_CHECK_ARG(n > 0 && a && b && y, "mst_add_act: bad argument");
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, n, (const T*)a, (const T*)b, (T*)y);
+    MST_CHECK_LAUNCH("add_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_dropout_mask(int64_t n, float p, uint64_t seed, uint32_t site, uint8_t* keep, mst_stream_t stream) {
+  MST_CHECK_ARG(n > 0 && keep && p >= 0.f && p < 1.f, "mst_dropout_mask: bad argument");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, n, p, seed, site, keep);
+  MST_CHECK_LAUNCH("dropout_mask_kernel");
+  return MST_OK;
+}
