@@ -1,0 +1,143 @@
+"""ctypes binding of libmst_hip.so (include/mst_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing, or a kernel returns a
+non-zero status, an exception is raised. `load()` only dlopen()s and checks the exported symbols
+(so it works on a GPU-less box for the "does it build / export" tests); anything that launches a
+kernel needs a visible HIP device.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmst_hip.so")
+
+MST_BF16, MST_F16, MST_F32 = 0, 1, 2
+ACT_NONE, ACT_RELU = 0, 1
+
+c_i32, c_i64, c_f32, c_u64, c_u32 = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32
+vp = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("c_f32", c_i32),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("A", vp), ("lda", c_i64),
+        ("B", vp), ("ldb", c_i64),
+        ("C", vp), ("ldc", c_i64),
+        ("bias", vp),
+        ("resid", vp), ("ldr", c_i64),
+        ("act", c_i32),
+        ("gate", vp), ("ldg", c_i64),
+        ("alpha", c_f32),
+        ("rowadd", vp), ("ldra", c_i64), ("rowadd_period", c_i64),
+        ("grpadd", vp), ("ldga", c_i64), ("grp_index", vp),
+        ("a_rows_per_group", c_i64), ("a_group_stride", c_i64), ("a_group_offset", c_i64),
+        ("c_rows_per_group", c_i64), ("c_group_stride", c_i64), ("c_group_offset", c_i64),
+        ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_site", c_u32),
+        ("self_resid", c_i32),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("A", vp), ("lda", c_i64),
+        ("B", vp), ("ldb", c_i64),
+        ("dW", vp), ("ldw", c_i64),
+        ("db", vp),
+        ("scale", c_f32),
+        ("a_rows_per_group", c_i64), ("a_group_stride", c_i64), ("a_group_offset", c_i64),
+        ("b_rows_per_group", c_i64), ("b_group_stride", c_i64), ("b_group_offset", c_i64),
+    ]
+
+
+# name -> (restype, argtypes). Every symbol include/mst_hip.h declares must appear here.
+SIGNATURES = {
+    "mst_version": (C.c_int, []),
+    "mst_last_error": (C.c_char_p, []),
+    "mst_device_count": (C.c_int, []),
+    "mst_graph_begin": (C.c_int, [vp]),
+    "mst_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "mst_graph_launch": (C.c_int, [vp, vp]),
+    "mst_graph_destroy": (C.c_int, [vp]),
+    "mst_event_create": (C.c_int, [C.POINTER(vp)]),
+    "mst_event_record": (C.c_int, [vp, vp]),
+    "mst_event_sync": (C.c_int, [vp]),
+    "mst_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(c_f32)]),
+    "mst_event_destroy": (C.c_int, [vp]),
+    "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "mst_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
+    "mst_gemm_wgrad_batch": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
+    "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,
+                                vp, c_i64, c_i64, c_i64, vp, vp]),
+    "mst_embed_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, c_f32,
+                                vp, c_i64, c_i64, c_i64, vp]),
+    "mst_group_colsum": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, vp, vp, c_i64, c_f32, vp]),
+    "mst_mask_from_lengths": (C.c_int, [c_i64, c_i64, vp, c_i32, vp, vp]),
+    "mst_attn_keysoftmax_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64,
+                                          vp, vp, vp, c_i64, vp]),
+    "mst_attn_keysoftmax_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64,
+                                          vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
+    "mst_layernorm_fwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, c_f32, vp, c_i64, vp, vp, vp]),
+    "mst_layernorm_bwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_i64, vp, c_i64,
+                                    vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp]),
+    "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
+                                 vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
+    "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
+                                 vp, c_i64, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
+    "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),
+    "mst_reparam_kl_bwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, c_f32, vp, vp, vp]),
+    "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, vp]),
+    "mst_sigmoid_bce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, c_f32, C.c_int, vp, vp, vp, c_i64,
+                                  vp, c_i64, c_f32, vp]),
+    "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
+    "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                vp, vp]),
+    "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
+    "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),
+    "mst_dropout_mask": (C.c_int, [c_i64, c_f32, c_u64, c_u32, vp, vp]),
+    "mst_add_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp]),
+    "mst_selftest": (C.c_int, [vp, vp]),
+}
+
+
+class MstError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libmst_hip.so and bind every declared symbol. Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MstError(
+            f"{LIB_PATH} is missing: build it with `python -m musicstyletransfer_amd.csrc.build` "
+            "(there is no CPU fallback for the training step)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MstError(f"libmst_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mst_last_error()
+        raise MstError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

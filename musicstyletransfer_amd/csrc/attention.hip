@@ -1,0 +1,459 @@
+// attention.hip — MultiHeadDotAttention with the reference's KEY-ROW softmax, forward and backward.
+//
+// Reference arithmetic (VarAutoEncoder/transformer.py:85-126), per (batch b, head h):
+//   L[k,q] = K[k]·Q[q] / sqrt(dh) + (keymask[k] ? 0 : -1e9)        :96-99,106-126
+//   P[k,:] = softmax over q (the LAST axis of [B,H,T_K,T_Q])        :100
+//   O[q]   = sum_k P[k,q] V[k]                                      :102 (transpose_a)
+// Quirks reproduced on purpose: normalisation runs over queries, not keys; the padding mask adds
+// the same -1e9 to a whole softmax row, so in fp32 a padded key row collapses to a (near-)uniform
+// 1/S row instead of being excluded. The kernels add -1e9 in fp32 to the fp32 MFMA accumulator
+// exactly as the reference does, in 16-bit modes too (no -inf, no NaN).
+//
+// Nothing S x S ever reaches HBM. Four kernels, all on v_mfma_f32_32x32x16 with the softmax axis
+// chosen per kernel so reductions stay in-lane:
+//   fwd_stats (key-owner, key on the lane)   : lse[k] = logsumexp_q L[k,q]        (online, in-lane)
+//   fwd_out   (query-owner, query on the lane): O[q] += P^T V, P tile reused straight from the
+//                                               accumulator registers as the next MFMA's A operand
+//   bwd_kv    (key-owner)  : dV[k] = sum_q P dO[q];  delta[k] = sum_q P dP;  dK[k] = s * sum_q dL Q[q]
+//   bwd_q     (query-owner): dQ[q] = s * sum_k dL[k,q] K[k],  dL = P * (dP - delta[k]),  dP = dO[q]·V[k]
+// Operands that a product needs "transposed" (V, dO, Q, K as the B operand of an X^T·B product) are
+// staged row-major in LDS and read with ds_read_tr16_b64.
+#include <math.h>
+#include "common.hpp"
+
+namespace mst {
+
+constexpr int ATT_STAGE = 64;   // rows staged in LDS per step
+constexpr int ATT_WG_ROWS = 128;  // owner rows per workgroup (4 waves x 32)
+constexpr float MASK_VALUE = -1e9f;
+constexpr float NEG_BIG = -3.0e38f;
+
+__device__ __forceinline__ i16x4 att_tr_read(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
+}
+
+// copy rows [row0, row0+ATT_STAGE) x DH of a [S, ld] matrix into LDS [ATT_STAGE][DH]; zero-fill rows >= S
+template <typename T, int DH>
+__device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, int64_t ld, int64_t row0, int64_t S, int tid) {
+  constexpr int CPR = DH / 8;
+  for (int c = tid; c < ATT_STAGE * CPR; c += 256) {
+    const int r = c / CPR, ch = c % CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + r < S) v = *reinterpret_cast<const u32x4*>(g + (row0 + r) * ld + ch * 8);
+    *reinterpret_cast<u32x4*>(lds + r * DH + ch * 8) = v;
+  }
+}
+
+// row fragment (A or B operand, k-contiguous) of rows [r0, r0+32) from an LDS tile with DH columns
+template <typename T, int DH>
+__device__ __forceinline__ typename Act<T>::vec8 lds_row_frag(const T* tile, int r0, int s, int lane) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(tile + (r0 + (lane & 31)) * DH + 16 * s + 8 * (lane >> 5));
+  return __builtin_bit_cast(typename Act<T>::vec8, v);
+}
+
+// row fragment straight from global (owner rows, loaded once per wave); zero beyond S
+template <typename T>
+__device__ __forceinline__ typename Act<T>::vec8 glb_row_frag(const T* __restrict__ g, int64_t ld, int64_t row, int64_t S, int s,
+                                                              int lane) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < S) v = *reinterpret_cast<const u32x4*>(g + row * ld + 16 * s + 8 * (lane >> 5));
+  return __builtin_bit_cast(typename Act<T>::vec8, v);
+}
+
+// B operand of an X^T·B product where X is a 32x32 accumulator tile used as the A operand:
+// element j of lane-half h must be row 16*s2 + 8*(j>>2) + 4*h + (j&3) of the staged tile, column d0 + (lane&31).
+template <typename T, int DH>
+__device__ __forceinline__ typename Act<T>::vec8 lds_tr_frag(const T* tile, int r0, int s2, int d0, int lane) {
+  const int h = lane >> 5, i = lane & 15, q = i >> 2, p = i & 3;
+  const int c0 = (DH >= 32) ? d0 + 16 * ((lane >> 4) & 1) : 0;
+  const int rlo = r0 + 16 * s2 + 4 * h + q;
+  const i16x4 lo = att_tr_read(tile + rlo * DH + c0 + 4 * p);
+  const i16x4 hi = att_tr_read(tile + (rlo + 8) * DH + c0 + 4 * p);
+  const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(typename Act<T>::vec8, v);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Act<T>::vec8 acc_to_frag(const f32x16& x, int s2) {
+  typename Act<T>::vec8 a;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = (T)x[8 * s2 + j];
+  return a;
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int DH>
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+struct AttnArgs {
+  int64_t B, S, H;
+  const void* qkv; int64_t ld_qkv, k_off, q_off, v_off;
+  const uint8_t* keymask;
+  float* lse;
+  void* out; int64_t ld_out;
+  const void* dout; int64_t ld_dout;
+  void* dqkv; int64_t ld_dqkv;
+  float* delta;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------ fwd_stats
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16;
+  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * DH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int64_t S = a.S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* Kg = base + a.k_off;
+  const T* Qg = base + a.q_off;
+  const int64_t k_lane = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32 + (lane & 31);
+
+  typename Act<T>::vec8 kf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
+  const float madd = (k_lane < S && a.keymask[b * S + k_lane]) ? 0.f : MASK_VALUE;
+
+  float m = NEG_BIG, l = 0.f;
+  for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
+    __syncthreads();
+    stage_rows<T, DH>(sQ, Qg, a.ld_qkv, q0, S, tid);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
+      if (q0 + blk * 32 >= S) break;
+      f32x16 x = zero16<DH>();
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, blk * 32, s, lane), kf[s], x);
+      float t[16], tmax = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
+        t[r] = valid ? x[r] * a.scale + madd : NEG_BIG;
+        tmax = fmaxf(tmax, t[r]);
+      }
+      const float m_new = fmaxf(m, tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
+      l = l * __expf(m - m_new) + sum;
+      m = m_new;
+    }
+  }
+  // the two lane halves hold disjoint query subsets of the same key
+  const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+  const float M = fmaxf(m, m2);
+  const float L = l * __expf(m - M) + l2 * __expf(m2 - M);
+  if (lane < 32 && k_lane < S) a.lse[bh * S + k_lane] = M + __logf(L);
+}
+
+// ------------------------------------------------------------------------------------ fwd_out
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
+  __shared__ float sLse[ATT_STAGE], sMadd[ATT_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int64_t S = a.S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* Kg = base + a.k_off;
+  const T* Qg = base + a.q_off;
+  const T* Vg = base + a.v_off;
+  const int64_t q_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t q_lane = q_wave0 + (lane & 31);
+
+  typename Act<T>::vec8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
+
+  for (int64_t k0 = 0; k0 < S; k0 += ATT_STAGE) {
+    __syncthreads();
+    stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
+    stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    if (tid < ATT_STAGE) {
+      const int64_t k = k0 + tid;
+      sLse[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
+      if (k0 + blk * 32 >= S) break;
+      f32x16 x = zero16<DH>();
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sK, blk * 32, s, lane), qf[s], x);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = blk * 32 + acc_row(r, lane);
+        x[r] = (k0 + kr < S) ? __expf(x[r] * a.scale + sMadd[kr] - sLse[kr]) : 0.f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(sV, blk * 32, s2, d * 32, lane), o[d]);
+      }
+    }
+  }
+  T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
+#pragma unroll
+  for (int d = 0; d < DB; ++d) {
+    const int col = d * 32 + (lane & 31);
+    if (col < DH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t q = q_wave0 + acc_row(r, lane);
+        if (q < S) og[q * a.ld_out + col] = (T)o[d][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ bwd_kv
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sdO[ATT_STAGE * DH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int64_t S = a.S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* Kg = base + a.k_off;
+  const T* Qg = base + a.q_off;
+  const T* Vg = base + a.v_off;
+  const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
+  const int64_t k_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t k_lane = k_wave0 + (lane & 31);
+
+  typename Act<T>::vec8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
+    vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
+  }
+  const float madd = (k_lane < S && a.keymask[b * S + k_lane]) ? 0.f : MASK_VALUE;
+  const float lse = (k_lane < S) ? a.lse[bh * S + k_lane] : 0.f;
+
+  f32x16 acc[DB];
+  float delta = 0.f;
+  // pass 0: dV and delta; pass 1: dK
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+    for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
+      __syncthreads();
+      stage_rows<T, DH>(sQ, Qg, a.ld_qkv, q0, S, tid);
+      stage_rows<T, DH>(sdO, dOg, a.ld_dout, q0, S, tid);
+      __syncthreads();
+#pragma unroll
+      for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
+        if (q0 + blk * 32 >= S) break;
+        f32x16 x = zero16<DH>(), dp = zero16<DH>();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, blk * 32, s, lane), kf[s], x);
+          dp = Act<T>::mfma32(lds_row_frag<T, DH>(sdO, blk * 32, s, lane), vf[s], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
+          const float p = valid ? __expf(x[r] * a.scale + madd - lse) : 0.f;
+          if (pass == 0) {
+            delta += p * dp[r];
+            x[r] = p;
+          } else {
+            x[r] = p * (dp[r] - delta) * a.scale;
+          }
+        }
+        const T* tr_src = (pass == 0) ? sdO : sQ;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+            acc[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(tr_src, blk * 32, s2, d * 32, lane), acc[d]);
+        }
+      }
+    }
+    if (pass == 0) {
+      delta += __shfl_xor(delta, 32, 64);
+      if (lane < 32 && k_lane < S) a.delta[bh * S + k_lane] = delta;
+    }
+    T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + (pass == 0 ? a.v_off : a.k_off);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int col = d * 32 + (lane & 31);
+      if (col < DH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t k = k_wave0 + acc_row(r, lane);
+          if (k < S) dst[k * a.ld_dqkv + col] = (T)acc[d][r];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ bwd_q
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
+  __shared__ float sLse[ATT_STAGE], sMadd[ATT_STAGE], sDelta[ATT_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int64_t S = a.S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* Kg = base + a.k_off;
+  const T* Qg = base + a.q_off;
+  const T* Vg = base + a.v_off;
+  const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
+  const int64_t q_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t q_lane = q_wave0 + (lane & 31);
+
+  typename Act<T>::vec8 qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
+    dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, S, s, lane);
+  }
+  f32x16 acc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+
+  for (int64_t k0 = 0; k0 < S; k0 += ATT_STAGE) {
+    __syncthreads();
+    stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
+    stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    if (tid < ATT_STAGE) {
+      const int64_t k = k0 + tid;
+      sLse[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sDelta[tid] = (k < S) ? a.delta[bh * S + k] : 0.f;
+      sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
+      if (k0 + blk * 32 >= S) break;
+      f32x16 x = zero16<DH>(), dp = zero16<DH>();
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        x = Act<T>::mfma32(lds_row_frag<T, DH>(sK, blk * 32, s, lane), qf[s], x);
+        dp = Act<T>::mfma32(lds_row_frag<T, DH>(sV, blk * 32, s, lane), dof[s], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = blk * 32 + acc_row(r, lane);
+        const float p = (k0 + kr < S) ? __expf(x[r] * a.scale + sMadd[kr] - sLse[kr]) : 0.f;
+        x[r] = p * (dp[r] - sDelta[kr]) * a.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(sK, blk * 32, s2, d * 32, lane), acc[d]);
+      }
+    }
+  }
+  T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + a.q_off;
+#pragma unroll
+  for (int d = 0; d < DB; ++d) {
+    const int col = d * 32 + (lane & 31);
+    if (col < DH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t q = q_wave0 + acc_row(r, lane);
+        if (q < S) dst[q * a.ld_dqkv + col] = (T)acc[d][r];
+      }
+    }
+  }
+}
+
+static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off) {
+  MST_CHECK_ARG(B > 0 && S > 0 && H > 0, "attention: B,S,H must be positive");
+  MST_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "attention: head size must be 16, 32 or 64 (got %lld)", (long long)dh);
+  MST_CHECK_ARG(ld % 8 == 0 && k_off % 8 == 0 && q_off % 8 == 0 && v_off % 8 == 0, "attention: ld and offsets must be multiples of 8");
+  MST_CHECK_ARG(B * H <= 65535, "attention: B*H too large for grid.y");
+  return MST_OK;
+}
+
+template <typename T, int DH>
+static int launch_fwd(const AttnArgs& a, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
+  hipLaunchKernelGGL((attn_fwd_stats_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  MST_CHECK_LAUNCH("attn_fwd_stats_kernel");
+  hipLaunchKernelGGL((attn_fwd_out_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  MST_CHECK_LAUNCH("attn_fwd_out_kernel");
+  return MST_OK;
+}
+template <typename T, int DH>
+static int launch_bwd(const AttnArgs& a, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  MST_CHECK_LAUNCH("attn_bwd_kv_kernel");
+  hipLaunchKernelGGL((attn_bwd_q_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  MST_CHECK_LAUNCH("attn_bwd_q_kernel");
+  return MST_OK;
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* qkv,
+                                       int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                                       const uint8_t* keymask, float* lse, void* out, int64_t ld_out,
+                                       mst_stream_t stream) {
+  int rc = attn_check(B, S, H, dh, ld_qkv, k_off, q_off, v_off);
+  if (rc) return rc;
+  MST_CHECK_ARG(qkv && keymask && lse && out, "mst_attn_keysoftmax_fwd: null pointer");
+  MST_CHECK_ARG(ld_out >= H * dh, "mst_attn_keysoftmax_fwd: ld_out < H*dh");
+  AttnArgs a = {};
+  a.B = B; a.S = S; a.H = H; a.qkv = qkv; a.ld_qkv = ld_qkv; a.k_off = k_off; a.q_off = q_off; a.v_off = v_off;
+  a.keymask = keymask; a.lse = lse; a.out = out; a.ld_out = ld_out;
+  a.scale = 1.f / sqrtf((float)dh);
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    if (dh == 16) return launch_fwd<T, 16>(a, s);
+    if (dh == 32) return launch_fwd<T, 32>(a, s);
+    return launch_fwd<T, 64>(a, s);
+  });
+}
+
+extern "C" int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* qkv,
+                                       int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                                       const uint8_t* keymask, const float* lse, const void* dout, int64_t ld_dout,
+                                       void* dqkv, int64_t ld_dqkv, float* delta, mst_stream_t stream) {
+  int rc = attn_check(B, S, H, dh, ld_qkv, k_off, q_off, v_off);
+  if (rc) return rc;
+  MST_CHECK_ARG(qkv && keymask && lse && dout && dqkv && delta, "mst_attn_keysoftmax_bwd: null pointer");
+  MST_CHECK_ARG(ld_dout % 8 == 0 && ld_dout >= H * dh && ld_dqkv % 8 == 0, "mst_attn_keysoftmax_bwd: bad leading dims");
+  AttnArgs a = {};
+  a.B = B; a.S = S; a.H = H; a.qkv = qkv; a.ld_qkv = ld_qkv; a.k_off = k_off; a.q_off = q_off; a.v_off = v_off;
+  a.keymask = keymask; a.lse = const_cast<float*>(lse); a.dout = dout; a.ld_dout = ld_dout; a.dqkv = dqkv;
+  a.ld_dqkv = ld_dqkv; a.delta = delta;
+  a.scale = 1.f / sqrtf((float)dh);
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    if (dh == 16) return launch_bwd<T, 16>(a, s);
+    if (dh == 32) return launch_bwd<T, 32>(a, s);
+    return launch_bwd<T, 64>(a, s);
+  });
+}

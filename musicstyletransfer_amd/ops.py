@@ -1,0 +1,285 @@
+"""Thin torch-tensor front end over the C-ABI (include/mst_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every function below passes raw
+`data_ptr()`s, sizes and the current HIP stream to libmst_hip.so. Nothing in this module computes
+on the CPU or through torch operators — if the library or a GPU is missing, calls raise.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+
+_DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
+
+
+def dt(x):
+    try:
+        return _DT[x if isinstance(x, torch.dtype) else x.dtype]
+    except KeyError:
+        raise TypeError(f"activation dtype must be bfloat16 or float16, got {x}") from None
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "mst ops need device tensors (there is no CPU fallback)"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+def ld(t):
+    """leading dimension (elements) of a 2-D row-major view"""
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+# --------------------------------------------------------------------------- GEMMs
+def gemm_nt(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_NONE, gate=None, alpha=1.0,
+            rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
+            dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False):
+    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T); see mst_gemm_args in include/mst_hip.h."""
+    g = GemmArgs()
+    g.dtype = dt(A)
+    g.c_f32 = 1 if C_out.dtype == torch.float32 else 0
+    g.M = A.shape[0] if M is None else M
+    g.N = B.shape[0] if N is None else N
+    g.K = A.shape[1] if K is None else K
+    g.A, g.lda = ptr(A), ld(A)
+    g.B, g.ldb = ptr(B), ld(B)
+    g.C, g.ldc = ptr(C_out), ld(C_out)
+    g.bias = ptr(bias)
+    g.resid, g.ldr = ptr(resid), (ld(resid) if resid is not None else 0)
+    g.act = act
+    g.gate, g.ldg = ptr(gate), (ld(gate) if gate is not None else 0)
+    g.alpha = alpha
+    g.rowadd, g.ldra = ptr(rowadd), (ld(rowadd) if rowadd is not None else 0)
+    g.rowadd_period = rowadd_period
+    g.grpadd, g.ldga = ptr(grpadd), (ld(grpadd) if grpadd is not None else 0)
+    g.grp_index = ptr(grp_index)
+    g.a_rows_per_group, g.a_group_stride, g.a_group_offset = a_remap
+    g.c_rows_per_group, g.c_group_stride, g.c_group_offset = c_remap
+    g.dropout_p, g.dropout_seed, g.dropout_site = dropout_p, dropout_seed, dropout_site
+    g.self_resid = 1 if self_resid else 0
+    call("mst_gemm_nt", C.byref(g), stream())
+
+
+def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=(0, 0, 0), b_remap=(0, 0, 0)):
+    w = WgradArgs()
+    w.dtype = dt(A)
+    w.M = A.shape[0] if M is None else M
+    w.N = dW.shape[0] if N is None else N
+    w.K = dW.shape[1] if K is None else K
+    w.A, w.lda = ptr(A), ld(A)
+    w.B, w.ldb = ptr(B), ld(B)
+    w.dW, w.ldw = ptr(dW), ld(dW)
+    w.db = ptr(db)
+    w.scale = scale
+    w.a_rows_per_group, w.a_group_stride, w.a_group_offset = a_remap
+    w.b_rows_per_group, w.b_group_stride, w.b_group_offset = b_remap
+    return w
+
+
+def gemm_wgrad_batch(problems):
+    """dW_i[N,K] += A_i^T @ B_i for up to 8 problems in one launch."""
+    arr = (WgradArgs * len(problems))(*problems)
+    call("mst_gemm_wgrad_batch", arr, len(problems), stream())
+
+
+def gemm_wgrad(A, B, dW, db=None, **kw):
+    gemm_wgrad_batch([wgrad_problem(A, B, dW, db, **kw)])
+
+
+# --------------------------------------------------------------------------- attention
+def attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off):
+    call("mst_attn_keysoftmax_fwd", dt(qkv), B, S, H, dh, ptr(qkv), ld(qkv), k_off, q_off, v_off, ptr(keymask),
+         ptr(lse), ptr(out), ld(out), stream())
+
+
+def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off):
+    call("mst_attn_keysoftmax_bwd", dt(qkv), B, S, H, dh, ptr(qkv), ld(qkv), k_off, q_off, v_off, ptr(keymask),
+         ptr(lse), ptr(dout), ld(dout), ptr(dqkv), ld(dqkv), ptr(delta), stream())
+
+
+# --------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5):
+    M = x.shape[0]
+    D = x.shape[1] if D is None else D
+    call("mst_layernorm_fwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(beta), eps, ptr(y), ld(y), ptr(mean),
+         ptr(rstd), stream())
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, D=None, dx_masked=None, mask_mode=0, dropout_p=0.0,
+                  dropout_seed=0, dropout_site=0):
+    M = x.shape[0]
+    D = x.shape[1] if D is None else D
+    call("mst_layernorm_bwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ld(dy), ptr(dx),
+         ld(dx), ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0), ptr(dgamma), ptr(dbeta), mask_mode,
+         dropout_p, dropout_seed, dropout_site, stream())
+
+
+# --------------------------------------------------------------------------- embedding / masks
+def embed_fwd(tokens, table, pos, out3, s_off, alpha, classes=None, cls_table=None, keymask=None):
+    """out3: [B, S_out, ld] activation buffer; tokens int32 [B, T]."""
+    B, T = tokens.shape
+    D = table.shape[1]
+    call("mst_embed_fwd", dt(out3), B, T, D, ptr(tokens), ptr(table), table.stride(0), ptr(classes), ptr(cls_table),
+         (cls_table.stride(0) if cls_table is not None else 0), ptr(pos), pos.stride(0), alpha, ptr(out3),
+         out3.stride(1), out3.shape[1], s_off, ptr(keymask), stream())
+
+
+def embed_bwd(tokens, dtable, dX3, s_off, alpha, classes=None, dcls=None):
+    B, T = tokens.shape
+    D = dtable.shape[1]
+    call("mst_embed_bwd", dt(dX3), B, T, D, ptr(tokens), ptr(dtable), dtable.stride(0), ptr(classes), ptr(dcls),
+         (dcls.stride(0) if dcls is not None else 0), alpha, ptr(dX3), dX3.stride(1), dX3.shape[1], s_off, stream())
+
+
+def group_colsum(X3, T, D, s_off, idx, dst, alpha):
+    B = X3.shape[0]
+    call("mst_group_colsum", dt(X3), B, T, D, ptr(X3), X3.stride(1), X3.shape[1], s_off, ptr(idx), ptr(dst),
+         dst.stride(0), alpha, stream())
+
+
+def mask_from_lengths(lens, add, keymask):
+    B, S = keymask.shape
+    call("mst_mask_from_lengths", B, S, ptr(lens), add, ptr(keymask), stream())
+
+
+# --------------------------------------------------------------------------- latent block
+def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in3):
+    B = enc_out3.shape[0]
+    De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
+    call("mst_latent_fwd", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
+         ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
+         ptr(kl), ptr(dec_in3), dec_in3.stride(0), stream())
+
+
+def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d, kl_weight, gscale, dWl, dbl, dWh, dbh,
+               dcls_d, d_enc_out3, scratch):
+    B = enc_out3.shape[0]
+    De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
+    call("mst_latent_bwd", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(eps), ptr(Wh),
+         ptr(classes), ptr(mu), ptr(sigma), ptr(z), ptr(d_dec_in3), d_dec_in3.stride(0), alpha_d, kl_weight, gscale,
+         ptr(dWl), ptr(dbl), ptr(dWh), ptr(dbh), ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3), d_enc_out3.stride(0),
+         ptr(scratch), stream())
+
+
+def reparam_kl_fwd(mu, sigma, eps, z, kl):
+    B, Z = mu.shape
+    call("mst_reparam_kl_fwd", B, Z, ptr(mu), ptr(sigma), ptr(eps), ptr(z), ptr(kl), stream())
+
+
+def reparam_kl_bwd(mu, sigma, eps, dz, kl_weight, dmu, dsigma):
+    B, Z = mu.shape
+    call("mst_reparam_kl_bwd", B, Z, ptr(mu), ptr(sigma), ptr(eps), ptr(dz), kl_weight, ptr(dmu), ptr(dsigma), stream())
+
+
+# --------------------------------------------------------------------------- loss heads
+def softmax_ce(logits, labels, loss, B, T, V, probs=None, dlogits=None, gscale=1.0):
+    call("mst_softmax_ce", dt(logits), B, T, V, ptr(logits), ld(logits), ptr(labels), ptr(loss), ptr(probs),
+         (ld(probs) if probs is not None else 0), ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale,
+         stream())
+
+
+def sigmoid_bce(logits, labels, loss, B, T, P, label_smoothing=0.0, downweight=False, npos=None, probs=None,
+                dlogits=None, gscale=1.0):
+    call("mst_sigmoid_bce", dt(logits), B, T, P, ptr(logits), ld(logits), ptr(labels), label_smoothing,
+         1 if downweight else 0, ptr(npos), ptr(loss), ptr(probs), (ld(probs) if probs is not None else 0),
+         ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale, stream())
+
+
+def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None):
+    call("mst_loss_combine", recon.shape[0], ptr(recon), ptr(kl), kl_weight, ptr(total), ptr(metric_acc), stream())
+
+
+# --------------------------------------------------------------------------- optimizer / shadows
+def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0):
+    call("mst_adam_flat", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd,
+         rescale, clip, ptr(step_state), stream())
+
+
+def transpose_shadows(w, wt16, desc, tile_prefix, n_mat, total_tiles):
+    call("mst_transpose_shadows", dt(wt16), ptr(w), ptr(wt16), ptr(desc), ptr(tile_prefix), n_mat, total_tiles, stream())
+
+
+def cast_to_act(src, dst):
+    call("mst_cast_f32_to_act", dt(dst), src.numel(), ptr(src), ptr(dst), stream())
+
+
+def add_act(a, b, y):
+    call("mst_add_act", dt(a), a.numel(), ptr(a), ptr(b), ptr(y), stream())
+
+
+def dropout_mask(n, p, seed, site, keep):
+    call("mst_dropout_mask", n, p, seed, site, ptr(keep), stream())
+
+
+def selftest():
+    flags = torch.zeros(4, dtype=torch.int32, device="cuda")
+    call("mst_selftest", ptr(flags), stream())
+    torch.cuda.synchronize()
+    return flags.cpu().tolist()
+
+
+# --------------------------------------------------------------------------- graphs / events
+class Graph:
+    """hipGraph captured on the current torch stream through the library's own capture helpers."""
+
+    def __init__(self):
+        self.exec = C.c_void_p()
+
+    def capture(self, fn):
+        st = stream()
+        call("mst_graph_begin", st)
+        try:
+            fn()
+        finally:
+            call("mst_graph_end", st, C.byref(self.exec))
+        return self
+
+    def launch(self):
+        call("mst_graph_launch", self.exec, stream())
+
+    def __del__(self):
+        try:
+            if self.exec:
+                _lib.load().mst_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p()
+        call("mst_event_create", C.byref(self.ev))
+
+    def record(self):
+        call("mst_event_record", self.ev, stream())
+
+    def sync(self):
+        call("mst_event_sync", self.ev)
+
+    def elapsed_ms(self, later):
+        ms = C.c_float()
+        call("mst_event_elapsed_ms", self.ev, later.ev, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().mst_event_destroy(self.ev)
+        except Exception:
+            pass
+
+
+def sqrt_d(d):
+    return math.sqrt(float(d))

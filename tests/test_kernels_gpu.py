@@ -1,0 +1,592 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain torch fp32 reference of
+the same operator on the same (16-bit-rounded) inputs. Tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def ops():
+    from musicstyletransfer_amd import ops as o
+    return o
+
+
+def rnd(shape, dev, scale=1.0, dtype=BF, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} out of tolerance, max err {err.max().item():.4g}, ref max {b.abs().max().item():.4g}"
+
+
+# ------------------------------------------------------------------------------------------ layout
+def test_selftest_layout_maps(gpu):
+    flags = ops().selftest()
+    assert flags == [1, 1, 1, 1], f"MFMA / ds_read_tr16_b64 lane maps differ from the ones the kernels assume: {flags}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (16384, 256, 256), (1000, 96, 160), (15, 10, 32), (16448, 128, 128),
+                                   (2048, 1024, 256), (512, 296, 128)])
+def test_gemm_nt_plain(gpu, M, N, K):
+    o = ops()
+    A = rnd((M, K), gpu, seed=1)
+    B = rnd((N, K), gpu, seed=2)
+    ldc = o.roundup(N, 8)
+    C = torch.full((M, ldc), 7.0, dtype=BF, device=gpu)
+    o.gemm_nt(A, B, C, N=N)
+    torch.cuda.synchronize()
+    ref = A.float() @ B.float().t()
+    # bf16 output rounding: 2^-8 relative; fp32 accumulation over K
+    close(C[:, :N], ref, 1e-2, 1e-2 * math.sqrt(K), "gemm_nt")
+    n4 = min(o.roundup(N, 4), ldc)
+    assert (C[:, N:n4] == 0).all(), "pad columns up to roundup4(N) must be written as zeros"
+
+
+def test_gemm_nt_integer_exact_asymmetric(gpu):
+    """small-integer operands: exact in bf16 and fp32, catches any transposed / permuted fragment"""
+    o = ops()
+    M, N, K = 192, 160, 96
+    i = torch.arange(M).view(-1, 1)
+    k = torch.arange(K).view(1, -1)
+    A = (((i * 3 + k * 5) % 7) - 3).to(BF).to(gpu)
+    n = torch.arange(N).view(-1, 1)
+    B = (((n * 2 + k * 7) % 5) - 2).to(BF).to(gpu)
+    C = torch.zeros(M, N, dtype=torch.float32, device=gpu)
+    o.gemm_nt(A, B, C)
+    torch.cuda.synchronize()
+    ref = A.float() @ B.float().t()
+    assert torch.equal(C, ref)
+
+
+def test_gemm_nt_epilogue(gpu):
+    o = ops()
+    Bsz, S, N, K = 6, 50, 72, 64
+    M = Bsz * S
+    A = rnd((M, K), gpu, seed=3)
+    W = rnd((N, K), gpu, seed=4, scale=0.2)
+    bias = rnd((N,), gpu, dtype=torch.float32, seed=5)
+    resid = rnd((M, N), gpu, seed=6)
+    gate = rnd((M, N), gpu, seed=7)
+    pos = rnd((S, N), gpu, dtype=torch.float32, seed=8)
+    cls = rnd((3, N), gpu, dtype=torch.float32, seed=9)
+    classes = torch.tensor([0, 2, 1, 1, 0, 2], dtype=torch.int32, device=gpu)
+    C = torch.zeros(M, N, dtype=BF, device=gpu)
+    o.gemm_nt(A, W, C, bias=bias, resid=resid, act=o.ACT_RELU, gate=gate, alpha=1.7, rowadd=pos, rowadd_period=S,
+              grpadd=cls, grp_index=classes)
+    torch.cuda.synchronize()
+    t = A.float() @ W.float().t() + bias + cls[classes.long()].repeat_interleave(S, 0)
+    t = torch.relu(t * 1.7) + pos.repeat(Bsz, 1) + resid.float()
+    ref = torch.where(gate.float() > 0, t, torch.zeros_like(t))
+    close(C, ref, 1e-2, 2e-2, "gemm_nt epilogue")
+
+
+def test_gemm_nt_row_remaps_and_f32_out(gpu):
+    o = ops()
+    Bsz, T, N, K = 5, 9, 40, 32
+    # A rows live in a [B, T+1, K] buffer at offset 1 (decoder output with row 0 dropped, model.py:253)
+    Abuf = rnd((Bsz * (T + 1), K), gpu, seed=10)
+    W = rnd((N, K), gpu, seed=11)
+    Cbuf = torch.zeros(Bsz * (T + 1), N, dtype=torch.float32, device=gpu)
+    o.gemm_nt(Abuf, W, Cbuf, M=Bsz * T, a_remap=(T, T + 1, 1), c_remap=(T, T + 1, 1))
+    torch.cuda.synchronize()
+    A3 = Abuf.view(Bsz, T + 1, K)[:, 1:, :].float()
+    ref = A3 @ W.float().t()
+    got = Cbuf.view(Bsz, T + 1, N)
+    close(got[:, 1:, :], ref, 1e-5, 1e-4, "remap")
+    assert (got[:, 0, :] == 0).all()
+
+
+def test_gemm_nt_dropout_matches_mask_kernel(gpu):
+    o = ops()
+    M, N, K = 300, 64, 64
+    A = rnd((M, K), gpu, seed=12)
+    W = rnd((N, K), gpu, seed=13)
+    C = torch.zeros(M, N, dtype=torch.float32, device=gpu)
+    p, seed, site = 0.2, 1234567, 3
+    o.gemm_nt(A, W, C, dropout_p=p, dropout_seed=seed, dropout_site=site)
+    keep = torch.zeros(M * N, dtype=torch.uint8, device=gpu)
+    o.dropout_mask(M * N, p, seed, site, keep)
+    torch.cuda.synchronize()
+    ref = (A.float() @ W.float().t()) * keep.view(M, N).float() / (1 - p)
+    close(C, ref, 1e-5, 1e-4, "dropout")
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.8) < 0.01
+    C2 = torch.zeros_like(C)
+    o.gemm_nt(A, W, C2, dropout_p=p, dropout_seed=seed, dropout_site=site, self_resid=True)
+    torch.cuda.synchronize()
+    t = A.float() @ W.float().t()
+    close(C2, t + t * keep.view(M, N).float() / (1 - p), 1e-5, 1e-4, "self_resid")
+
+
+# ------------------------------------------------------------------------------------------ wgrad
+@pytest.mark.parametrize("M,N,K", [(512, 64, 64), (16384, 256, 256), (4097, 128, 1024), (100, 16, 32), (16448, 384, 128)])
+def test_gemm_wgrad(gpu, M, N, K):
+    o = ops()
+    dY = rnd((M, N), gpu, seed=20, scale=0.1)
+    X = rnd((M, K), gpu, seed=21)
+    dW = torch.zeros(N, K, dtype=torch.float32, device=gpu)
+    db = torch.zeros(N, dtype=torch.float32, device=gpu)
+    o.gemm_wgrad(dY, X, dW, db)
+    torch.cuda.synchronize()
+    ref = dY.float().t() @ X.float()
+    refb = dY.float().sum(0)
+    close(dW, ref, 2e-3, 2e-3 * math.sqrt(M) * 0.1, "wgrad dW")
+    close(db, refb, 2e-3, 2e-3 * math.sqrt(M) * 0.1, "wgrad db")
+
+
+def test_gemm_wgrad_integer_exact_and_batch(gpu):
+    o = ops()
+    M = 200
+    m = torch.arange(M).view(-1, 1)
+    probs, refs, outs = [], [], []
+    for (N, K, s) in [(32, 48, 1.0), (72, 16, 2.0), (8, 8, 1.0)]:
+        A = (((m * 3 + torch.arange(N).view(1, -1) * 5) % 7) - 3).to(BF).to(gpu)
+        B = (((m * 2 + torch.arange(K).view(1, -1) * 7) % 5) - 2).to(BF).to(gpu)
+        dW = torch.zeros(N, K, dtype=torch.float32, device=gpu)
+        db = torch.zeros(N, dtype=torch.float32, device=gpu)
+        probs.append(o.wgrad_problem(A, B, dW, db, scale=s))
+        refs.append((s * (A.float().t() @ B.float()), s * A.float().sum(0)))
+        outs.append((dW, db, A, B))
+    o.gemm_wgrad_batch(probs)
+    torch.cuda.synchronize()
+    for (dW, db, _, _), (rw, rb) in zip(outs, refs):
+        assert torch.equal(dW, rw)
+        assert torch.equal(db, rb)
+
+
+def test_gemm_wgrad_remap(gpu):
+    o = ops()
+    Bsz, T, N, K = 4, 33, 24, 40
+    dYbuf = rnd((Bsz * (T + 1), N), gpu, seed=22)
+    X = rnd((Bsz * T, K), gpu, seed=23)
+    dW = torch.zeros(N, K, dtype=torch.float32, device=gpu)
+    o.gemm_wgrad(dYbuf, X, dW, M=Bsz * T, a_remap=(T, T + 1, 1))
+    torch.cuda.synchronize()
+    dY = dYbuf.view(Bsz, T + 1, N)[:, 1:, :].reshape(Bsz * T, N).float()
+    close(dW, dY.t() @ X.float(), 1e-4, 1e-2, "wgrad remap")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_reference(qkv, keymask, B, S, H, dh, k_off, q_off, v_off):
+    """fp32 restatement of transformer.py:85-104 (key-row softmax, P^T V, -1e9 on padded key rows)"""
+    x = qkv.float().view(B, S, -1)
+    D = H * dh
+
+    def heads(off):
+        return x[:, :, off:off + D].reshape(B, S, H, dh).permute(0, 2, 1, 3)
+
+    K, Q, V = heads(k_off), heads(q_off), heads(v_off)
+    logits = torch.matmul(K, Q.transpose(-1, -2)) / math.sqrt(dh)  # [B,H,k,q]
+    madd = torch.where(keymask.view(B, 1, S, 1) > 0, 0.0, -1e9).to(torch.float32)
+    logits = logits + madd
+    P = torch.softmax(logits, dim=-1)
+    O = torch.matmul(P.transpose(-1, -2), V)  # [B,H,q,dh]
+    return O.permute(0, 2, 1, 3).reshape(B * S, D), torch.logsumexp(logits, dim=-1)
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 64, 2, 32), (3, 5, 2, 16), (2, 257, 8, 16), (2, 256, 8, 32), (1, 100, 1, 64),
+                                     (1, 1024, 2, 32)])
+def test_attention_fwd_bwd(gpu, B, S, H, dh):
+    o = ops()
+    D = H * dh
+    ldq = 3 * D
+    qkv = rnd((B * S, ldq), gpu, seed=30, scale=1.0)
+    lens = torch.tensor([S - (i * 7) % max(1, S // 2) for i in range(B)], dtype=torch.int32, device=gpu)
+    keymask = torch.zeros(B, S, dtype=torch.uint8, device=gpu)
+    o.mask_from_lengths(lens, 0, keymask)
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+    out = torch.zeros(B * S, D, dtype=BF, device=gpu)
+    k_off, q_off, v_off = 0, D, 2 * D
+    o.attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off)
+    torch.cuda.synchronize()
+    assert keymask.sum().item() == int(lens.sum().item())
+
+    qkv_ref = qkv.float().clone().requires_grad_(True)
+    ref, lse_ref = attn_reference(qkv_ref, keymask, B, S, H, dh, k_off, q_off, v_off)
+    close(lse, lse_ref.detach(), 1e-4, 2e-3, "lse")
+    close(out, ref.detach(), 1.6e-2, 1.6e-2, "attention out")
+
+    dout = rnd((B * S, D), gpu, seed=31, scale=1.0)
+    dqkv = torch.zeros(B * S, ldq, dtype=BF, device=gpu)
+    delta = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+    o.attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off)
+    torch.cuda.synchronize()
+    ref.backward(dout.float())
+    g = qkv_ref.grad
+    scale = g.abs().max().item()
+    close(dqkv[:, v_off:v_off + D], g[:, v_off:v_off + D], 2e-2, 2e-2 * scale, "dV")
+    close(dqkv[:, k_off:k_off + D], g[:, k_off:k_off + D], 3e-2, 3e-2 * scale, "dK")
+    close(dqkv[:, q_off:q_off + D], g[:, q_off:q_off + D], 3e-2, 3e-2 * scale, "dQ")
+
+
+def test_attention_padded_key_rows_are_uniform(gpu):
+    """a padded key row is NOT excluded, it contributes V[k]/S to every query"""
+    o = ops()
+    B, S, H, dh = 1, 32, 1, 16
+    D = H * dh
+    qkv = rnd((B * S, 3 * D), gpu, seed=33)
+    keymask = torch.zeros(B, S, dtype=torch.uint8, device=gpu)  # every key padded
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+    out = torch.zeros(B * S, D, dtype=BF, device=gpu)
+    o.attn_fwd(qkv, keymask, lse, out, B, S, H, dh, 0, D, 2 * D)
+    torch.cuda.synchronize()
+    vmean_times_1 = qkv[:, 2 * D:].float().sum(0) / S  # sum_k V[k] / S
+    close(out, vmean_times_1.expand(S, D), 1e-2, 1e-2, "uniform rows")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(1000, 256), (77, 128), (16, 32), (300, 1024)])
+def test_layernorm_fwd_bwd(gpu, M, D):
+    o = ops()
+    x = rnd((M, D), gpu, seed=40, scale=2.0)
+    gamma = (1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=41)).contiguous()
+    beta = rnd((D,), gpu, dtype=torch.float32, seed=42, scale=0.1)
+    y = torch.zeros(M, D, dtype=BF, device=gpu)
+    mean = torch.zeros(M, dtype=torch.float32, device=gpu)
+    rstd = torch.zeros(M, dtype=torch.float32, device=gpu)
+    o.layernorm_fwd(x, gamma, beta, y, mean, rstd)
+    xr = x.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    torch.cuda.synchronize()
+    close(y, ref.detach(), 1e-2, 1e-2, "ln fwd")
+    close(mean, x.float().mean(1), 1e-5, 1e-5, "mean")
+    dy = rnd((M, D), gpu, seed=43)
+    dx = torch.zeros(M, D, dtype=BF, device=gpu)
+    dg = torch.zeros(D, dtype=torch.float32, device=gpu)
+    db = torch.zeros(D, dtype=torch.float32, device=gpu)
+    o.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db)
+    torch.cuda.synchronize()
+    ref.backward(dy.float())
+    close(dx, xr.grad, 1e-2, 1e-2, "ln dx")
+    close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dgamma")
+    close(db, br.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dbeta")
+
+
+def test_layernorm_bwd_dropout_modes(gpu):
+    o = ops()
+    M, D = 64, 128
+    x = rnd((M, D), gpu, seed=44)
+    gamma = torch.ones(D, device=gpu)
+    beta = torch.zeros(D, device=gpu)
+    y = torch.zeros(M, D, dtype=BF, device=gpu)
+    mean = torch.zeros(M, device=gpu)
+    rstd = torch.zeros(M, device=gpu)
+    o.layernorm_fwd(x, gamma, beta, y, mean, rstd)
+    dy = rnd((M, D), gpu, seed=45)
+    dx0 = torch.zeros(M, D, dtype=BF, device=gpu)
+    dg = torch.zeros(D, device=gpu)
+    db = torch.zeros(D, device=gpu)
+    o.layernorm_bwd(x, gamma, mean, rstd, dy, dx0, dg, db)
+    p, seed, site = 0.25, 99, 5
+    keep = torch.zeros(M * D, dtype=torch.uint8, device=gpu)
+    o.dropout_mask(M * D, p, seed, site, keep)
+    k = keep.view(M, D).float() / (1 - p)
+    dx1 = torch.zeros_like(dx0)
+    dxm = torch.zeros_like(dx0)
+    o.layernorm_bwd(x, gamma, mean, rstd, dy, dx1, dg, db, dx_masked=dxm, mask_mode=1, dropout_p=p, dropout_seed=seed,
+                    dropout_site=site)
+    dx2 = torch.zeros_like(dx0)
+    o.layernorm_bwd(x, gamma, mean, rstd, dy, dx2, dg, db, mask_mode=2, dropout_p=p, dropout_seed=seed, dropout_site=site)
+    dx3 = torch.zeros_like(dx0)
+    o.layernorm_bwd(x, gamma, mean, rstd, dy, dx3, dg, db, mask_mode=2)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    close(dxm, dx0.float() * k, 1e-2, 1e-3, "masked copy")
+    close(dx2, dx0.float() * (1 + k), 1.6e-2, 1e-3, "self-resid mode")
+    close(dx3, dx0.float() * 2, 1e-2, 1e-3, "self-resid p=0")
+
+
+# ------------------------------------------------------------------------------------------ embedding
+def test_embed_fwd_bwd(gpu):
+    o = ops()
+    B, T, D, V, Cn = 4, 7, 32, 11, 3
+    S_out, s_off = T + 1, 1
+    tokens = torch.randint(0, V, (B, T), dtype=torch.int32).to(gpu)
+    classes = torch.tensor([0, 1, 2, 1], dtype=torch.int32, device=gpu)
+    table = rnd((V, D), gpu, dtype=torch.float32, seed=50)
+    cls = rnd((Cn, D), gpu, dtype=torch.float32, seed=51)
+    pos = rnd((S_out, D), gpu, dtype=torch.float32, seed=52)
+    out = torch.zeros(B, S_out, D, dtype=BF, device=gpu)
+    km = torch.zeros(B, S_out, dtype=torch.uint8, device=gpu)
+    alpha = math.sqrt(D)
+    o.embed_fwd(tokens, table, pos, out, s_off, alpha, classes=classes, cls_table=cls, keymask=km)
+    torch.cuda.synchronize()
+    ref = alpha * (table[tokens.long()] + cls[classes.long()].unsqueeze(1)) + pos[s_off:s_off + T]
+    close(out[:, s_off:], ref, 1e-2, 1e-2, "embed fwd")
+    assert (out[:, 0] == 0).all()
+    assert torch.equal(km[:, s_off:], (tokens != 0).to(torch.uint8))
+    dX = rnd((B, S_out, D), gpu, seed=53)
+    dtab = torch.zeros(V, D, device=gpu)
+    dcls = torch.zeros(Cn, D, device=gpu)
+    o.embed_bwd(tokens, dtab, dX, s_off, alpha, classes=classes, dcls=dcls)
+    torch.cuda.synchronize()
+    g = alpha * dX[:, s_off:].float()
+    rt = torch.zeros(V, D, device=gpu).index_add_(0, tokens.long().view(-1), g.reshape(-1, D))
+    rc = torch.zeros(Cn, D, device=gpu).index_add_(0, classes.long(), g.sum(1))
+    close(dtab, rt, 1e-4, 1e-3, "dtable")
+    close(dcls, rc, 1e-4, 1e-3, "dcls")
+
+
+# ------------------------------------------------------------------------------------------ latent
+def test_latent_fwd_bwd(gpu):
+    o = ops()
+    B, S, De, Z, Dd, Cn, Sd = 5, 6, 64, 16, 32, 3, 7
+    enc = rnd((B, S, De), gpu, seed=60)
+    Wl = rnd((2 * Z, De), gpu, dtype=torch.float32, seed=61, scale=0.2)
+    bl = rnd((2 * Z,), gpu, dtype=torch.float32, seed=62, scale=0.5)
+    Wh = rnd((Dd, Z), gpu, dtype=torch.float32, seed=63, scale=0.3)
+    bh = rnd((Dd,), gpu, dtype=torch.float32, seed=64, scale=0.1)
+    cls_d = rnd((Cn, Dd), gpu, dtype=torch.float32, seed=65)
+    pos_d = rnd((Sd, Dd), gpu, dtype=torch.float32, seed=66)
+    eps = rnd((B, Z), gpu, dtype=torch.float32, seed=67)
+    classes = torch.tensor([0, 1, 2, 1, 0], dtype=torch.int32, device=gpu)
+    mu = torch.zeros(B, Z, device=gpu); sigma = torch.zeros(B, Z, device=gpu); z = torch.zeros(B, Z, device=gpu)
+    kl = torch.zeros(B, device=gpu)
+    dec_in = torch.zeros(B, Sd, Dd, dtype=BF, device=gpu)
+    alpha_d = math.sqrt(Dd)
+    o.latent_fwd(enc, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in)
+    torch.cuda.synchronize()
+
+    h0 = enc[:, 0].float().clone().requires_grad_(True)
+    P = [t.clone().requires_grad_(True) for t in (Wl, bl, Wh, bh, cls_d)]
+    lat = h0 @ P[0].t() + P[1]
+    mu_r, sg_r = lat[:, :Z], lat[:, Z:]
+    z_r = mu_r + eps * sg_r
+    kl_r = 0.5 * (sg_r * sg_r + mu_r * mu_r - 1 - torch.log(sg_r * sg_r)).sum(1)
+    d0 = alpha_d * (z_r @ P[2].t() + P[3] + P[4][classes.long()]) + pos_d[0]
+    close(mu, mu_r.detach(), 1e-5, 1e-5, "mu")
+    close(sigma, sg_r.detach(), 1e-5, 1e-5, "sigma")
+    close(z, z_r.detach(), 1e-5, 1e-5, "z")
+    close(kl, kl_r.detach(), 1e-5, 1e-4, "kl")
+    close(dec_in[:, 0], d0.detach(), 1e-2, 1e-2, "dec_in row 0")
+    assert (dec_in[:, 1:] == 0).all()
+
+    g0 = rnd((B, Sd, Dd), gpu, seed=68, scale=0.1)
+    beta = 0.7
+    dWl = torch.zeros_like(Wl); dbl = torch.zeros_like(bl); dWh = torch.zeros_like(Wh); dbh = torch.zeros_like(bh)
+    dcls = torch.zeros_like(cls_d)
+    denc = torch.zeros(B, S, De, dtype=BF, device=gpu)
+    scratch = torch.zeros(B * (Dd + 2 * Z), device=gpu)
+    o.latent_bwd(enc, Wl, eps, Wh, classes, mu, sigma, z, g0, alpha_d, beta, 1.0, dWl, dbl, dWh, dbh, dcls, denc, scratch)
+    torch.cuda.synchronize()
+    total = (d0 * g0[:, 0].float()).sum() + beta * kl_r.sum()
+    total.backward()
+    for got, ref, name in zip((dWl, dbl, dWh, dbh, dcls), (p.grad for p in P), ("dWl", "dbl", "dWh", "dbh", "dcls")):
+        close(got, ref, 1e-4, 1e-4 * max(1.0, ref.abs().max().item()), name)
+    close(denc[:, 0], h0.grad, 1e-2, 1e-2 * h0.grad.abs().max().item(), "d enc row 0")
+
+
+def test_reparam_kl_known_answers(gpu):
+    o = ops()
+    B, Z = 3, 8
+    mu = torch.zeros(B, Z, device=gpu)
+    sigma = torch.tensor([[1.0] * Z, [-1.0] * Z, [2.0] * Z], device=gpu)
+    eps = torch.ones(B, Z, device=gpu)
+    z = torch.zeros(B, Z, device=gpu); kl = torch.zeros(B, device=gpu)
+    o.reparam_kl_fwd(mu, sigma, eps, z, kl)
+    torch.cuda.synchronize()
+    # KL(mu=0, sigma=+-1) = 0 ; sigma=2: 0.5*(4 - 1 - log 4) per dim
+    want = torch.tensor([0.0, 0.0, Z * 0.5 * (3 - math.log(4.0))])
+    close(kl, want, 1e-6, 1e-6, "kl KAT")
+    assert torch.equal(z.cpu(), sigma.cpu())
+    dmu = torch.zeros(B, Z, device=gpu); dsg = torch.zeros(B, Z, device=gpu)
+    dz = torch.full((B, Z), 0.5, device=gpu)
+    o.reparam_kl_bwd(mu, sigma, eps, dz, 2.0, dmu, dsg)
+    torch.cuda.synchronize()
+    close(dmu, torch.full((B, Z), 0.5), 1e-6, 1e-6, "dmu")
+    close(dsg, 2.0 * (sigma.cpu() - 1 / sigma.cpu()) + 0.5, 1e-6, 1e-6, "dsigma")
+
+
+# ------------------------------------------------------------------------------------------ loss heads
+@pytest.mark.parametrize("B,T,V", [(3, 5, 10), (8, 65, 293), (2, 4, 2048)])
+def test_softmax_ce(gpu, B, T, V):
+    o = ops()
+    ldv = o.roundup(V, 8)
+    logits = torch.zeros(B * T, ldv, dtype=BF, device=gpu)
+    logits[:, :V] = rnd((B * T, V), gpu, seed=70, scale=2.0)
+    labels = torch.randint(0, V, (B * T,), dtype=torch.int32).to(gpu)
+    labels[::4] = 0  # PAD positions are masked out
+    loss = torch.zeros(B, device=gpu)
+    probs = torch.zeros(B * T, V, device=gpu)
+    dlog = torch.full((B * T, ldv), 3.0, dtype=BF, device=gpu)
+    o.softmax_ce(logits, labels, loss, B, T, V, probs=probs, dlogits=dlog, gscale=1.0)
+    torch.cuda.synchronize()
+    lr = logits[:, :V].float().clone().requires_grad_(True)
+    p = torch.softmax(lr, -1)
+    mask = (labels != 0).float()
+    nll = -torch.log(p.gather(1, labels.long().view(-1, 1)).squeeze(1)) * mask
+    ref = nll.view(B, T).mean(1)  # divides by T, not by the number of valid tokens (loss.py:23)
+    close(loss, ref.detach(), 1e-5, 1e-5, "ce loss")
+    close(probs, p.detach(), 1e-4, 1e-6, "probs")
+    ref.sum().backward()
+    close(dlog[:, :V], lr.grad, 1e-2, 1e-5, "dlogits")
+    assert (dlog[:, V:min(o.roundup(V, 4), ldv)] == 0).all()
+
+
+def test_softmax_ce_uniform_known_answer(gpu):
+    o = ops()
+    B, T, V = 2, 6, 10
+    logits = torch.zeros(B * T, 16, dtype=BF, device=gpu)
+    labels = torch.tensor([1, 2, 3, 0, 0, 0, 4, 5, 6, 7, 8, 0], dtype=torch.int32, device=gpu)
+    loss = torch.zeros(B, device=gpu)
+    o.softmax_ce(logits, labels, loss, B, T, V)
+    torch.cuda.synchronize()
+    want = torch.tensor([math.log(V) * 3 / T, math.log(V) * 5 / T])
+    close(loss, want, 1e-6, 1e-6, "uniform CE = log V * n_valid / T")
+
+
+@pytest.mark.parametrize("B,T,P,ls,dw", [(4, 16, 128, 0.0, False), (4, 16, 128, 0.1, True), (3, 7, 30, 0.0, True),
+                                         (64, 256, 128, 0.0, False)])
+def test_sigmoid_bce(gpu, B, T, P, ls, dw):
+    o = ops()
+    ldp = o.roundup(P, 8)
+    logits = torch.zeros(B * T, ldp, dtype=BF, device=gpu)
+    logits[:, :P] = rnd((B * T, P), gpu, seed=80, scale=2.0)
+    g = torch.Generator().manual_seed(81)
+    labels = (torch.rand(B * T, P, generator=g) < 0.1).to(torch.uint8).to(gpu)
+    loss = torch.zeros(B, device=gpu)
+    npos = torch.zeros(B, dtype=torch.int32, device=gpu)
+    probs = torch.zeros(B * T, ldp, dtype=BF, device=gpu)
+    dlog = torch.zeros(B * T, ldp, dtype=BF, device=gpu)
+    o.sigmoid_bce(logits, labels, loss, B, T, P, label_smoothing=ls, downweight=dw, npos=npos, probs=probs, dlogits=dlog)
+    torch.cuda.synchronize()
+    # plain restatement of loss.py:38-80
+    x = logits[:, :P].float().clone().requires_grad_(True)
+    y = labels.float()
+    p = torch.sigmoid(x)
+    s = (1 - ls) * y + ls * 0.5
+    bce = -(s * torch.log(1e-12 + p) + (1 - s) * torch.log(1e-12 + (1 - p)))
+    if dw:
+        y3 = y.view(B, T * P)
+        npos_r = (y3 == 1).float().sum(1)
+        nneg_r = (y3 != 1).float().sum(1)
+        w = (npos_r / (nneg_r + 1e-12)).view(B, 1).expand(B, T * P).reshape(B * T, P)
+        bce = torch.where(y == 0, (w * bce) * bce, bce)
+        assert torch.equal(npos.cpu().float(), npos_r.cpu())
+    ref = bce.view(B, T * P).mean(1)
+    close(loss, ref.detach(), 2e-4, 1e-6, "bce loss")
+    close(probs[:, :P], p.detach(), 1e-2, 1e-3, "probs")
+    ref.sum().backward()
+    gmax = x.grad.abs().max().item()
+    close(dlog[:, :P], x.grad, 1.6e-2, 1e-2 * gmax * 0.01 + 1e-12, "dlogits")
+
+
+def test_bce_logit_zero_known_answer(gpu):
+    o = ops()
+    B, T, P = 2, 4, 8
+    logits = torch.zeros(B * T, 8, dtype=BF, device=gpu)
+    labels = torch.zeros(B * T, P, dtype=torch.uint8, device=gpu)
+    labels[::2] = 1
+    loss = torch.zeros(B, device=gpu)
+    o.sigmoid_bce(logits, labels, loss, B, T, P)
+    torch.cuda.synchronize()
+    close(loss, torch.full((B,), math.log(2.0)), 1e-6, 1e-6, "BCE at logit 0 = log 2")
+
+
+def test_loss_combine(gpu):
+    o = ops()
+    B = 70
+    recon = rnd((B,), gpu, dtype=torch.float32, seed=90).abs()
+    kl = rnd((B,), gpu, dtype=torch.float32, seed=91).abs()
+    total = torch.zeros(B, device=gpu)
+    acc = torch.zeros(3, device=gpu)
+    o.loss_combine(recon, kl, 0.5, total, acc)
+    o.loss_combine(recon, kl, 0.5, total, acc)
+    torch.cuda.synchronize()
+    close(total, recon + 0.5 * kl, 1e-6, 1e-6, "total")
+    close(acc, torch.stack([2 * kl.sum(), 2 * (recon + 0.5 * kl).sum(), torch.tensor(2.0 * B, device=gpu)]), 1e-5, 1e-4, "acc")
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def mxnet_adam_reference(w, g, m, v, t, lr, b1, b2, eps, wd, rescale, clip):
+    g = g * rescale + wd * w
+    if clip >= 0:
+        g = g.clamp(-clip, clip)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    w = w - lr_t * m / (v.sqrt() + eps)
+    return w, m, v
+
+
+def test_adam_flat_mxnet_rule(gpu):
+    o = ops()
+    n = 10007
+    w = rnd((n,), gpu, dtype=torch.float32, seed=100)
+    w0 = w.clone()
+    m = torch.zeros(n, device=gpu); v = torch.zeros(n, device=gpu)
+    w16 = torch.zeros(n, dtype=BF, device=gpu)
+    state = torch.zeros(2, dtype=torch.int32, device=gpu)
+    wr, mr, vr = w0.clone(), m.clone(), v.clone()
+    for t in range(1, 4):
+        g = rnd((n,), gpu, dtype=torch.float32, seed=100 + t, scale=50.0)
+        o.adam_flat(w, g, m, v, w16, state, lr=3e-4, rescale=1 / 32, clip=1.0)
+        wr, mr, vr = mxnet_adam_reference(wr, g, mr, vr, t, 3e-4, 0.9, 0.999, 1e-8, 0.0, 1 / 32, 1.0)
+    torch.cuda.synchronize()
+    assert state[0].item() == 3
+    close(w, wr, 1e-6, 1e-7, "adam w")
+    close(m, mr, 1e-5, 1e-7, "adam m")
+    close(v, vr, 1e-5, 1e-9, "adam v")
+    assert torch.equal(w16, w.to(BF))
+
+
+def test_transpose_shadows_and_cast(gpu):
+    o = ops()
+    shapes = [(10, 32), (293, 128), (128, 64)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += r * c
+    w = rnd((total,), gpu, dtype=torch.float32, seed=110)
+    desc, prefix, doff = [], [0], 0
+    for (r, c), so in zip(shapes, offs):
+        desc += [so, doff, r, c]
+        doff += c * o.roundup(r, 8)
+        prefix.append(prefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+    wt = torch.full((doff,), 9.0, dtype=BF, device=gpu)
+    o.transpose_shadows(w, wt, torch.tensor(desc, dtype=torch.int64, device=gpu),
+                        torch.tensor(prefix, dtype=torch.int64, device=gpu), len(shapes), prefix[-1])
+    w16 = torch.zeros(total, dtype=BF, device=gpu)
+    o.cast_to_act(w, w16)
+    torch.cuda.synchronize()
+    assert torch.equal(w16, w.to(BF))
+    d = 0
+    for (r, c), so in zip(shapes, offs):
+        ldt = o.roundup(r, 8)
+        got = wt[d:d + c * ldt].view(c, ldt)
+        assert torch.equal(got[:, :r], w[so:so + r * c].view(r, c).t().to(BF))
+        assert (got[:, r:] == 0).all()
+        d += c * ldt
+
+
+def test_graph_capture_and_events(gpu):
+    o = ops()
+    a = rnd((1024,), gpu, seed=120)
+    b = rnd((1024,), gpu, seed=121)
+    y = torch.zeros(1024, dtype=BF, device=gpu)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = o.Graph().capture(lambda: (o.add_act(a, b, y), o.add_act(y, b, y)))
+        e0, e1 = o.Event(), o.Event()
+        e0.record()
+        g.launch()
+        e1.record()
+        e1.sync()
+        assert e0.elapsed_ms(e1) >= 0.0
+    torch.cuda.synchronize()
+    want = ((a.float() + b.float()).to(BF).float() + b.float()).to(BF)
+    assert torch.equal(y, want)
