@@ -104,6 +104,7 @@ typedef struct mst_gemm_args {
   int64_t c_rows_per_group, c_group_stride, c_group_offset;
   float dropout_p; uint64_t dropout_seed; uint32_t dropout_site;
   int32_t self_resid;
+  const uint64_t* dropout_seed_ptr; /* optional DEVICE word XORed into dropout_seed (per-step seed under graph replay) */
 } mst_gemm_args;
 
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
@@ -113,7 +114,8 @@ int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
  * plus optional bias gradient db[n] += sum_m A[m,n].
  * Autograd counterpart of the Dense call sites above (trainer.py:176).
  * dW, db are fp32 and are ACCUMULATED INTO (callers zero the flat gradient
- * bucket once per step); ldw in elements. N, K multiples of 8; lda, ldb multiples of 8.
+ * bucket once per step); ldw in elements. lda, ldb multiples of 8 and >= roundup8(N) / roundup8(K)
+ * (pad columns must hold zeros).
  * Row remaps as in mst_gemm_args apply to A (a_*) and B (b_*).
  * beta_scale multiplies the contribution (sqrt(D) for embedding-side GEMMs).
  * ------------------------------------------------------------------------ */
@@ -168,7 +170,9 @@ int mst_mask_from_lengths(int64_t B, int64_t S, const int32_t* lens, int32_t add
  * (transformer.py:85-126): logits[k,q] = K[k]·Q[q]/sqrt(dh) + (keymask[k] ? 0 : -1e9),
  * P = softmax over q, O[q] = sum_k P[k,q] V[k].
  *   qkv   : act dtype [B*S, ld_qkv]; K at column k_off + h*dh, Q at q_off + h*dh, V at v_off + h*dh
- *   lse   : fp32 [B, H, S] (written by fwd, read by bwd)
+ *   lse   : fp32 [2, B, H, S] softmax row statistics (written by fwd, read by bwd): plane 0 = row max,
+ *           plane 1 = log(row sum). Kept apart because a padded key row has max -1e9, where a single
+ *           fp32 logsumexp would round log(S) away.
  *   out   : act dtype [B*S, ld_out], head h at column h*dh
  * dh in {16, 32, 64}.
  * ------------------------------------------------------------------------ */
@@ -205,7 +209,7 @@ int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ld
                       const void* dy, int64_t ldy, void* dx, int64_t ld_dx,
                       void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
                       int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
-                      mst_stream_t stream);
+                      const uint64_t* dropout_seed_ptr, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K8/K9/K10 latent block (model.py:97-103,292,229-232; loss.py:8-12), fp32 math:
@@ -304,6 +308,15 @@ int mst_cast_f32_to_act(int dtype, int64_t n, const float* src, void* dst, mst_s
 
 /* counter-based dropout keep-mask materialisation (for the oracle comparison): keep[i] in {0,1} */
 int mst_dropout_mask(int64_t n, float p, uint64_t seed, uint32_t site, uint8_t* keep, mst_stream_t stream);
+
+/* stream-ordered memset to zero (gradient bucket, metric sums) */
+int mst_zero(void* ptr, int64_t bytes, mst_stream_t stream);
+/* device-resident per-step RNG seed: state = uint64[3] {seed for this step, step counter, base seed};
+ * one launch per step advances it, so dropout masks and eps differ on every replay of a captured graph */
+int mst_rng_advance(uint64_t* state, mst_stream_t stream);
+/* eps ~ N(0,1) (replaces mx.nd.random_normal, model.py:292): Box-Muller over the counter hash;
+ * effective seed = seed ^ (seed_ptr ? *seed_ptr : 0) */
+int mst_randn(int64_t n, float* out, uint64_t seed, const uint64_t* seed_ptr, uint32_t site, mst_stream_t stream);
 
 /* elementwise act-dtype helpers used on gradient joins: y = a + b */
 int mst_add_act(int dtype, int64_t n, const void* a, const void* b, void* y, mst_stream_t stream);

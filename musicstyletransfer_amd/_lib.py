@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("c_rows_per_group", c_i64), ("c_group_stride", c_i64), ("c_group_offset", c_i64),
         ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_site", c_u32),
         ("self_resid", c_i32),
+        ("dropout_seed_ptr", vp),
     ]
 
 
@@ -82,7 +83,7 @@ SIGNATURES = {
                                           vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_layernorm_fwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, c_f32, vp, c_i64, vp, vp, vp]),
     "mst_layernorm_bwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_i64, vp, c_i64,
-                                    vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp]),
+                                    vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, vp]),
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
@@ -100,6 +101,9 @@ SIGNATURES = {
     "mst_dropout_mask": (C.c_int, [c_i64, c_f32, c_u64, c_u32, vp, vp]),
     "mst_add_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp]),
     "mst_selftest": (C.c_int, [vp, vp]),
+    "mst_zero": (C.c_int, [vp, c_i64, vp]),
+    "mst_rng_advance": (C.c_int, [vp, vp]),
+    "mst_randn": (C.c_int, [c_i64, vp, c_u64, vp, c_u32, vp]),
 }
 
 

@@ -151,7 +151,12 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
   const float M = fmaxf(m, m2);
   const float L = l * __expf(m - M) + l2 * __expf(m2 - M);
-  if (lane < 32 && k_lane < S) a.lse[bh * S + k_lane] = M + __logf(L);
+  // Stored as TWO planes (row max, log of the row sum): for a padded key row the max is -1e9 and a
+  // single fp32 logsumexp would round log(S) away, turning the uniform 1/S row into ones.
+  if (lane < 32 && k_lane < S) {
+    a.lse[bh * S + k_lane] = M;
+    a.lse[a.B * a.H * S + bh * S + k_lane] = __logf(L);
+  }
 }
 
 // ------------------------------------------------------------------------------------ fwd_out
@@ -160,10 +165,11 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
   __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
-  __shared__ float sLse[ATT_STAGE], sMadd[ATT_STAGE];
+  __shared__ float sMax[ATT_STAGE], sLogl[ATT_STAGE], sMadd[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
+  const int64_t plane = a.B * a.H * S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
     stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
     if (tid < ATT_STAGE) {
       const int64_t k = k0 + tid;
-      sLse[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sMax[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sLogl[tid] = (k < S) ? a.lse[plane + bh * S + k] : 0.f;
       sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
     }
     __syncthreads();
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = blk * 32 + acc_row(r, lane);
-        x[r] = (k0 + kr < S) ? __expf(x[r] * a.scale + sMadd[kr] - sLse[kr]) : 0.f;
+        x[r] = (k0 + kr < S) ? __expf(((x[r] * a.scale + sMadd[kr]) - sMax[kr]) - sLogl[kr]) : 0.f;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -246,7 +253,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
   }
   const float madd = (k_lane < S && a.keymask[b * S + k_lane]) ? 0.f : MASK_VALUE;
-  const float lse = (k_lane < S) ? a.lse[bh * S + k_lane] : 0.f;
+  const float rmax = (k_lane < S) ? a.lse[bh * S + k_lane] : 0.f;
+  const float logl = (k_lane < S) ? a.lse[a.B * a.H * S + bh * S + k_lane] : 0.f;
 
   f32x16 acc[DB];
   float delta = 0.f;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
-          const float p = valid ? __expf(x[r] * a.scale + madd - lse) : 0.f;
+          const float p = valid ? __expf(((x[r] * a.scale + madd) - rmax) - logl) : 0.f;
           if (pass == 0) {
             delta += p * dp[r];
             x[r] = p;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
   __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
-  __shared__ float sLse[ATT_STAGE], sMadd[ATT_STAGE], sDelta[ATT_STAGE];
+  __shared__ float sMax[ATT_STAGE], sLogl[ATT_STAGE], sMadd[ATT_STAGE], sDelta[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
@@ -342,7 +350,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
     stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
     if (tid < ATT_STAGE) {
       const int64_t k = k0 + tid;
-      sLse[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sMax[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
+      sLogl[tid] = (k < S) ? a.lse[a.B * a.H * S + bh * S + k] : 0.f;
       sDelta[tid] = (k < S) ? a.delta[bh * S + k] : 0.f;
       sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
     }
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = blk * 32 + acc_row(r, lane);
-        const float p = (k0 + kr < S) ? __expf(x[r] * a.scale + sMadd[kr] - sLse[kr]) : 0.f;
+        const float p = (k0 + kr < S) ? __expf(((x[r] * a.scale + sMadd[kr]) - sMax[kr]) - sLogl[kr]) : 0.f;
         x[r] = p * (dp[r] - sDelta[kr]) * a.scale;
       }
 #pragma unroll

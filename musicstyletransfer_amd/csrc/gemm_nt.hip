@@ -141,6 +141,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   // ------------------------------------------------------------------ epilogue
   const int64_t n_store = ((a.N + 3) / 4 * 4) < a.ldc ? ((a.N + 3) / 4 * 4) : a.ldc;
   const float inv_keep = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+  const uint64_t dseed = a.dropout_seed ^ ((a.dropout_p > 0.f && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int64_t m = m0 + wm * WTM + i * 16 + frow;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
           if (a.dropout_p > 0.f || a.self_resid) {
             float u = t;
             if (a.dropout_p > 0.f)
-              u = dropout_keep(a.dropout_seed, a.dropout_site, (uint64_t)(m * a.N + n), a.dropout_p) ? t * inv_keep : 0.f;
+              u = dropout_keep(dseed, a.dropout_site, (uint64_t)(m * a.N + n), a.dropout_p) ? t * inv_keep : 0.f;
             t = a.self_resid ? t + u : u;
           }
           if (ra_row) t += ra_row[n];

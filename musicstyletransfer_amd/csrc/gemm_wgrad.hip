@@ -212,8 +212,10 @@ static int launch_wgrad(const WgradBatch& b, bool big, hipStream_t s) {
 
 static int check_wgrad(const mst_wgrad_args& a) {
   MST_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "mst_gemm_wgrad: M,N,K must be positive");
-  MST_CHECK_ARG(a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0,
-                "mst_gemm_wgrad: N, K, lda, ldb must be multiples of 8 (got N=%lld K=%lld lda=%lld ldb=%lld)",
+  // N and K may be ragged as long as the 16-byte chunk that straddles the edge stays inside the row
+  // (callers keep pad columns zero); outputs beyond N / K are never written.
+  MST_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= roundup(a.N, 8) && a.ldb >= roundup(a.K, 8),
+                "mst_gemm_wgrad: lda/ldb must be multiples of 8 and >= roundup8(N)/roundup8(K) (got N=%lld K=%lld lda=%lld ldb=%lld)",
                 (long long)a.N, (long long)a.K, (long long)a.lda, (long long)a.ldb);
   MST_CHECK_ARG(a.A && a.B && a.dW, "mst_gemm_wgrad: null operand");
   MST_CHECK_ARG(a.ldw >= a.K, "mst_gemm_wgrad: ldw < K");

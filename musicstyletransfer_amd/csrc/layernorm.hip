@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
                                                             T* __restrict__ dx, int64_t ld_dx,
                                                             T* __restrict__ dxm, int64_t ld_dxm,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int mask_mode, float p, uint64_t seed, uint32_t site) {
+                                                            int mask_mode, float p, uint64_t seed_in, uint32_t site,
+                                                            const uint64_t* __restrict__ seed_ptr) {
   __shared__ float red[2][4][LN_MAXV * 256];
+  const uint64_t seed = seed_in ^ ((p > 0.f && seed_ptr) ? seed_ptr[0] : 0ull);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -200,7 +202,7 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
                                  const float* mean, const float* rstd, const void* dy, int64_t ldy, void* dx,
                                  int64_t ld_dx, void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
                                  int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
-                                 mst_stream_t stream) {
+                                 const uint64_t* dropout_seed_ptr, mst_stream_t stream) {
   int rc = ln_check(M, D, ldx, ldy);
   if (rc) return rc;
   MST_CHECK_ARG(x && gamma && mean && rstd && dy && dx && dgamma && dbeta, "mst_layernorm_bwd: null pointer");
@@ -213,7 +215,7 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
     typedef decltype(tag) T;
     hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
                        (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
-                       dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site);
+                       dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr);
     MST_CHECK_LAUNCH("layernorm_bwd_kernel");
     return MST_OK;
   });

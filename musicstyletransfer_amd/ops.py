@@ -46,7 +46,7 @@ def ld(t):
 # --------------------------------------------------------------------------- GEMMs
 def gemm_nt(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_NONE, gate=None, alpha=1.0,
             rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
-            dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False):
+            dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None):
     """C[M,N] = epilogue(A[M,K] @ B[N,K]^T); see mst_gemm_args in include/mst_hip.h."""
     g = GemmArgs()
     g.dtype = dt(A)
@@ -70,6 +70,7 @@ def gemm_nt(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_
     g.c_rows_per_group, g.c_group_stride, g.c_group_offset = c_remap
     g.dropout_p, g.dropout_seed, g.dropout_site = dropout_p, dropout_seed, dropout_site
     g.self_resid = 1 if self_resid else 0
+    g.dropout_seed_ptr = ptr(dropout_seed_ptr)
     call("mst_gemm_nt", C.byref(g), stream())
 
 
@@ -119,12 +120,12 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5):
 
 
 def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, D=None, dx_masked=None, mask_mode=0, dropout_p=0.0,
-                  dropout_seed=0, dropout_site=0):
+                  dropout_seed=0, dropout_site=0, dropout_seed_ptr=None):
     M = x.shape[0]
     D = x.shape[1] if D is None else D
     call("mst_layernorm_bwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ld(dy), ptr(dx),
          ld(dx), ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0), ptr(dgamma), ptr(dbeta), mask_mode,
-         dropout_p, dropout_seed, dropout_site, stream())
+         dropout_p, dropout_seed, dropout_site, ptr(dropout_seed_ptr), stream())
 
 
 # --------------------------------------------------------------------------- embedding / masks
@@ -222,6 +223,18 @@ def add_act(a, b, y):
 
 def dropout_mask(n, p, seed, site, keep):
     call("mst_dropout_mask", n, p, seed, site, ptr(keep), stream())
+
+
+def zero(t):
+    call("mst_zero", ptr(t), t.numel() * t.element_size(), stream())
+
+
+def rng_advance(state):
+    call("mst_rng_advance", ptr(state), stream())
+
+
+def randn(out, seed=0, seed_ptr=None, site=0):
+    call("mst_randn", out.numel(), ptr(out), seed, ptr(seed_ptr), site, stream())
 
 
 def selftest():

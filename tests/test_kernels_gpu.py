@@ -206,7 +206,7 @@ def test_attention_fwd_bwd(gpu, B, S, H, dh):
     lens = torch.tensor([S - (i * 7) % max(1, S // 2) for i in range(B)], dtype=torch.int32, device=gpu)
     keymask = torch.zeros(B, S, dtype=torch.uint8, device=gpu)
     o.mask_from_lengths(lens, 0, keymask)
-    lse = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+    lse = torch.zeros(2, B, H, S, dtype=torch.float32, device=gpu)
     out = torch.zeros(B * S, D, dtype=BF, device=gpu)
     k_off, q_off, v_off = 0, D, 2 * D
     o.attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off)
@@ -215,7 +215,7 @@ def test_attention_fwd_bwd(gpu, B, S, H, dh):
 
     qkv_ref = qkv.float().clone().requires_grad_(True)
     ref, lse_ref = attn_reference(qkv_ref, keymask, B, S, H, dh, k_off, q_off, v_off)
-    close(lse, lse_ref.detach(), 1e-4, 2e-3, "lse")
+    close(lse[0] + lse[1], lse_ref.detach(), 1e-4, 2e-3, "lse")
     close(out, ref.detach(), 1.6e-2, 1.6e-2, "attention out")
 
     dout = rnd((B * S, D), gpu, seed=31, scale=1.0)
@@ -238,7 +238,7 @@ def test_attention_padded_key_rows_are_uniform(gpu):
     D = H * dh
     qkv = rnd((B * S, 3 * D), gpu, seed=33)
     keymask = torch.zeros(B, S, dtype=torch.uint8, device=gpu)  # every key padded
-    lse = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+    lse = torch.zeros(2, B, H, S, dtype=torch.float32, device=gpu)
     out = torch.zeros(B * S, D, dtype=BF, device=gpu)
     o.attn_fwd(qkv, keymask, lse, out, B, S, H, dh, 0, D, 2 * D)
     torch.cuda.synchronize()
@@ -540,7 +540,7 @@ def test_adam_flat_mxnet_rule(gpu):
     assert state[0].item() == 3
     close(w, wr, 1e-6, 1e-7, "adam w")
     close(m, mr, 1e-5, 1e-7, "adam m")
-    close(v, vr, 1e-5, 1e-9, "adam v")
+    close(v, vr, 1e-4, 1e-9, "adam v")  # (1-beta2) is formed in fp32 on the device, as in MXNet
     assert torch.equal(w16, w.to(BF))
 
 
