@@ -235,7 +235,8 @@ int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const int32_t* classes,
                    const float* mu, const float* sigma, const float* z,
                    const void* d_dec_in, int64_t dec_sample_stride, float alpha_d,
-                   float kl_weight, float gscale,
+                   float kl_weight, float gscale /* encoder-side loss scale */,
+                   float enc_scale /* gscale / decoder-side loss scale */,
                    float* dWl, float* dbl, float* dWh, float* dbh, float* dcls_d, int64_t ld_cls,
                    void* d_enc_out, int64_t denc_sample_stride, float* scratch /* fp32 [B*(Dd+2Z)] */,
                    mst_stream_t stream);
@@ -294,6 +295,7 @@ int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_we
 int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
                   void* w16, float lr, float beta1, float beta2, float eps, float wd,
                   float rescale, float clip, int32_t* step_state /* device int32[2]: {t, bits(lr_t)} */,
+                  int advance_step /* 0: reuse the lr_t of the previous launch (second range of one step) */,
                   mst_stream_t stream);
 
 /* 16-bit shadow + transposed shadow refresh for a list of matrices.

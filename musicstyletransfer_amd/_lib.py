@@ -87,7 +87,7 @@ SIGNATURES = {
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
-                                 vp, c_i64, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
+                                 vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),
     "mst_reparam_kl_bwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, c_f32, vp, vp, vp]),
     "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, vp]),
@@ -95,7 +95,7 @@ SIGNATURES = {
                                   vp, c_i64, c_f32, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
-                                vp, vp]),
+                                vp, C.c_int, vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
     "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),
     "mst_dropout_mask": (C.c_int, [c_i64, c_f32, c_u64, c_u32, vp, vp]),

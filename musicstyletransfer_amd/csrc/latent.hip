@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void latent_bwd_vec_kernel(int De, int Z, int 
                                                              const float* __restrict__ sigma,
                                                              const T* __restrict__ d_dec_in, int64_t dec_stride,
                                                              float alpha_d, float kl_weight, float gscale,
-                                                             float* __restrict__ tvec, float* __restrict__ dlat,
+                                                             float enc_scale, float* __restrict__ tvec, float* __restrict__ dlat,
                                                              T* __restrict__ d_enc_out, int64_t denc_stride) {
   extern __shared__ float sm[];
   float* t = sm;            // [Dd]
@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) void latent_bwd_vec_kernel(int De, int Z, int 
     float acc = 0.f;
     for (int j = 0; j < Dd; ++j) acc += t[j] * Wh[(int64_t)j * Z + i];
     const float m = mu[b * Z + i], s = sigma[b * Z + i];
-    // the KL term's gradient carries the loss scale too (gscale == 1 unless fp16 loss scaling)
-    const float dm = kl_weight * gscale * m + acc;
-    const float ds = kl_weight * gscale * (s - 1.f / s) + eps[b * Z + i] * acc;
+    // gscale: loss scale of everything upstream of here (the encoder); enc_scale = gscale / (loss scale the
+    // incoming decoder-side gradient carries). Both are 1 unless fp16 loss scaling is on.
+    const float dm = kl_weight * gscale * m + enc_scale * acc;
+    const float ds = kl_weight * gscale * (s - 1.f / s) + enc_scale * eps[b * Z + i] * acc;
     dl[i] = dm;
     dl[Z + i] = ds;
     dlat[b * 2 * Z + i] = dm;
@@ -174,7 +175,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
                               int64_t enc_sample_stride, const float* Wl, const float* eps, const float* Wh,
                               const int32_t* classes, const float* mu, const float* sigma, const float* z,
                               const void* d_dec_in, int64_t dec_sample_stride, float alpha_d, float kl_weight,
-                              float gscale, float* dWl, float* dbl, float* dWh, float* dbh, float* dcls_d,
+                              float gscale, float enc_scale, float* dWl, float* dbl, float* dWh, float* dbh, float* dcls_d,
                               int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride, float* scratch,
                               mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_bwd: sizes must be positive");
@@ -188,7 +189,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   int rc = dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(256), lds, s, (int)De, (int)Z, (int)Dd, Wl, eps,
-                       Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, tvec, dlat,
+                       Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec, dlat,
                        (T*)d_enc_out, denc_sample_stride);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     // dWl[2Z, De] += dlat^T · h0 ; dbl += sum_b dlat

@@ -125,13 +125,15 @@ static unsigned grid_for(int64_t n, int per_thread) {
 
 extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, float lr,
                              float beta1, float beta2, float eps, float wd, float rescale, float clip,
-                             int32_t* step_state, mst_stream_t stream) {
+                             int32_t* step_state, int advance_step, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
   MST_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                 "mst_adam_flat: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_state, lr, beta1, beta2);
-  MST_CHECK_LAUNCH("adam_tick_kernel");
+  if (advance_step) {  // a second launch over another range of the same step passes 0
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_state, lr, beta1, beta2);
+    MST_CHECK_LAUNCH("adam_tick_kernel");
+  }
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,

@@ -1,0 +1,580 @@
+"""Step engine: sequences the C-ABI kernels (include/mst_hip.h) into the VarAutoEncoder training
+step of the reference — Trainer._step (VarAutoEncoder/trainer.py:155-179): forward
+(model.py:287-296), CE/BCE + beta*KL (loss.py), backward, MXNet-rule Adam — with every
+intermediate resident in HBM buffers allocated once, and the whole step captured in a hipGraph.
+
+Layout in HBM
+  * ParamStore: ONE flat fp32 buffer each for parameters, gradients (the bucket RCCL all-reduces),
+    Adam m and v; a same-offset 16-bit shadow (GEMM B operands) and a second flat buffer of
+    transposed 16-bit shadows (dgrad B operands / piano-roll embedding tables). W_k, W_q, W_v of a
+    layer sit back to back so the three reference Dense layers run as one [3D, D] GEMM.
+  * StepPlan(B, T): activations as [rows, ld] 16-bit matrices (ld = roundup8(width), pad columns
+    zero), saved for backward; fp32 only for softmax statistics, LayerNorm mean/rstd, the latent
+    block and the losses.
+
+There is no torch autograd, no torch operator and no CPU fallback on this path: backward is written
+out by hand below, mirroring the forward line by line.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops as o
+
+
+def roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+class VAEConfig:
+    """Shape of the model: the union of ModelConfig/EncoderConfig/DecoderConfig/TransformerConfig
+    (model.py:22-54, transformer.py:8-21) flattened, plus which ends are attached:
+    kind='token' (Embedding in, softmax-CE out: the reference's executed path) or
+    kind='pianoroll' (multi-hot frame x table in, sigmoid + BinaryCrossEntropy out)."""
+
+    def __init__(self, kind, in_dim, out_dim, num_classes, latent_dim, e_model, e_layers, e_heads, d_model, d_layers,
+                 d_heads, e_dropout=0.0, d_dropout=0.0):
+        assert kind in ("token", "pianoroll")
+        assert e_model % e_heads == 0 and d_model % d_heads == 0  # transformer.py:134,167
+        self.kind = kind
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.num_classes, self.latent_dim = num_classes, latent_dim
+        self.e_model, self.e_layers, self.e_heads = e_model, e_layers, e_heads
+        self.d_model, self.d_layers, self.d_heads = d_model, d_layers, d_heads
+        self.e_dropout, self.d_dropout = float(e_dropout), float(d_dropout)
+
+    def as_dict(self):
+        return dict(self.__dict__)
+
+
+def positional_table(model_size, max_len):
+    """transformer.py:204-211: exponent 2*i/D for every column, sin on even / cos on odd columns,
+    float64 then cast (host-side constant, built once)."""
+    pos = np.arange(max_len).reshape((-1, 1)) / np.power(10000, (2.0 / model_size) * np.arange(model_size).reshape((1, -1)))
+    pos[:, 0::2] = np.sin(pos[:, 0::2])
+    pos[:, 1::2] = np.cos(pos[:, 1::2])
+    return pos.astype(np.float32)
+
+
+def logical_param_shapes(cfg):
+    """name -> shape in the reference's construction order (model.py:57-71,206-227;
+    transformer.py:24-46,49-68,129-149,162-182): 58 tensors at e_layers=2, d_layers=1."""
+    s = OrderedDict()
+    De, Dd, Z, C = cfg.e_model, cfg.d_model, cfg.latent_dim, cfg.num_classes
+
+    def layer(prefix, D, last_ln):
+        for w in ("W_k", "W_q", "W_v", "W_proj"):
+            s[f"{prefix}.att.{w}.weight"] = (D, D)
+            s[f"{prefix}.att.{w}.bias"] = (D,)
+        s[f"{prefix}.ln1.gamma"] = (D,)
+        s[f"{prefix}.ln1.beta"] = (D,)
+        s[f"{prefix}.ff1.weight"] = (4 * D, D)
+        s[f"{prefix}.ff1.bias"] = (4 * D,)
+        s[f"{prefix}.ff2.weight"] = (D, 4 * D)
+        s[f"{prefix}.ff2.bias"] = (D,)
+        s[f"{prefix}.{last_ln}.gamma"] = (D,)
+        s[f"{prefix}.{last_ln}.beta"] = (D,)
+
+    s["encoder.class2hid.weight"] = (C, De)
+    s["encoder.embedding.weight"] = (cfg.in_dim, De)
+    for i in range(cfg.e_layers):
+        layer(f"encoder.layer{i}", De, "ln2")
+    s["encoder.latent_proj.weight"] = (2 * Z, De)
+    s["encoder.latent_proj.bias"] = (2 * Z,)
+    s["decoder.latent2hid.weight"] = (Dd, Z)
+    s["decoder.latent2hid.bias"] = (Dd,)
+    s["decoder.class2hid.weight"] = (C, Dd)
+    s["decoder.embedding.weight"] = (cfg.out_dim, Dd)
+    for i in range(cfg.d_layers):
+        layer(f"decoder.layer{i}", Dd, "ln3")
+    s["decoder.output_layer.weight"] = (cfg.out_dim, Dd)
+    s["decoder.output_layer.bias"] = (cfg.out_dim,)
+    return s
+
+
+def xavier_init(cfg, rng):
+    """trainer.py:103-105 model.initialize(mx.init.Xavier()): uniform, factor 'avg', magnitude 3 for
+    every '*weight' (Embedding tables included); biases / beta 0; gamma 1."""
+    out = OrderedDict()
+    for name, shape in logical_param_shapes(cfg).items():
+        if name.endswith("weight"):
+            fan_out, fan_in = shape[0], int(np.prod(shape[1:]))
+            scale = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+            out[name] = rng.uniform(-scale, scale, size=shape).astype(np.float32)
+        elif name.endswith("gamma"):
+            out[name] = np.ones(shape, np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+class ParamStore:
+    """Flat parameter / gradient / Adam-state buffers and their 16-bit shadows."""
+
+    def __init__(self, cfg, device, act_dtype=torch.bfloat16, params_np=None, seed=1234):
+        self.cfg, self.device, self.act_dtype = cfg, device, act_dtype
+        shapes = logical_param_shapes(cfg)
+        # flat order: per attention block the three K,Q,V weights first (fused [3D,D] GEMM), then their biases
+        order = []
+        for name in shapes:
+            if ".att.W_q." in name or ".att.W_v." in name:
+                continue
+            if name.endswith(".att.W_k.weight"):
+                p = name[: -len("W_k.weight")]
+                order += [p + "W_k.weight", p + "W_q.weight", p + "W_v.weight"]
+            elif name.endswith(".att.W_k.bias"):
+                p = name[: -len("W_k.bias")]
+                order += [p + "W_k.bias", p + "W_q.bias", p + "W_v.bias"]
+            else:
+                order.append(name)
+        self.shapes, self.offsets = shapes, OrderedDict()
+        off = 0
+        for name in order:
+            fused_tail = (".att.W_q." in name) or (".att.W_v." in name)
+            if not fused_tail:
+                off = roundup(off, 8)
+            self.offsets[name] = off
+            off += int(np.prod(shapes[name]))
+        self.n = roundup(off, 8)
+        self.n_params = sum(int(np.prod(s)) for s in shapes.values())
+        f32 = dict(dtype=torch.float32, device=device)
+        self.w = torch.zeros(self.n, **f32)
+        self.g = torch.zeros(self.n, **f32)
+        self.m = torch.zeros(self.n, **f32)
+        self.v = torch.zeros(self.n, **f32)
+        self.w16 = torch.zeros(self.n, dtype=act_dtype, device=device)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=device)
+
+        # transposed shadows: (source offset, rows, cols) -> dst [cols, roundup8(rows)]
+        self.t_specs = OrderedDict()
+        for side, D, L in (("encoder", cfg.e_model, cfg.e_layers), ("decoder", cfg.d_model, cfg.d_layers)):
+            for i in range(L):
+                p = f"{side}.layer{i}"
+                self.t_specs[f"{p}.att.W_kqv"] = (self.offsets[f"{p}.att.W_k.weight"], 3 * D, D)
+                self.t_specs[f"{p}.att.W_proj.weight"] = (self.offsets[f"{p}.att.W_proj.weight"], D, D)
+                self.t_specs[f"{p}.ff1.weight"] = (self.offsets[f"{p}.ff1.weight"], 4 * D, D)
+                self.t_specs[f"{p}.ff2.weight"] = (self.offsets[f"{p}.ff2.weight"], D, 4 * D)
+        self.t_specs["decoder.output_layer.weight"] = (self.offsets["decoder.output_layer.weight"], cfg.out_dim, cfg.d_model)
+        if cfg.kind == "pianoroll":
+            self.t_specs["encoder.embedding.weight"] = (self.offsets["encoder.embedding.weight"], cfg.in_dim, cfg.e_model)
+            self.t_specs["decoder.embedding.weight"] = (self.offsets["decoder.embedding.weight"], cfg.out_dim, cfg.d_model)
+        desc, prefix, doff, self.t_off = [], [0], 0, OrderedDict()
+        for name, (so, r, c) in self.t_specs.items():
+            self.t_off[name] = doff
+            desc += [so, doff, r, c]
+            doff += c * roundup(r, 8)
+            prefix.append(prefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+        self.wt16 = torch.zeros(max(doff, 8), dtype=act_dtype, device=device)
+        self.t_desc = torch.tensor(desc, dtype=torch.int64, device=device)
+        self.t_prefix = torch.tensor(prefix, dtype=torch.int64, device=device)
+        self.t_tiles = prefix[-1]
+
+        if params_np is None:
+            params_np = xavier_init(cfg, np.random.default_rng(seed))
+        self.load_numpy(params_np)
+
+    # ---- views
+    def _view(self, flat, name):
+        shape = self.shapes[name]
+        off = self.offsets[name]
+        return flat[off: off + int(np.prod(shape))].view(*shape)
+
+    def p(self, name):
+        return self._view(self.w, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def h(self, name):
+        return self._view(self.w16, name)
+
+    def fused(self, flat, prefix, what):
+        """[3D, D] weight or [3D] bias view of a layer's K,Q,V Dense layers (K rows first)"""
+        D = self.shapes[f"{prefix}.att.W_k.weight"][0]
+        off = self.offsets[f"{prefix}.att.W_k.{what}"]
+        return flat[off: off + 3 * D * D].view(3 * D, D) if what == "weight" else flat[off: off + 3 * D]
+
+    def t(self, name):
+        so, r, c = self.t_specs[name]
+        off = self.t_off[name]
+        return self.wt16[off: off + c * roundup(r, 8)].view(c, roundup(r, 8))
+
+    # ---- host <-> device
+    def load_numpy(self, params_np):
+        host = np.zeros(self.n, np.float32)
+        for name, shape in self.shapes.items():
+            a = np.asarray(params_np[name], np.float32)
+            assert tuple(a.shape) == tuple(shape), f"{name}: expected {shape}, got {a.shape}"
+            host[self.offsets[name]: self.offsets[name] + a.size] = a.reshape(-1)
+        self.w.copy_(torch.from_numpy(host))
+        self.refresh_shadows()
+
+    def to_numpy(self, which="w"):
+        host = getattr(self, which).detach().cpu().numpy()
+        return OrderedDict((n, host[self.offsets[n]: self.offsets[n] + int(np.prod(s))].reshape(s).copy())
+                           for n, s in self.shapes.items())
+
+    def refresh_shadows(self):
+        o.cast_to_act(self.w, self.w16)
+        o.transpose_shadows(self.w, self.wt16, self.t_desc, self.t_prefix, len(self.t_specs), self.t_tiles)
+
+
+class _Layer:
+    pass
+
+
+class StepPlan:
+    """All buffers and the kernel sequence of one training step at a fixed (B, T)."""
+
+    def __init__(self, store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, label_smoothing=0.0,
+                 negative_label_downscaling=False, global_batch=None, gscale=None, want_probs=False, seed=0,
+                 internal_eps=False, optimizer_params=None):
+        cfg = store.cfg
+        self.store, self.cfg, self.B, self.T = store, cfg, B, T
+        self.dev, self.adt = store.device, store.act_dtype
+        self.lr, self.clip, self.kl_weight = lr, clip_gradient, kl_weight
+        self.ls, self.nld = label_smoothing, negative_label_downscaling
+        self.global_batch = global_batch or B
+        # fp16 needs loss scaling for the 1/(T*P)-sized reconstruction gradients (decoder side); bf16 does
+        # not. The encoder side is fed by the KL term, whose sigma - 1/sigma gradient is huge near sigma = 0
+        # (loss.py:9 has no epsilon), so it keeps scale 1: the two halves of the flat bucket carry their own
+        # scale and Adam un-scales each range.
+        self.gscale = gscale if gscale is not None else (1024.0 if self.adt == torch.float16 else 1.0)
+        self.gscale_enc = 1.0
+        self.want_probs, self.internal_eps = want_probs, internal_eps
+        self.opt = dict(beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0)
+        if optimizer_params:
+            for k_src, k_dst in (("beta1", "beta1"), ("beta2", "beta2"), ("epsilon", "eps"), ("wd", "wd")):
+                if k_src in optimizer_params:
+                    self.opt[k_dst] = float(optimizer_params[k_src])
+        dev, adt = self.dev, self.adt
+        De, Dd, Z = cfg.e_model, cfg.d_model, cfg.latent_dim
+        Se, Sd = T, T + 1
+        self.Me, self.Md = B * Se, B * Sd
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def act(rows, width):
+            return torch.zeros(rows, roundup(width, 8), dtype=adt, device=dev)
+
+        # ---- inputs (static device buffers; the batcher copies into them)
+        if cfg.kind == "token":
+            self.tokens = torch.zeros(B, T, dtype=torch.int32, device=dev)
+            self.labels = torch.zeros(B, T, dtype=torch.int32, device=dev)
+        else:
+            self.roll = act(B * T, cfg.in_dim)
+            self.labels = torch.zeros(B * T, cfg.out_dim, dtype=torch.uint8, device=dev)
+        self.seq_lens = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.classes = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.eps = torch.zeros(B, Z, **f32)
+        self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D], dtype=torch.int64, device=dev)
+
+        self.pos_e = torch.from_numpy(positional_table(De, Se)).to(dev)
+        self.pos_d = torch.from_numpy(positional_table(Dd, Sd)).to(dev)
+        self.keymask_e = torch.zeros(B, Se, dtype=torch.uint8, device=dev)
+        self.keymask_d = torch.zeros(B, Sd, dtype=torch.uint8, device=dev)
+
+        def layers(n, M, D, H, S):
+            out = []
+            for _ in range(n):
+                L = _Layer()
+                L.qkv, L.att, L.h1, L.x1 = act(M, 3 * D), act(M, D), act(M, D), act(M, D)
+                L.a, L.h2, L.x2 = act(M, 4 * D), act(M, D), act(M, D)
+                L.lse = torch.zeros(2, B, H, S, **f32)
+                L.mean1, L.rstd1 = torch.zeros(M, **f32), torch.zeros(M, **f32)
+                L.mean2, L.rstd2 = torch.zeros(M, **f32), torch.zeros(M, **f32)
+                out.append(L)
+            return out
+
+        self.x0_e = act(self.Me, De)
+        self.enc = layers(cfg.e_layers, self.Me, De, cfg.e_heads, Se)
+        self.x0_d = act(self.Md, Dd)
+        self.dec = layers(cfg.d_layers, self.Md, Dd, cfg.d_heads, Sd)
+        self.mu, self.sigma, self.z = torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32)
+        self.kl, self.recon, self.total = torch.zeros(B, **f32), torch.zeros(B, **f32), torch.zeros(B, **f32)
+        self.metric_acc = torch.zeros(3, **f32)  # [sum kl, sum total, count]  (trainer.py:115-116)
+        self.logits = act(B * T, cfg.out_dim)
+        self.dlogits = act(B * T, cfg.out_dim)
+        if cfg.kind == "token":
+            self.probs = torch.zeros(B * T, cfg.out_dim, **f32) if want_probs else None
+        else:
+            self.probs = act(B * T, cfg.out_dim) if want_probs else None
+        self.npos = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        # ---- backward temporaries (encoder and decoder sized separately)
+        def bwd_bufs(M, D, H, S):
+            t = _Layer()
+            t.dx_a, t.dx_b = act(M, D), act(M, D)      # gradient w.r.t. a layer's output / input (ping-pong)
+            t.dh, t.dhm = act(M, D), act(M, D)          # LN backward output and its dropout-masked copy
+            t.dh1, t.dh1m = act(M, D), act(M, D)
+            t.dpre, t.dx1 = act(M, 4 * D), act(M, D)
+            t.datt, t.dqkv = act(M, D), act(M, 3 * D)
+            t.delta = torch.zeros(B, H, S, **f32)
+            return t
+
+        self.be = bwd_bufs(self.Me, De, cfg.e_heads, Se)
+        self.bd = bwd_bufs(self.Md, Dd, cfg.d_heads, Sd)
+        self.lat_scratch = torch.zeros(B * (Dd + 2 * Z), **f32)
+        # Sparse gradient carriers, never used as ping-pong targets so their untouched rows stay zero:
+        #   d_dec_out: d(decoder output) - rows 1..T written by the output-layer dgrad, row 0 always 0 (model.py:253)
+        #   d_enc_out: d(encoder output) - only row 0 of each sample written, by latent_bwd (model.py:97)
+        self.d_dec_out = act(self.Md, Dd)
+        self.d_enc_out = act(self.Me, De)
+        self.graph = None
+        self.graph_opt = None
+
+    # ------------------------------------------------------------------------------ inputs
+    def load_batch(self, x, seq_lens, classes, labels, eps=None):
+        """Copy one batch (host or device tensors / numpy arrays) into the static input buffers."""
+        def dev(a, dtype):
+            t = torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a
+            return t.to(device=self.dev, dtype=dtype, non_blocking=True)
+
+        cfg, B, T = self.cfg, self.B, self.T
+        if cfg.kind == "token":
+            self.tokens.copy_(dev(x, torch.int32).view(B, T))
+            self.labels.copy_(dev(labels, torch.int32).view(B, T))
+        else:
+            self.roll[:, : cfg.in_dim].copy_(dev(x, self.adt).view(B * T, cfg.in_dim))
+            self.labels.copy_(dev(labels, torch.uint8).view(B * T, cfg.out_dim))
+        self.seq_lens.copy_(dev(seq_lens, torch.int32))
+        self.classes.copy_(dev(classes, torch.int32))
+        if eps is not None:
+            self.eps.copy_(dev(eps, torch.float32))
+
+    # ------------------------------------------------------------------------------ forward
+    def _drop(self, p, site):
+        return dict(dropout_p=p, dropout_site=site, dropout_seed_ptr=self.rng_state) if p > 0 else {}
+
+    def _layer_fwd(self, side, i, L, x_in, keymask, D, H, S, p, site0):
+        st = self.store
+        pre = f"{side}.layer{i}"
+        dh = D // H
+        o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
+        o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
+        o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
+                  resid=x_in, **self._drop(p, site0))
+        o.layernorm_fwd(L.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), L.x1, L.mean1, L.rstd1, D=D)
+        o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU,
+                  **self._drop(p, site0 + 1))
+        if side == "encoder":
+            o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1,
+                      **self._drop(p, site0 + 2))
+            ln = "ln2"
+        else:  # transformer.py:199-200: LN3(ff + dropout(ff))
+            o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), self_resid=True,
+                      **self._drop(p, site0 + 2))
+            ln = "ln3"
+        o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
+        return L.x2
+
+    def forward(self):
+        cfg, st, B, T = self.cfg, self.store, self.B, self.T
+        De, Dd = cfg.e_model, cfg.d_model
+        Se, Sd = T, T + 1
+        sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
+        if cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps:
+            o.rng_advance(self.rng_state)
+        if self.internal_eps:
+            o.randn(self.eps, seed_ptr=self.rng_state, site=0x7FFF0000)
+        # ---- encoder input (model.py:81-91, transformer.py:270)
+        if cfg.kind == "token":
+            o.embed_fwd(self.tokens, st.p("encoder.embedding.weight"), self.pos_e, self.x0_e.view(B, Se, -1), 0, sq_e,
+                        classes=self.classes, cls_table=st.p("encoder.class2hid.weight"), keymask=self.keymask_e)
+        else:
+            o.gemm_nt(self.roll, st.t("encoder.embedding.weight"), self.x0_e, N=De, alpha=sq_e,
+                      grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T)
+            o.mask_from_lengths(self.seq_lens, 0, self.keymask_e)
+        x = self.x0_e
+        for i, L in enumerate(self.enc):
+            x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, 3 * i)
+        self.enc_out = x
+        # ---- latent block + decoder position 0 (model.py:97-103,292,229-232)
+        o.latent_fwd(x.view(B, Se, -1), st.p("encoder.latent_proj.weight"), st.p("encoder.latent_proj.bias"), self.eps,
+                     st.p("decoder.latent2hid.weight"), st.p("decoder.latent2hid.bias"), self.classes,
+                     st.p("decoder.class2hid.weight"), self.pos_d, sq_d, self.mu, self.sigma, self.z, self.kl,
+                     self.x0_d.view(B, Sd, -1))
+        # ---- decoder positions 1..T (model.py:241-245, transformer.py:237)
+        if cfg.kind == "token":
+            o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos_d, self.x0_d.view(B, Sd, -1), 1, sq_d)
+        else:
+            o.gemm_nt(self.roll, st.t("decoder.embedding.weight"), self.x0_d, M=B * T, N=Dd, alpha=sq_d,
+                      rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1))
+        o.mask_from_lengths(self.seq_lens, 1, self.keymask_d)  # model.py:246-247
+        x = self.x0_d
+        site_d = 3 * cfg.e_layers
+        for i, L in enumerate(self.dec):
+            x = self._layer_fwd("decoder", i, L, x, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout, site_d + 3 * i)
+        self.dec_out = x
+        # ---- output layer on positions 1..T (model.py:253-256)
+        o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, M=B * T, K=Dd, bias=st.p("decoder.output_layer.bias"),
+                  a_remap=(T, Sd, 1))
+
+    def losses(self, with_grad=True):
+        cfg, B, T = self.cfg, self.B, self.T
+        dl = self.dlogits if with_grad else None
+        if cfg.kind == "token":
+            o.softmax_ce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, probs=self.probs, dlogits=dl,
+                         gscale=self.gscale)
+        else:
+            o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
+                          downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale)
+        o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
+
+    # ------------------------------------------------------------------------------ backward
+    def _layer_bwd(self, side, i, L, x_in, dy, dx_in, keymask, D, H, S, p, site0, t):
+        """dy: gradient w.r.t. the layer output x2; writes the gradient w.r.t. x_in into dx_in."""
+        st = self.store
+        pre = f"{side}.layer{i}"
+        dhd = D // H
+        inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+        dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
+        if side == "encoder":
+            ln = "ln2"
+            if p > 0:
+                o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
+                                st.grad(f"{pre}.ln2.beta"), D=D, dx_masked=t.dhm, mask_mode=1, dropout_site=site0 + 2, **dk)
+                dff = t.dhm
+            else:
+                o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
+                                st.grad(f"{pre}.ln2.beta"), D=D)
+                dff = t.dh
+            resid_ff = t.dh
+        else:
+            ln = "ln3"
+            o.layernorm_bwd(L.h2, st.p(f"{pre}.ln3.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln3.gamma"),
+                            st.grad(f"{pre}.ln3.beta"), D=D, mask_mode=2, dropout_site=site0 + 2, **dk)
+            dff = t.dh
+            resid_ff = None
+        # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
+        o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
+        o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
+        if p > 0:
+            o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
+                            st.grad(f"{pre}.ln1.beta"), D=D, dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk)
+            dproj = t.dh1m
+        else:
+            o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
+                            st.grad(f"{pre}.ln1.beta"), D=D)
+            dproj = t.dh1
+        o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
+        o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
+        o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
+        # all four weight gradients of the layer in one launch
+        o.gemm_wgrad_batch([
+            o.wgrad_problem(dff, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=D, K=4 * D),
+            o.wgrad_problem(t.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * D, K=D),
+            o.wgrad_problem(dproj, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=D, K=D),
+            o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
+        ])
+
+    def backward(self):
+        cfg, st, B, T = self.cfg, self.store, self.B, self.T
+        De, Dd = cfg.e_model, cfg.d_model
+        Se, Sd = T, T + 1
+        sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
+        o.zero(st.g)
+        bd, be = self.bd, self.be
+        # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
+        ldv = self.dlogits.shape[1]
+        o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
+        o.gemm_wgrad(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
+                     st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1))
+        dy, tgt, nxt = self.d_dec_out, bd.dx_a, bd.dx_b
+        site_d = 3 * cfg.e_layers
+        for i in reversed(range(cfg.d_layers)):
+            x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d
+            self._layer_bwd("decoder", i, self.dec[i], x_in, dy, tgt, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout,
+                            site_d + 3 * i, bd)
+            dy, tgt, nxt = tgt, nxt, tgt
+        d_x0_d = dy  # gradient w.r.t. the decoder input [B, Sd, Dd]
+        # ---- decoder input: rows 1..T -> embedding, row 0 -> latent block
+        if cfg.kind == "token":
+            o.embed_bwd(self.tokens, st.grad("decoder.embedding.weight"), d_x0_d.view(B, Sd, -1), 1, sq_d)
+        else:
+            o.gemm_wgrad(self.roll, d_x0_d, st.grad("decoder.embedding.weight"), M=B * T, N=cfg.out_dim, K=Dd, scale=sq_d,
+                         b_remap=(T, Sd, 1))
+        # gradient w.r.t. the encoder output: zero except position 0 of every sample
+        d_enc = self.d_enc_out
+        o.latent_bwd(self.enc_out.view(B, Se, -1), st.p("encoder.latent_proj.weight"), self.eps,
+                     st.p("decoder.latent2hid.weight"), self.classes, self.mu, self.sigma, self.z,
+                     d_x0_d.view(B, Sd, -1), sq_d, self.kl_weight, self.gscale_enc,
+                     st.grad("encoder.latent_proj.weight"), st.grad("encoder.latent_proj.bias"),
+                     st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"),
+                     st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
+                     enc_scale=self.gscale_enc / self.gscale)
+        dy, tgt, nxt = self.d_enc_out, be.dx_a, be.dx_b
+        for i in reversed(range(cfg.e_layers)):
+            x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
+            self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
+                            3 * i, be)
+            dy, tgt, nxt = tgt, nxt, tgt
+        d_x0_e = dy
+        if cfg.kind == "token":
+            o.embed_bwd(self.tokens, st.grad("encoder.embedding.weight"), d_x0_e.view(B, Se, -1), 0, sq_e,
+                        classes=self.classes, dcls=st.grad("encoder.class2hid.weight"))
+        else:
+            o.gemm_wgrad(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim, K=De, scale=sq_e)
+            o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
+
+    def optimizer(self):
+        st = self.store
+        clip = self.clip if self.clip is not None else -1.0
+        if self.gscale == self.gscale_enc:
+            o.adam_flat(st.w, st.g, st.m, st.v, st.w16, st.step_state, lr=self.lr,
+                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, **self.opt)
+        else:
+            # encoder.* tensors come first in the flat buffers; everything from decoder.latent2hid on is decoder-side.
+            # NOTE the latent_proj gradients are produced by latent_bwd at the encoder-side scale.
+            cut = st.offsets["decoder.latent2hid.weight"]
+            rng = [(0, cut, self.gscale_enc, True), (cut, st.n, self.gscale, False)]
+            for a, b, gs, adv in rng:
+                o.adam_flat(st.w[a:b], st.g[a:b], st.m[a:b], st.v[a:b], st.w16[a:b], st.step_state, lr=self.lr,
+                            rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv, **self.opt)
+        o.transpose_shadows(st.w, st.wt16, st.t_desc, st.t_prefix, len(st.t_specs), st.t_tiles)
+
+    # ------------------------------------------------------------------------------ step
+    def fwd_bwd_kernels(self, is_train=True):
+        self.forward()
+        self.losses(with_grad=is_train)
+        if is_train:
+            self.backward()
+
+    def step_kernels(self, is_train=True, reduce_fn=None):
+        """One step, eagerly: forward, losses, backward, [gradient all-reduce], Adam + shadow refresh."""
+        self.fwd_bwd_kernels(is_train)
+        if is_train:
+            if reduce_fn is not None:
+                reduce_fn(self.store.g)
+            self.optimizer()
+
+    def capture(self, is_train=True, split_optimizer=False):
+        """Capture the step into hipGraph(s) on the current stream. Run one eager step of this shape
+        first (lazy HIP module loads are not capturable). With split_optimizer the optimizer lives in
+        its own graph so a gradient all-reduce can run between the two (data parallel)."""
+        self.is_train, self.split = is_train, split_optimizer
+        if split_optimizer or not is_train:
+            self.graph = o.Graph().capture(lambda: self.fwd_bwd_kernels(is_train))
+            self.graph_opt = o.Graph().capture(self.optimizer) if is_train else None
+        else:
+            self.graph = o.Graph().capture(lambda: self.step_kernels(True))
+            self.graph_opt = None
+        return self
+
+    def run(self, reduce_fn=None):
+        if self.graph is None:
+            raise RuntimeError("call capture() first")
+        self.graph.launch()
+        if self.graph_opt is not None:
+            if reduce_fn is not None:
+                reduce_fn(self.store.g)
+            self.graph_opt.launch()
+
+    def metrics(self, reset=True):
+        """(kl_loss, total_loss) batch means accumulated on the device (trainer.py:115-116,185-186); one sync."""
+        acc = self.metric_acc.cpu().tolist()
+        if reset:
+            self.metric_acc.zero_()
+        n = max(acc[2], 1.0)
+        return {"kl_loss": acc[0] / n, "total_loss": acc[1] / n, "count": acc[2]}

@@ -166,12 +166,12 @@ def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu
 
 
 def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d, kl_weight, gscale, dWl, dbl, dWh, dbh,
-               dcls_d, d_enc_out3, scratch):
+               dcls_d, d_enc_out3, scratch, enc_scale=1.0):
     B = enc_out3.shape[0]
     De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
     call("mst_latent_bwd", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(eps), ptr(Wh),
          ptr(classes), ptr(mu), ptr(sigma), ptr(z), ptr(d_dec_in3), d_dec_in3.stride(0), alpha_d, kl_weight, gscale,
-         ptr(dWl), ptr(dbl), ptr(dWh), ptr(dbh), ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3), d_enc_out3.stride(0),
+         enc_scale, ptr(dWl), ptr(dbl), ptr(dWh), ptr(dbh), ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3), d_enc_out3.stride(0),
          ptr(scratch), stream())
 
 
@@ -204,9 +204,10 @@ def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None):
 
 
 # --------------------------------------------------------------------------- optimizer / shadows
-def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0):
+def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0,
+              advance_step=True):
     call("mst_adam_flat", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd,
-         rescale, clip, ptr(step_state), stream())
+         rescale, clip, ptr(step_state), 1 if advance_step else 0, stream())
 
 
 def transpose_shadows(w, wt16, desc, tile_prefix, n_mat, total_tiles):

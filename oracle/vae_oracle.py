@@ -326,6 +326,18 @@ class OracleTrainer:
         self.kl_sum = self.total_sum = 0.0  # trainer.py:115-116 CustomMetric(mean)
         self.count = 0
 
+    def load_state(self, w, m=None, v=None, t=None):
+        """overwrite parameters (and optionally Adam moments / step count) from name -> numpy arrays"""
+        with torch.no_grad():
+            for k, p in self.P.items():
+                p.copy_(torch.as_tensor(np.asarray(w[k]), dtype=self.dtype))
+                if m is not None:
+                    self.m[k] = torch.as_tensor(np.asarray(m[k]), dtype=self.dtype).clone()
+                if v is not None:
+                    self.v[k] = torch.as_tensor(np.asarray(v[k]), dtype=self.dtype).clone()
+        if t is not None:
+            self.t = int(t)
+
     def step(self, batch, eps, masks=None, is_train=True):
         for p in self.P.values():
             p.grad = None
@@ -343,8 +355,8 @@ class OracleTrainer:
                                           clip_gradient=self.clip)  # :177 step(batch_size)
                     p.copy_(w)
                     self.m[k], self.v[k] = m, v
-        self.kl_sum += float(kl.sum())
-        self.total_sum += float(loss.sum())
+        self.kl_sum += float(kl.detach().sum())
+        self.total_sum += float(loss.detach().sum())
         self.count += loss.numel()
         return {"loss": loss.detach(), "recon": recon.detach(), "kl": kl.detach(), "probs": probs.detach(),
                 "means": means.detach(), "stds": stds.detach(), "grads": grads}
