@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — VarAutoEncoder training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training step (forward, BCE + KL, backward, gradient all-reduce when N > 1,
+MXNet-rule Adam) over one batch of synthetic piano-rolls already resident in HBM: BASELINE.json
+configs[1] per GPU (T=256, pitch=128, latent=64, batch=64, bf16; widths from scripts/train-vae.sh:
+encoder 256 x 2 layers x 8 heads, decoder 128 x 1 layer x 8 heads, dropout 0.2), weak scaling
+(configs[3] is the same per-GPU batch on 8 GPUs). Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     : the dominant kernel of the step, re-launched on the step's own operands and timed with
+                 HIP events on its stream; algorithmic FLOPs (or bytes) / average launch duration against
+                 the gfx950 peak (profiles/ holds the rocprofv3 summary of the same command)
+  cpu_baseline : the CPU oracle (oracle/vae_oracle.py, a restatement of the reference — the MXNet
+                 reference itself cannot run here) timed on this node's host cores on a bounded sample of
+                 the same workload. A reported baseline, not the optimisation target.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(kind="pianoroll", in_dim=128, out_dim=128, num_classes=2, latent_dim=64, e_model=256, e_layers=2, e_heads=8,
+            d_model=128, d_layers=1, d_heads=8)
+B_LOCAL, T_LEN = 64, 256
+DROPOUT = 0.2  # scripts/train-vae.sh:23,29
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def fwd_flops(cfg, B, T):
+    """SURVEY §8d algorithmic FLOPs of one forward pass; a step is 3x this."""
+    De, Dd, Z, P = cfg["e_model"], cfg["d_model"], cfg["latent_dim"], cfg["in_dim"]
+    Le, Ld, V = cfg["e_layers"], cfg["d_layers"], cfg["out_dim"]
+    layer = lambda S, D: 24 * S * D * D + 4 * S * S * D
+    per = (Le * layer(T, De) + 2 * T * P * De + 4 * De * Z + 2 * Z * Dd + Ld * layer(T + 1, Dd) + 2 * T * Dd * V)
+    return B * per
+
+
+def synthetic_batches(n, B, T, P, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        roll = (rng.random((B, T + 1, P)) < 0.04).astype(np.uint8)  # ~5 active pitches of 128 per frame
+        x = roll[:, :T].copy()
+        x[:, 0, :] = 0
+        x[:, 0, 0] = 1  # reserved start row
+        out.append(dict(x=x, labels=roll[:, 1:].copy(), seq_lens=np.full(B, T, np.int32),
+                        classes=rng.integers(0, 2, size=B).astype(np.int32)))
+    return out
+
+
+def cpu_baseline(steps=2):
+    """time the CPU oracle on a bounded sample: `steps` training steps of the same B=64, T=256 batch"""
+    from oracle import vae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(CFG2["kind"], CFG2["in_dim"], CFG2["out_dim"], CFG2["num_classes"], CFG2["latent_dim"],
+                         CFG2["e_model"], CFG2["e_layers"], CFG2["e_heads"], CFG2["d_model"], CFG2["d_layers"], CFG2["d_heads"])
+    rng = np.random.default_rng(1234)
+    tr = O.OracleTrainer(cfg, O.init_params(cfg, rng), lr=3e-4, clip_gradient=1.0)
+    batch = O.synthetic_pianoroll_batch(rng, B_LOCAL, T_LEN, CFG2["in_dim"])
+    eps = torch.from_numpy(rng.standard_normal((B_LOCAL, CFG2["latent_dim"])).astype(np.float32))
+    tr.step(batch, eps)  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(batch, eps)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": B_LOCAL * T_LEN / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps of one B={B_LOCAL}, T={T_LEN}, P={CFG2['in_dim']} batch, fp32 torch-CPU restatement "
+                      f"(dropout 0), {dt * 1e3:.0f} ms/step"}
+
+
+def dominant_kernel_roofline(plan, o, iters=50):
+    """Re-launch the step's heaviest kernels on the step's own buffers, time each with HIP events on the
+    launch stream and report the one with the largest share of the step."""
+    st, cfg = plan.store, plan.cfg
+    De, M = cfg.e_model, plan.Me
+    L = plan.enc[0]
+    pre = "encoder.layer0"
+    cands = {
+        "gemm_nt_kernel[enc ff1 fwd: M=16384 N=1024 K=256]": (
+            lambda: o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU),
+            2.0 * M * 4 * De * De, 6 * cfg.e_layers),  # same-sized GEMMs per step: ff1/ff2 fwd + 2 dgrads each, per layer
+        "wgrad_kernel[enc layer: 4 problems, M=16384]": (
+            lambda: o.gemm_wgrad_batch([
+                o.wgrad_problem(plan.be.dh, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=De, K=4 * De),
+                o.wgrad_problem(plan.be.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * De, K=De),
+                o.wgrad_problem(plan.be.dh1, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=De, K=De),
+                o.wgrad_problem(plan.be.dqkv, plan.x0_e, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * De, K=De)]),
+            2.0 * M * 12 * De * De, cfg.e_layers),
+        "attn_bwd(kv+q)[enc: B*H=512, S=256, dh=32]": (
+            lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, plan.be.datt, plan.be.dqkv, plan.be.delta, plan.B, plan.T,
+                               cfg.e_heads, De // cfg.e_heads, 0, De, 2 * De),
+            2.0 * 4 * plan.B * plan.T * plan.T * De, cfg.e_layers),  # algorithmic: 2x the forward's 4*S^2*D per sample
+    }
+    best = None
+    for name, (fn, flops, per_step) in cands.items():
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = o.Event(), o.Event()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.sync()
+        ms = e0.elapsed_ms(e1) / iters
+        rec = dict(kernel=name, ms=ms, flops=flops, share_ms=ms * per_step)
+        if best is None or rec["share_ms"] > best["share_ms"]:
+            best = rec
+    achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": best["kernel"], "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": best["ms"],
+            "algorithmic_flops_per_launch": best["flops"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=DROPOUT)
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (launch with torch.distributed.run); WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the training step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from musicstyletransfer_amd import engine as E
+    from musicstyletransfer_amd import ops as o
+    from musicstyletransfer_amd import parallel
+
+    dist = parallel.init_process_group(world, rank) if world > 1 else None
+    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = E.VAEConfig(e_dropout=args.dropout, d_dropout=args.dropout, **CFG2)
+    store = E.ParamStore(cfg, dev, adt, seed=1234)  # identical initial weights on every rank
+    plan = E.StepPlan(store, B_LOCAL, T_LEN, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B_LOCAL * world,
+                      internal_eps=True, seed=1000 + rank)
+    # synthetic piano-rolls, uploaded once: inputs are resident in HBM before the timed region
+    host = synthetic_batches(4, B_LOCAL, T_LEN, CFG2["in_dim"], seed=1234 + rank)
+    resident = []
+    for hb in host:
+        resident.append(dict(x=torch.from_numpy(hb["x"]).to(dev).to(adt).view(B_LOCAL * T_LEN, -1),
+                             labels=torch.from_numpy(hb["labels"]).to(dev).view(B_LOCAL * T_LEN, -1),
+                             seq_lens=torch.from_numpy(hb["seq_lens"]).to(dev), classes=torch.from_numpy(hb["classes"]).to(dev)))
+    reduce_fn = parallel.make_grad_allreduce(dist) if world > 1 else None
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def feed(i):
+            rb = resident[i % len(resident)]
+            plan.roll[:, : cfg.in_dim].copy_(rb["x"])
+            plan.labels.copy_(rb["labels"])
+            plan.seq_lens.copy_(rb["seq_lens"])
+            plan.classes.copy_(rb["classes"])
+
+        feed(0)
+        plan.step_kernels(True, reduce_fn=reduce_fn)  # first step eager (HIP module loads), then capture
+        torch.cuda.synchronize()
+        plan.capture(True, split_optimizer=world > 1)
+
+        def one_step(i):
+            feed(i)
+            plan.run(reduce_fn=reduce_fn)
+
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        m = plan.metrics()
+        roof = dominant_kernel_roofline(plan, o) if rank == 0 else None
+
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    frames = B_LOCAL * T_LEN * world * args.steps
+    step_flops = 3.0 * fwd_flops(CFG2, B_LOCAL, T_LEN)
+    out = {
+        "metric": "piano-roll frames/s (VAE train step)", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: single-track piano-roll VAE train step, T=256, pitch=128, latent=64, "
+                               f"batch={B_LOCAL}/GPU, {args.dtype}; encoder 256x2x8h, decoder 128x1x8h (scripts/train-vae.sh), "
+                               f"dropout {args.dropout}; Xavier-initialised weights",
+                   "global_batch": B_LOCAL * world, "seq_len": T_LEN, "pitches": CFG2["in_dim"], "parallelism": f"dp{world}",
+                   "params": store.n_params},
+        "step_tflops": step_flops / (ms * 1e-3) / 1e12,
+        "step_mfma_frac": step_flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+        "elbo": m["total_loss"], "kl": m["kl_loss"],
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,11 @@ def load():
         raise MstError(
             f"{LIB_PATH} is missing: build it with `python -m musicstyletransfer_amd.csrc.build` "
             "(there is no CPU fallback for the training step)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7. It must be in the process BEFORE this library
+    # is dlopen()ed, so that our NEEDED libamdhip64.so.7 binds to that same runtime instance (same SONAME):
+    # torch's hipStream_t handles and device pointers are then valid in our launches. Loaded the other way
+    # round, two HIP runtimes coexist and the second reports "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -1,0 +1,65 @@
+"""Data parallelism for the VAE step: one process per GPU, the minibatch sharded contiguously, ONE
+collective per step — a SUM all-reduce of the flat fp32 gradient bucket (RCCL over xGMI; `nccl` IS RCCL
+on ROCm) — followed by the same fused Adam on every rank.
+
+The reference has no counterpart (single context everywhere: main.py:124, trainer.py:75,99-101); the
+only cross-sample operation in its step is the implicit sum over the batch in loss.backward() plus the
+1/B of Trainer.step(batch_size) (trainer.py:176-177). Hence:
+  * every rank normalises by the GLOBAL batch size (StepPlan(global_batch=...)),
+  * every rank pads to the GLOBAL batch-max length, because SoftmaxCrossEntropy divides by the padded
+    length T (loss.py:23) and data.py:196-198 truncates to the batch maximum,
+  * parameters, Adam state and positional tables are replicated; initial weights are identical on every
+    rank (same seed), and identical reduced gradients keep them identical.
+The bucket is 7.5 MB (configs[1]); xGMI is point-to-point (7 links x ~153 GB/s per GPU), so the
+collective costs tens of microseconds and is issued as a single call on the step's stream between the
+captured forward/backward graph and the captured optimizer graph.
+"""
+import os
+
+import numpy as np
+import torch
+
+
+def init_process_group(world, rank, backend=None):
+    """env:// rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
+    return dist
+
+
+def make_grad_allreduce(dist):
+    """returns reduce_fn(flat_grad): in-place SUM over ranks, asynchronous on the current stream (nccl) or
+    blocking (gloo, CPU tests)"""
+    def reduce_fn(flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return reduce_fn
+
+
+def shard_bounds(global_batch, world, rank):
+    """contiguous shard [lo, hi) of the global batch for `rank`"""
+    assert global_batch % world == 0, "global batch must divide evenly over the ranks"
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_batch(batch, world, rank):
+    """slice every per-sample array of a batch dict; the padded length (axis 1) is left at the global
+    batch maximum on purpose (see module docstring)"""
+    B = len(batch["seq_lens"])
+    lo, hi = shard_bounds(B, world, rank)
+    return {k: v[lo:hi] for k, v in batch.items()}
+
+
+def global_eps(seed, step, global_batch, latent_dim, lo, hi):
+    """eps drawn per GLOBAL sample index, so results do not depend on how the batch is sharded"""
+    rng = np.random.default_rng([seed, step])
+    return rng.standard_normal((global_batch, latent_dim)).astype(np.float32)[lo:hi]
