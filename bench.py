@@ -62,10 +62,16 @@ def synthetic_batches(n, B, T, P, seed):
     return out
 
 
-def cpu_baseline(steps=2):
+def cpu_baseline(steps=3):
     """time the CPU oracle on a bounded sample: `steps` training steps of the same B=64, T=256 batch"""
     from oracle import vae_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: 16 cores (asking torch for every core the kernel
+    # reports oversubscribes that share and runs ~50x slower)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(CFG2["kind"], CFG2["in_dim"], CFG2["out_dim"], CFG2["num_classes"], CFG2["latent_dim"],
                          CFG2["e_model"], CFG2["e_layers"], CFG2["e_heads"], CFG2["d_model"], CFG2["d_layers"], CFG2["d_heads"])

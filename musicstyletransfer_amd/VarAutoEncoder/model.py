@@ -1,0 +1,124 @@
+"""Model / config classes with the reference's signatures (VarAutoEncoder/model.py:22-54,275-296), backed by
+the MI355X step engine.
+
+    Model(config)(tokens, seq_lens, classes) -> (probs, means, vars)
+
+`tokens` is [B, T] token ids (the reference's path) or [B, T, P] {0,1} piano-roll frames (the piano-roll
+ends). Parameters live in one flat HBM buffer (engine.ParamStore); `.encoder` / `.decoder` expose them by
+name. The model must be placed on a HIP device before it is called: there is no CPU forward."""
+import sys
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from .config import Config
+from .transformer import TransformerConfig  # noqa: F401
+
+
+class LSTMConfig(Config):  # kept for config files that name it (model.py:11-19); the LSTM decoder is dead code there
+    def __init__(self, n_layers: int, hidden_dim: int, dropout: float):
+        super().__init__()
+        self.n_layers, self.hidden_dim, self.dropout = n_layers, hidden_dim, dropout
+
+
+class DecoderConfig(Config):
+    def __init__(self, transformer_config, latent_dim: int, num_classes: int, output_dim: int):
+        super().__init__()
+        self.transformer_config = transformer_config
+        self.latent_dim, self.num_classes, self.output_dim = latent_dim, num_classes, output_dim
+
+
+class EncoderConfig(Config):
+    def __init__(self, transformer_config, latent_dim: int, num_classes: int, input_dim: int):
+        super().__init__()
+        self.transformer_config = transformer_config
+        self.latent_dim, self.num_classes, self.input_dim = latent_dim, num_classes, input_dim
+
+
+class ModelConfig(Config):
+    def __init__(self, encoder_config: EncoderConfig, decoder_config: DecoderConfig, kind: str = "token"):
+        super().__init__()
+        self.encoder_config, self.decoder_config = encoder_config, decoder_config
+        self.kind = kind  # 'token' (reference) or 'pianoroll'
+
+    def to_engine(self):
+        e, d = self.encoder_config, self.decoder_config
+        te, td = e.transformer_config, d.transformer_config
+        assert e.latent_dim == d.latent_dim and e.num_classes == d.num_classes
+        return E.VAEConfig(self.kind, e.input_dim, d.output_dim, e.num_classes, e.latent_dim, te.model_size, te.num_layers,
+                           te.num_heads, td.model_size, td.num_layers, td.num_heads, te.dropout, td.dropout)
+
+
+class _ParamGroup:
+    """name -> fp32 parameter view of one half of the model (what collect_params() gives in the reference)"""
+
+    def __init__(self, model, prefix):
+        self._model, self._prefix = model, prefix
+
+    def collect_params(self):
+        st = self._model.store
+        return {n: st.p(n) for n in st.shapes if n.startswith(self._prefix)}
+
+
+class Model:
+    def __init__(self, config: ModelConfig, *args, **kwargs):
+        print("Creating a model with the following configuration:")
+        config.output_to_stream(sys.stdout)
+        self.config = config
+        self.engine_config = config.to_engine()
+        self.store = None
+        self._plans = {}
+        self.encoder = _ParamGroup(self, "encoder.")
+        self.decoder = _ParamGroup(self, "decoder.")
+        self.act_dtype = torch.bfloat16
+
+    # -- placement / initialisation (model.initialize(mx.init.Xavier(), ctx), trainer.py:103-105)
+    def initialize(self, ctx=None, seed=1234, params_np=None, act_dtype=None):
+        dev = ctx.device if hasattr(ctx, "device") else (ctx if ctx is not None else torch.device("cuda", 0))
+        if torch.device(dev).type != "cuda":
+            raise RuntimeError("the VarAutoEncoder step runs on hand-written HIP kernels only: no CPU path exists "
+                               "(pass --gpu / a HIP device)")
+        if act_dtype is not None:
+            self.act_dtype = act_dtype
+        self.store = E.ParamStore(self.engine_config, torch.device(dev), self.act_dtype, params_np=params_np, seed=seed)
+        self._plans = {}
+        return self
+
+    def collect_params(self):
+        return {n: self.store.p(n) for n in self.store.shapes}
+
+    def plan(self, B, T, **hyper):
+        key = (B, T, tuple(sorted(hyper.items())))
+        if key not in self._plans:
+            self._plans[key] = E.StepPlan(self.store, B, T, **hyper)
+        return self._plans[key]
+
+    def __call__(self, tokens, seq_lens, classes, eps=None):
+        """forward only (model.py:287-296): returns (probs, means, vars) as device tensors"""
+        if self.store is None:
+            raise RuntimeError("call initialize(ctx) first")
+        x = np.asarray(tokens.cpu() if torch.is_tensor(tokens) else tokens)
+        B, T = x.shape[0], x.shape[1]
+        plan = self.plan(B, T, want_probs=True, internal_eps=eps is None)
+        cfg = self.engine_config
+        dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
+        plan.load_batch(x, seq_lens, classes, dummy, eps)
+        plan.forward()
+        plan.losses(with_grad=False)
+        V = cfg.out_dim
+        probs = plan.probs[:, :V].float().view(B, T, V)
+        return probs, plan.mu, plan.sigma
+
+    # -- checkpoints (utils.save_model / load_model_parameters)
+    def save_parameters(self, fname):
+        np.savez(fname if fname.endswith(".npz") else fname + ".npz", **self.store.to_numpy("w"))
+
+    def load_parameters(self, fname, ctx=None):
+        f = fname if fname.endswith(".npz") else fname + ".npz"
+        with np.load(f) as z:
+            params = {k: z[k] for k in z.files}
+        if self.store is None:
+            self.initialize(ctx, params_np=params)
+        else:
+            self.store.load_numpy(params)

@@ -1,0 +1,73 @@
+"""File helpers (reference VarAutoEncoder/utils.py:15-70): checkpoint discovery, parameter and training-state
+persistence. On-disk names are the reference's (`params.N`, `train_state.pkl`); the parameter format is a
+numpy .npz of name -> array (the reference's is MXNet's binary NDArray file). Fixed here: the checkpoint
+index regex (`(\\d)+` there captures only the last digit, utils.py:18-20)."""
+import os
+import pickle
+import re
+
+
+class Context:
+    """what mx.gpu() / mx.cpu() are in the reference (main.py:124): a device selector"""
+
+    def __init__(self, kind, index=0):
+        import torch
+        self.kind = kind
+        self.device = torch.device("cuda", index) if kind == "gpu" else torch.device("cpu")
+
+    def __repr__(self):
+        return f"{self.kind}({self.device.index or 0})"
+
+
+def gpu(index=None):
+    if index is None:
+        index = int(os.environ.get("LOCAL_RANK", "0"))
+    return Context("gpu", index)
+
+
+def cpu():
+    return Context("cpu")
+
+
+def create_directory_if_not_present(path):
+    if path and not os.path.exists(path):
+        os.makedirs(path, exist_ok=True)
+
+
+def get_latest_checkpoint_index(model_folder):
+    best = None
+    for name in os.listdir(model_folder):
+        m = re.fullmatch(r"params\.(\d+)(\.npz)?", name)
+        if m:
+            best = max(best or 0, int(m.group(1)))
+    if best is None:
+        raise FileNotFoundError("no checkpoint in " + model_folder)
+    return best
+
+
+def save_model(model, path):
+    model.save_parameters(path)
+
+
+def load_model_parameters(model, path, context):
+    model.load_parameters(path, context)
+
+
+def save_object(obj, path):
+    with open(path, "wb") as f:
+        pickle.dump(obj, f)
+
+
+def load_object(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def log_config(config):
+    import sys
+    config.output_to_stream(sys.stdout)
+
+
+def log_model_variables(model):
+    for name, shape in model.store.shapes.items() if model.store is not None else []:
+        print(name, shape)

@@ -71,12 +71,15 @@ __global__ __launch_bounds__(256) void group_colsum_kernel(int64_t T_len, int D,
                                                            int64_t S_out, int64_t s_off,
                                                            const int32_t* __restrict__ idx, float* __restrict__ dst,
                                                            int64_t ldd, float alpha) {
+  // grid = (cdiv(D,256), B, chunks of 32 frames): each thread sums one column over its chunk, one atomic each
   const int64_t b = blockIdx.y;
   const int d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
+  const int64_t t0 = (int64_t)blockIdx.z * 32;
+  const int64_t t1 = t0 + 32 < T_len ? t0 + 32 : T_len;
   const T* base = X + (b * S_out + s_off) * ldx + d;
   float acc = 0.f;
-  for (int64_t t = 0; t < T_len; ++t) acc += to_f32(base[t * ldx]);
+  for (int64_t t = t0; t < t1; ++t) acc += to_f32(base[t * ldx]);
   atomicAdd(dst + (int64_t)idx[b] * ldd + d, alpha * acc);
 }
 
@@ -117,7 +120,7 @@ extern "C" int mst_group_colsum(int dtype, int64_t B, int64_t T, int64_t D, cons
   MST_CHECK_ARG(B <= 65535, "mst_group_colsum: B too large for grid.y");
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) TT;
-    hipLaunchKernelGGL((group_colsum_kernel<TT>), dim3((unsigned)cdiv(D, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, T,
+    hipLaunchKernelGGL((group_colsum_kernel<TT>), dim3((unsigned)cdiv(D, 256), (unsigned)B, (unsigned)cdiv(T, 32)), dim3(256), 0, (hipStream_t)stream, T,
                        (int)D, (const TT*)X, ldx, S_out, s_off, idx, dst, ldd, alpha);
     MST_CHECK_LAUNCH("group_colsum_kernel");
     return MST_OK;

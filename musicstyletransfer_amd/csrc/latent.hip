@@ -17,8 +17,10 @@
 
 namespace mst {
 
+constexpr int LAT_THREADS = 1024;  // 16 waves: these kernels are B workgroups of dependent dot products (latency-bound)
+
 template <typename T>
-__global__ __launch_bounds__(256) void latent_fwd_kernel(int De, int Z, int Dd, const T* __restrict__ enc_out,
+__global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, int Dd, const T* __restrict__ enc_out,
                                                          int64_t enc_stride, const float* __restrict__ Wl,
                                                          const float* __restrict__ bl, const float* __restrict__ eps,
                                                          const float* __restrict__ Wh, const float* __restrict__ bh,
@@ -32,13 +34,14 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(int De, int Z, int Dd, 
   float* h0 = sm;            // [De]
   float* lat = sm + De;      // [2Z]
   float* zs = lat + 2 * Z;   // [Z]
-  __shared__ float klred[4];
+  __shared__ float klred[LAT_THREADS / 64];
+  constexpr int NW = LAT_THREADS / 64;
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int d = tid; d < De; d += 256) h0[d] = to_f32(enc_out[b * enc_stride + d]);
+  for (int d = tid; d < De; d += LAT_THREADS) h0[d] = to_f32(enc_out[b * enc_stride + d]);
   __syncthreads();
   // one wave per output, lanes across the contraction (coalesced weight rows)
-  for (int j = wave; j < 2 * Z; j += 4) {
+  for (int j = wave; j < 2 * Z; j += NW) {
     float acc = 0.f;
     for (int d = lane; d < De; d += 64) acc += h0[d] * Wl[(int64_t)j * De + d];
     acc = wave_sum(acc);
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(int De, int Z, int Dd, 
   }
   __syncthreads();
   float klacc = 0.f;
-  for (int i = tid; i < Z; i += 256) {
+  for (int i = tid; i < Z; i += LAT_THREADS) {
     const float m = lat[i], s = lat[Z + i];
     const float zz = m + eps[b * Z + i] * s;
     mu[b * Z + i] = m;
@@ -59,9 +62,13 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(int De, int Z, int Dd, 
   klacc = wave_sum(klacc);
   if (lane == 0) klred[wave] = klacc;
   __syncthreads();
-  if (tid == 0) kl[b] = klred[0] + klred[1] + klred[2] + klred[3];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w) t += klred[w];
+    kl[b] = t;
+  }
   const int c = classes[b];
-  for (int j = wave; j < Dd; j += 4) {
+  for (int j = wave; j < Dd; j += NW) {
     float acc = 0.f;
     for (int i = lane; i < Z; i += 64) acc += zs[i] * Wh[(int64_t)j * Z + i];
     acc = wave_sum(acc);
@@ -94,10 +101,19 @@ __global__ __launch_bounds__(256) void latent_bwd_vec_kernel(int De, int Z, int 
     tvec[b * Dd + j] = v;
   }
   __syncthreads();
-  // dz[i] = sum_j t[j] * Wh[j,i]  (thread per i: consecutive threads read consecutive Wh columns)
-  for (int i = tid; i < Z; i += 256) {
+  // dz[i] = sum_j t[j] * Wh[j,i]: thread (i, part) sums a quarter of j (consecutive threads read consecutive
+  // Wh columns), the parts are combined through LDS
+  float* part = dl + 2 * Z;  // [4][max(Z, De)] scratch
+  const int nparts = 4;
+  for (int w = tid; w < Z * nparts; w += 256) {
+    const int i = w % Z, pt = w / Z;
     float acc = 0.f;
-    for (int j = 0; j < Dd; ++j) acc += t[j] * Wh[(int64_t)j * Z + i];
+    for (int j = pt; j < Dd; j += nparts) acc += t[j] * Wh[(int64_t)j * Z + i];
+    part[pt * Z + i] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < Z; i += 256) {
+    const float acc = (part[i] + part[Z + i]) + (part[2 * Z + i] + part[3 * Z + i]);
     const float m = mu[b * Z + i], s = sigma[b * Z + i];
     // gscale: loss scale of everything upstream of here (the encoder); enc_scale = gscale / (loss scale the
     // incoming decoder-side gradient carries). Both are 1 unless fp16 loss scaling is on.
@@ -125,9 +141,16 @@ __global__ __launch_bounds__(256) void batch_outer_kernel(int64_t B, int J, int 
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (int64_t)J * I) {
     const int j = (int)(idx / I), i = (int)(idx % I);
-    float acc = 0.f;
-    for (int64_t b = 0; b < B; ++b) acc += L[b * J + j] * to_f32(R[b * r_stride + i]);
-    out[idx] += acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // independent chains: the loop is load-latency bound
+    int64_t b = 0;
+    for (; b + 4 <= B; b += 4) {
+      a0 += L[(b + 0) * J + j] * to_f32(R[(b + 0) * r_stride + i]);
+      a1 += L[(b + 1) * J + j] * to_f32(R[(b + 1) * r_stride + i]);
+      a2 += L[(b + 2) * J + j] * to_f32(R[(b + 2) * r_stride + i]);
+      a3 += L[(b + 3) * J + j] * to_f32(R[(b + 3) * r_stride + i]);
+    }
+    for (; b < B; ++b) a0 += L[b * J + j] * to_f32(R[b * r_stride + i]);
+    out[idx] += (a0 + a1) + (a2 + a3);
   }
   if (obias && idx < J) {
     float acc = 0.f;
@@ -163,7 +186,7 @@ extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   MST_CHECK_ARG(lds <= 60000, "mst_latent_fwd: De + 3Z too large for one workgroup");
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((latent_fwd_kernel<T>), dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, (int)De, (int)Z,
+    hipLaunchKernelGGL((latent_fwd_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
                        (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
                        alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
     MST_CHECK_LAUNCH("latent_fwd_kernel");
@@ -185,7 +208,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   hipStream_t s = (hipStream_t)stream;
   float* tvec = scratch;            // [B, Dd]
   float* dlat = scratch + B * Dd;   // [B, 2Z]
-  const size_t lds = sizeof(float) * (Dd + 2 * Z);
+  const size_t lds = sizeof(float) * (Dd + 2 * Z + 4 * Z);
   int rc = dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(256), lds, s, (int)De, (int)Z, (int)Dd, Wl, eps,

@@ -210,7 +210,9 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
   MST_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "mst_layernorm_bwd: mask_mode must be 0,1,2");
   MST_CHECK_ARG(mask_mode != 1 || (dx_masked && ld_dxm % 4 == 0 && ld_dxm >= D), "mst_layernorm_bwd: mask_mode 1 needs dx_masked");
   MST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mst_layernorm_bwd: dropout_p must be in [0,1)");
-  const unsigned grid = (unsigned)(cdiv(M, 16) < 1024 ? cdiv(M, 16) : 1024);
+  // one workgroup per CU: every workgroup ends with one atomic per column on the SAME 2*D addresses, so the
+  // count of workgroups (not rows) sets the contention
+  const unsigned grid = (unsigned)(cdiv(M, 16) < 256 ? cdiv(M, 16) : 256);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,

@@ -1,0 +1,80 @@
+"""Data-parallel correctness by construction, on CPU with gloo at world_size 2: sharding the global batch,
+summing the per-rank gradient buckets and normalising by the GLOBAL batch reproduces the single-process step
+(the oracle stands in for the per-rank compute; the collective, the shard bounds and the global-length / global-
+batch conventions are the product code of musicstyletransfer_amd/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from musicstyletransfer_amd import parallel
+    from oracle import vae_oracle as O
+    dist = parallel.init_process_group(world, rank, backend="gloo")
+    rng = np.random.default_rng(11)
+    cfg = O.OracleConfig("token", 20, 20, 2, 8, 16, 1, 2, 16, 1, 2)
+    params = O.init_params(cfg, rng)
+    params["encoder.latent_proj.bias"][8:] += 1.5
+    B, T = 4, 9
+    lens = np.array([9, 5, 7, 6])
+    x = np.zeros((B, T), np.int64)
+    labels = np.zeros((B, T), np.int64)
+    for b in range(B):
+        d = rng.integers(3, 20, size=lens[b] - 1)
+        x[b, 0], x[b, 1:lens[b]] = 1, d
+        labels[b, : lens[b] - 1], labels[b, lens[b] - 1] = d, 2
+    batch = {"x": torch.from_numpy(x), "seq_lens": torch.from_numpy(lens), "classes": torch.tensor([0, 1, 1, 0]),
+             "labels": torch.from_numpy(labels)}
+    lo, hi = parallel.shard_bounds(B, world, rank)
+    eps_all = parallel.global_eps(3, 0, B, 8, 0, B)
+    eps = parallel.global_eps(3, 0, B, 8, lo, hi)
+    assert np.array_equal(eps, eps_all[lo:hi])
+    shard = parallel.shard_batch(batch, world, rank)
+    assert shard["x"].shape == (B // world, T)  # padded length stays global
+    P = O.to_torch_params(params)
+    loss = O.step_losses(P, cfg, shard, torch.from_numpy(eps))[0]
+    loss.sum().backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in P.values()])
+    parallel.make_grad_allreduce(dist)(flat)  # the one collective of the step
+    if rank == 0:
+        Pf = O.to_torch_params(params)
+        O.step_losses(Pf, cfg, batch, torch.from_numpy(eps_all))[0].sum().backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in Pf.values()])
+        q.put(float((flat - ref).abs().max() / ref.abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gradients_sum_to_the_global_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err < 1e-5, err
+
+
+def test_shard_bounds():
+    from musicstyletransfer_amd import parallel
+    assert [parallel.shard_bounds(512, 8, r) for r in (0, 7)] == [(0, 64), (448, 512)]
+    with pytest.raises(AssertionError):
+        parallel.shard_bounds(10, 4, 0)
