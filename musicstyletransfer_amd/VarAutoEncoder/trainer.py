@@ -68,6 +68,7 @@ class Trainer:
         self._initialize_optimizers()
         # the step runs (and is captured) on its own stream: the legacy default stream cannot be captured
         self.stream = torch.cuda.Stream(device=self.model.store.device)
+        torch.cuda.synchronize()  # parameter upload ran on the default stream; torch side streams do not wait for it
         self._captured = set()
         self._plans_used = []
         self.train_state = TrainingState()
@@ -203,8 +204,10 @@ class Trainer:
                 st.m.copy_(torch.from_numpy(z["m"]))
                 st.v.copy_(torch.from_numpy(z["v"]))
                 st.step_state.copy_(torch.from_numpy(z["step_state"]))
+        torch.cuda.synchronize()
 
     def _checkpoint(self, model_folder, validation_dataset):
+        self.stream.synchronize()  # the state below is read on the default stream
         self.train_state.n_checkpoints += 1
         n = self.train_state.n_checkpoints
         print("\nCheckpoint {} reached.".format(n))
