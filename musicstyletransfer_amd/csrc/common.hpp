@@ -113,10 +113,26 @@ __host__ __device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint32_
   x ^= x >> 32;
   return (uint32_t)x;
 }
+// Four keep decisions from ONE 64-bit mix (16 bits each): element idx uses bit (idx & 3) of the word drawn
+// for idx >> 2. keep iff field >= thr with thr = floor(p * 65536); the inverted-dropout scale uses the exact keep
+// probability (65536 - thr) / 65536 so the mask is unbiased.
+__host__ __device__ __forceinline__ uint32_t dropout_thr(float p) { return (uint32_t)(p * 65536.0f); }
+__host__ __device__ __forceinline__ float dropout_inv_keep(float p) {
+  return p > 0.f ? 65536.0f / (65536.0f - (float)dropout_thr(p)) : 1.f;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_keep4(uint64_t seed, uint32_t site, uint64_t idx4, float p) {
+  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx4 * 0xD1B54A32D192ED03ull);
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  const uint32_t thr = dropout_thr(p);
+  uint32_t m = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m |= (uint32_t)(((uint32_t)(x >> (16 * e)) & 0xFFFFu) >= thr) << e;
+  return m;
+}
 __host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, float p) {
-  // keep with probability 1-p
-  uint32_t thr = (uint32_t)((double)p * 4294967296.0);
-  return dropout_hash(seed, site, idx) >= thr;
+  return (dropout_keep4(seed, site, idx >> 2, p) >> (idx & 3)) & 1u;
 }
 
 template <typename F> static inline int dispatch_act(int dtype, F&& f) {

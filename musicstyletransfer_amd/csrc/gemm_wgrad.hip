@@ -24,6 +24,21 @@ struct WgradBatch {
 
 constexpr int BMR = 64;  // m rows per LDS stage
 
+// XOR swizzle of the 16-byte chunk index inside a tile row, chosen so that ds_read_tr16_b64 — whose 32-lane half
+// reads rows r0..r0+3 and r0+8..r0+11 of the same 16 columns — touches 32 distinct 8-byte slots (all 64 banks).
+// Unswizzled row-major tiles measured 75 % of LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+//   256-byte rows (128 columns): chunk ^= ((row & 3) << 2) | ((row >> 2) & 3)
+//   128-byte rows ( 64 columns): chunk ^= (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)
+template <int COLS>
+__device__ __forceinline__ int swz(int row) {
+  if (COLS == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+  return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+}
+template <int COLS>
+__device__ __forceinline__ int swz_off(int row, int col) {  // element offset of (row, col) in a swizzled [rows][COLS] tile
+  return row * COLS + ((((col >> 3) ^ swz<COLS>(row)) << 3) | (col & 7));
+}
+
 __device__ __forceinline__ i16x4 tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
 }
@@ -37,6 +52,7 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   constexpr int A_CH = BMR * A_CPR / NT, B_CH = BMR * B_CPR / NT;
   static_assert(BMR * A_CPR % NT == 0 && BMR * B_CPR % NT == 0, "tile/threads mismatch");
   static_assert(NT % A_CPR == 0 && NT % B_CPR == 0, "column ownership must be loop-invariant");
+  static_assert((BN == 64 || BN == 128) && (BKO == 64 || BKO == 128), "swizzles exist for 64- and 128-column tiles");
   typedef typename Act<T>::vec8 vec8;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,10 +122,10 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      *reinterpret_cast<u32x4*>(sA + (buf * BMR + a_row[i]) * BN + a_col[i]) = ra[i];
+      *reinterpret_cast<u32x4*>(sA + buf * BMR * BN + swz_off<BN>(a_row[i], a_col[i])) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      *reinterpret_cast<u32x4*>(sB + (buf * BMR + b_row[i]) * BKO + b_col[i]) = rb[i];
+      *reinterpret_cast<u32x4*>(sB + buf * BMR * BKO + swz_off<BKO>(b_row[i], b_col[i])) = rb[i];
     if (do_bias) {
       // every chunk this thread owns covers the same 8 columns (NT % A_CPR == 0)
 #pragma unroll
@@ -147,16 +163,16 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int c = wn * WTN + j * 16 + pcol;
-        i16x4 lo = tr_read(cA + (r_lo)*BN + c);
-        i16x4 hi = tr_read(cA + (r_lo + 4) * BN + c);
+        i16x4 lo = tr_read(cA + swz_off<BN>(r_lo, c));
+        i16x4 hi = tr_read(cA + swz_off<BN>(r_lo + 4, c));
         i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[j] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll
       for (int i = 0; i < TK; ++i) {
         const int c = wk * WTK + i * 16 + pcol;
-        i16x4 lo = tr_read(cB + (r_lo)*BKO + c);
-        i16x4 hi = tr_read(cB + (r_lo + 4) * BKO + c);
+        i16x4 lo = tr_read(cB + swz_off<BKO>(r_lo, c));
+        i16x4 hi = tr_read(cB + swz_off<BKO>(r_lo + 4, c));
         i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bf[i] = __builtin_bit_cast(vec8, v);
       }
@@ -241,7 +257,7 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
     if (list[i].M > maxM) maxM = list[i].M;
   }
   // tile size: 128x128 when that still leaves enough tiles to fill the chip at a modest split
-  const bool big = out_elems >= (int64_t)128 * 128 * 96;
+  const bool big = out_elems >= (int64_t)128 * 128 * 24;
   const int bn = big ? 128 : 64;
   b.tile_prefix[0] = 0;
   for (int i = 0; i < n; ++i)
@@ -249,7 +265,9 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
   for (int i = n + 1; i <= WG_MAXP; ++i) b.tile_prefix[i] = b.tile_prefix[n];
   const int64_t tiles = b.tile_prefix[n];
   // aim for >= 1024 workgroups, at least 2 LDS stages (128 rows) per workgroup
-  int64_t split = cdiv(1024, tiles);
+  // 128x128 tiles run 2 workgroups per CU at most (register file), 64x64 tiles 5: aim for one full wave of
+  // workgroups, no more — every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
+  int64_t split = cdiv(big ? 512 : 1024, tiles);
   int64_t max_split = cdiv(maxM, 2 * BMR);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;

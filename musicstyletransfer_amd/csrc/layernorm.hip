@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int nvec = D / 4;
-  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const float inv_keep = dropout_inv_keep(p);
   float dg[LN_MAXV][4], db[LN_MAXV][4];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i)
@@ -136,11 +136,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
       int c = lane + i * 64;
       if (c < nvec) {
         float o[4], om[4];
+        uint32_t keep4 = 0xFu;  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
+        if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(m * D + c * 4) >> 2, p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
           if (mask_mode != 0) {
-            float k = (p > 0.f) ? (dropout_keep(seed, site, (uint64_t)(m * D + c * 4 + e), p) ? inv_keep : 0.f) : 1.f;
+            float k = (p > 0.f) ? (((keep4 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
             if (mask_mode == 1) om[e] = o[e] * k; else o[e] = o[e] * (1.f + k);
           }
         }
