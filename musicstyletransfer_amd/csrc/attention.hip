@@ -27,6 +27,28 @@ constexpr int ATT_STAGE = 64;   // rows staged in LDS per step
 constexpr int ATT_WG_ROWS = 128;  // owner rows per workgroup (4 waves x 32)
 constexpr float MASK_VALUE = -1e9f;
 constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Softmax probabilities are evaluated as  P[k,q] = exp2(x * sk2[k] + ck2[k])  with per-key constants
+//   unmasked key: sk2 = scale*log2(e),  ck2 = -(rowmax + log(rowsum)) * log2(e)
+//   padded key  : sk2 = 0,              ck2 = -log(rowsum) * log2(e)
+//   key >= S    : sk2 = 0,              ck2 = -inf                       (P = 0, no per-element guard)
+// i.e. one FMA and one v_exp_f32 per element. For a padded key this is exact only while |x*scale| < 32, where
+// fl(x*scale - 1e9) == -1e9 == rowmax and the logit cancels (transformer.py:111-125). Beyond that the reference's
+// fp32 sum lands on another multiple of 64 and the row stops being uniform, so whenever a tile holds a padded key
+// the kernels take the EXACT path instead (exact_prob: the reference's operation order in fp32); the fast form is
+// used for tiles without padding (all of them in a full-length batch).
+__device__ __forceinline__ void key_consts(bool in_range, bool valid_key, float rmax, float logl, float scale, float& sk2,
+                                           float& ck2) {
+  if (!in_range) { sk2 = 0.f; ck2 = -INFINITY; }
+  else if (!valid_key) { sk2 = 0.f; ck2 = -logl * LOG2E; }
+  else { sk2 = scale * LOG2E; ck2 = -(rmax + logl) * LOG2E; }
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// the reference's arithmetic, step by step: t = fl(x*scale + madd); p = exp((t - rowmax) - log(rowsum))
+__device__ __forceinline__ float exact_prob(float x, float scale, float madd, float rmax, float logl) {
+  return fast_exp2(((fmaf(x, scale, madd) - rmax) - logl) * LOG2E);
+}
 
 __device__ __forceinline__ i16x4 att_tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
-        t[r] = valid ? x[r] * a.scale + madd : NEG_BIG;
+        t[r] = valid ? fmaf(x[r], a.scale, madd) : NEG_BIG;
         tmax = fmaxf(tmax, t[r]);
       }
       const float m_new = fmaxf(m, tmax);
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
   __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
-  __shared__ float sMax[ATT_STAGE], sLogl[ATT_STAGE], sMadd[ATT_STAGE];
+  __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
@@ -189,13 +211,17 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
     __syncthreads();
     stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
     stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    int padded = 0;
     if (tid < ATT_STAGE) {
       const int64_t k = k0 + tid;
-      sMax[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
-      sLogl[tid] = (k < S) ? a.lse[plane + bh * S + k] : 0.f;
-      sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
+      const bool in = k < S;
+      const bool vk = in && a.keymask[b * S + k];
+      const float rm = in ? a.lse[bh * S + k] : 0.f, ll = in ? a.lse[plane + bh * S + k] : 0.f;
+      key_consts(in, vk, rm, ll, a.scale, sSk[tid], sCk[tid]);
+      sMadd[tid] = vk ? 0.f : MASK_VALUE; sMax[tid] = rm; sLogl[tid] = in ? ll : INFINITY;
+      padded = in && !vk;
     }
-    __syncthreads();
+    const bool exact = __syncthreads_or(padded);  // wave-uniform: does this stage hold a padded key?
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
@@ -203,9 +229,20 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sK, blk * 32, s, lane), qf[s], x);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = blk * 32 + acc_row(r, lane);
-        x[r] = (k0 + kr < S) ? __expf(((x[r] * a.scale + sMadd[kr]) - sMax[kr]) - sLogl[kr]) : 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) {  // accumulator rows 4g..4g+3 are 4 consecutive keys: one 16-byte read each
+        const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
+        if (!exact) {
+          const f32x4 sk = *reinterpret_cast<const f32x4*>(sSk + kr);
+          const f32x4 ck = *reinterpret_cast<const f32x4*>(sCk + kr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[4 * g4 + e] = fast_exp2(fmaf(x[4 * g4 + e], sk[e], ck[e]));
+        } else {
+          const f32x4 ma = *reinterpret_cast<const f32x4*>(sMadd + kr);
+          const f32x4 mx = *reinterpret_cast<const f32x4*>(sMax + kr);
+          const f32x4 ll = *reinterpret_cast<const f32x4*>(sLogl + kr);  // +inf for keys >= S: p = 0
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[4 * g4 + e] = exact_prob(x[4 * g4 + e], a.scale, ma[e], mx[e], ll[e]);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -252,12 +289,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
     vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
   }
-  const float madd = (k_lane < S && a.keymask[b * S + k_lane]) ? 0.f : MASK_VALUE;
-  const float rmax = (k_lane < S) ? a.lse[bh * S + k_lane] : 0.f;
-  const float logl = (k_lane < S) ? a.lse[a.B * a.H * S + bh * S + k_lane] : 0.f;
+  float sk2, ck2, madd, rmax, logl;
+  bool exact;
+  {
+    const bool in = k_lane < S;
+    const bool vk = in && a.keymask[b * S + k_lane];
+    rmax = in ? a.lse[bh * S + k_lane] : 0.f;
+    logl = in ? a.lse[a.B * a.H * S + bh * S + k_lane] : INFINITY;
+    madd = vk ? 0.f : MASK_VALUE;
+    key_consts(in, vk, rmax, in ? logl : 0.f, a.scale, sk2, ck2);
+    exact = __any(in && !vk);  // wave-uniform: one of this wave's 32 keys is padded
+  }
 
   f32x16 acc[DB];
-  float delta = 0.f;
+  float delta = 0.f, delta_s = 0.f;
   // pass 0: dV and delta; pass 1: dK
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -276,16 +321,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
           x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, blk * 32, s, lane), kf[s], x);
           dp = Act<T>::mfma32(lds_row_frag<T, DH>(sdO, blk * 32, s, lane), vf[s], dp);
         }
+        // query rows >= S need no guard: their staged Q and dO rows are zero, so whatever P they get
+        // multiplies zeros in dV, delta and dK
+        if (exact) {  // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
-          const float p = valid ? __expf(((x[r] * a.scale + madd) - rmax) - logl) : 0.f;
-          if (pass == 0) {
-            delta += p * dp[r];
-            x[r] = p;
-          } else {
-            x[r] = p * (dp[r] - delta) * a.scale;
-          }
+          for (int r = 0; r < 16; ++r) x[r] = exact_prob(x[r], a.scale, madd, rmax, logl);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = fast_exp2(fmaf(x[r], sk2, ck2));
+        }
+        if (pass == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) delta = fmaf(x[r], dp[r], delta);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] *= fmaf(dp[r], a.scale, -delta_s);
         }
         const T* tr_src = (pass == 0) ? sdO : sQ;
 #pragma unroll
@@ -300,6 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     if (pass == 0) {
       delta += __shfl_xor(delta, 32, 64);
       if (lane < 32 && k_lane < S) a.delta[bh * S + k_lane] = delta;
+      delta_s = delta * a.scale;
     }
     T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + (pass == 0 ? a.v_off : a.k_off);
 #pragma unroll
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
   __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
-  __shared__ float sMax[ATT_STAGE], sLogl[ATT_STAGE], sMadd[ATT_STAGE], sDelta[ATT_STAGE];
+  __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sDs[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
@@ -348,14 +399,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
     __syncthreads();
     stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
     stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    int padded = 0;
     if (tid < ATT_STAGE) {
       const int64_t k = k0 + tid;
-      sMax[tid] = (k < S) ? a.lse[bh * S + k] : 0.f;
-      sLogl[tid] = (k < S) ? a.lse[a.B * a.H * S + bh * S + k] : 0.f;
-      sDelta[tid] = (k < S) ? a.delta[bh * S + k] : 0.f;
-      sMadd[tid] = (k < S && a.keymask[b * S + k]) ? 0.f : MASK_VALUE;
+      const bool in = k < S;
+      const bool vk = in && a.keymask[b * S + k];
+      const float rm = in ? a.lse[bh * S + k] : 0.f, ll = in ? a.lse[a.B * a.H * S + bh * S + k] : 0.f;
+      key_consts(in, vk, rm, ll, a.scale, sSk[tid], sCk[tid]);
+      sMadd[tid] = vk ? 0.f : MASK_VALUE; sMax[tid] = rm; sLogl[tid] = in ? ll : INFINITY;
+      sDs[tid] = in ? a.delta[bh * S + k] * a.scale : 0.f;
+      padded = in && !vk;
     }
-    __syncthreads();
+    const bool exact = __syncthreads_or(padded);
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
@@ -366,10 +421,24 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
         dp = Act<T>::mfma32(lds_row_frag<T, DH>(sV, blk * 32, s, lane), dof[s], dp);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = blk * 32 + acc_row(r, lane);
-        const float p = (k0 + kr < S) ? __expf(((x[r] * a.scale + sMadd[kr]) - sMax[kr]) - sLogl[kr]) : 0.f;
-        x[r] = p * (dp[r] - sDelta[kr]) * a.scale;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
+        const f32x4 ds = *reinterpret_cast<const f32x4*>(sDs + kr);
+        float pr[4];
+        if (!exact) {
+          const f32x4 sk = *reinterpret_cast<const f32x4*>(sSk + kr);
+          const f32x4 ck = *reinterpret_cast<const f32x4*>(sCk + kr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pr[e] = fast_exp2(fmaf(x[4 * g4 + e], sk[e], ck[e]));
+        } else {
+          const f32x4 ma = *reinterpret_cast<const f32x4*>(sMadd + kr);
+          const f32x4 mx = *reinterpret_cast<const f32x4*>(sMax + kr);
+          const f32x4 ll = *reinterpret_cast<const f32x4*>(sLogl + kr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pr[e] = exact_prob(x[4 * g4 + e], a.scale, ma[e], mx[e], ll[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * g4 + e] = pr[e] * fmaf(dp[4 * g4 + e], a.scale, -ds[e]);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

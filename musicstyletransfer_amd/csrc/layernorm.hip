@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t M, int D, co
 
 // mask_mode: 0 = dx only; 1 = dx and dxm = dx * keep/(1-p); 2 = dx <- dx * (1 + keep/(1-p))
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, const T* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, const T* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
@@ -93,11 +93,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int mask_mode, float p, uint64_t seed_in, uint32_t site,
                                                             const uint64_t* __restrict__ seed_ptr) {
-  __shared__ float red[2][4][LN_MAXV * 256];
+  // blockDim = 64 * NW waves (NW chosen by the host so that the [2][NW][D] reduction buffer fits 32 KiB):
+  // many waves per workgroup hide the row-after-row load latency, few workgroups keep the same-address
+  // atomics of the parameter gradients rare
+  extern __shared__ float red_dyn[];
+  const int NW = blockDim.x >> 6;
+  float* red0 = red_dyn;            // [NW][D]
+  float* red1 = red_dyn + NW * D;   // [NW][D]
   const uint64_t seed = seed_in ^ ((p > 0.f && seed_ptr) ? seed_ptr[0] : 0ull);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave_global = (int64_t)blockIdx.x * NW + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
   const int nvec = D / 4;
   const float inv_keep = dropout_inv_keep(p);
   float dg[LN_MAXV][4], db[LN_MAXV][4];
@@ -158,15 +164,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t M, int D, co
     if (c < nvec) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        red[0][wave][c * 4 + e] = dg[i][e];
-        red[1][wave][c * 4 + e] = db[i][e];
+        red0[wave * D + c * 4 + e] = dg[i][e];
+        red1[wave * D + c * 4 + e] = db[i][e];
       }
     }
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float a = red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d];
-    float b = red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < NW; ++w) { a += red0[w * D + d]; b += red1[w * D + d]; }
     atomicAdd(dgamma + d, a);
     atomicAdd(dbeta + d, b);
   }
@@ -214,10 +220,14 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
   MST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mst_layernorm_bwd: dropout_p must be in [0,1)");
   // one workgroup per CU: every workgroup ends with one atomic per column on the SAME 2*D addresses, so the
   // count of workgroups (not rows) sets the contention
-  const unsigned grid = (unsigned)(cdiv(M, 16) < 256 ? cdiv(M, 16) : 256);
+  int nw = (int)(32768 / (8 * D));  // reduction buffer 2 * nw * D floats <= 32 KiB
+  if (nw > 16) nw = 16;
+  if (nw < 1) nw = 1;
+  const unsigned grid = (unsigned)(cdiv(M, 4 * nw) < 256 ? cdiv(M, 4 * nw) : 256);
+  const size_t lds = (size_t)2 * nw * D * sizeof(float);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
                        (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
                        dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr);
     MST_CHECK_LAUNCH("layernorm_bwd_kernel");

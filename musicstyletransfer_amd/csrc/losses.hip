@@ -101,13 +101,21 @@ __global__ __launch_bounds__(256) void sigmoid_bce_kernel(int64_t rows_per_sampl
       x[0] = bits_to_f32<T>((uint16_t)(raw[0] & 0xffff)); x[1] = bits_to_f32<T>((uint16_t)(raw[0] >> 16));
       x[2] = bits_to_f32<T>((uint16_t)(raw[1] & 0xffff)); x[3] = bits_to_f32<T>((uint16_t)(raw[1] >> 16));
     }
+    uint32_t lab4 = 0;  // four label bytes in one load when the row is 4-byte aligned
+    if (P % 4 == 0) {
+      lab4 = *reinterpret_cast<const uint32_t*>(labels + r * P + c0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < P) lab4 |= (uint32_t)labels[r * P + c0 + e] << (8 * e);
+    }
     float pv[4], gv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = c0 + e;
       pv[e] = 0.f; gv[e] = 0.f;
       if (c < P) {
-        const float y = (float)labels[r * P + c];
+        const float y = (float)((lab4 >> (8 * e)) & 0xFFu);
         const float p = 1.f / (1.f + __expf(-x[e]));
         const float omp = 1.f - p;
         const float s = (1.f - ls) * y + 0.5f * ls;
