@@ -209,7 +209,10 @@ int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ld
                       const void* dy, int64_t ldy, void* dx, int64_t ld_dx,
                       void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
                       int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
-                      const uint64_t* dropout_seed_ptr, mst_stream_t stream);
+                      const uint64_t* dropout_seed_ptr,
+                      int64_t row_id_stride /* row m here is row m*row_id_stride of the forward (mean/rstd index and
+                                               dropout counter); 1 for a dense pass */,
+                      mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K8/K9/K10 latent block (model.py:97-103,292,229-232; loss.py:8-12), fp32 math:

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
                                                             T* __restrict__ dxm, int64_t ld_dxm,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int mask_mode, float p, uint64_t seed_in, uint32_t site,
-                                                            const uint64_t* __restrict__ seed_ptr) {
+                                                            const uint64_t* __restrict__ seed_ptr, int64_t row_id_stride) {
   // blockDim = 64 * NW waves (NW chosen by the host so that the [2][NW][D] reduction buffer fits 32 KiB):
   // many waves per workgroup hide the row-after-row load latency, few workgroups keep the same-address
   // atomics of the parameter gradients rare
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
 
   for (int64_t m = wave_global; m < M; m += nwaves) {
-    const float mean = mean_in[m], rstd = rstd_in[m];
+    // rows may be a strided subset of the forward's rows (e.g. position 0 of every sample): statistics and the
+    // dropout counter are indexed by the forward's row id
+    const int64_t rid = m * row_id_stride;
+    const float mean = mean_in[rid], rstd = rstd_in[rid];
     float xh[LN_MAXV][4], g[LN_MAXV][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
       if (c < nvec) {
         float o[4], om[4];
         uint32_t keep4 = 0xFu;  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
-        if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(m * D + c * 4) >> 2, p);
+        if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(rid * D + c * 4) >> 2, p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
@@ -210,7 +213,7 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
                                  const float* mean, const float* rstd, const void* dy, int64_t ldy, void* dx,
                                  int64_t ld_dx, void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
                                  int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
-                                 const uint64_t* dropout_seed_ptr, mst_stream_t stream) {
+                                 const uint64_t* dropout_seed_ptr, int64_t row_id_stride, mst_stream_t stream) {
   int rc = ln_check(M, D, ldx, ldy);
   if (rc) return rc;
   MST_CHECK_ARG(x && gamma && mean && rstd && dy && dx && dgamma && dbeta, "mst_layernorm_bwd: null pointer");
@@ -229,7 +232,8 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
     typedef decltype(tag) T;
     hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
                        (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
-                       dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr);
+                       dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
+                       row_id_stride > 0 ? row_id_stride : 1);
     MST_CHECK_LAUNCH("layernorm_bwd_kernel");
     return MST_OK;
   });

@@ -321,6 +321,16 @@ class StepPlan:
         #   d_enc_out: d(encoder output) - only row 0 of each sample written, by latent_bwd (model.py:97)
         self.d_dec_out = act(self.Md, Dd)
         self.d_enc_out = act(self.Me, De)
+        # Top encoder layer, backward: the loss reads the encoder only at position 0 (model.py:97), so the gradient
+        # entering the last layer is non-zero in B of its B*T rows, and LayerNorm / FFN / W_proj are row-wise: their
+        # backward runs on those B rows (strided views), exactly. Only attention mixes rows; it gets its dO through
+        # sp_datt and the residual branch through sp_dh1, full-size buffers whose other rows are never written.
+        c = _Layer()
+        c.dh, c.dhm, c.dx1, c.dh1m = act(B, De), act(B, De), act(B, De), act(B, De)
+        c.dpre = act(B, 4 * De)
+        self.top = c
+        self.sp_dh1 = act(self.Me, De)
+        self.sp_datt = act(self.Me, De)
         self.graph = None
         self.graph_opt = None
 
@@ -469,6 +479,51 @@ class StepPlan:
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
         ])
 
+    def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t):
+        """_layer_bwd for the LAST encoder layer, on the B rows (position 0 of each sample) that carry gradient."""
+        cfg, st, B, S = self.cfg, self.store, self.B, self.T
+        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, 3 * i
+        pre = f"encoder.layer{i}"
+        c = self.top
+        inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+        dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
+
+        def row0(buf):  # [B, ld] view of position 0 of every sample (row stride S*ld)
+            return buf.view(B, S, -1)[:, 0, :]
+
+        dy = row0(self.d_enc_out)
+        if p > 0:
+            o.layernorm_bwd(row0(L.h2), st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, c.dh, st.grad(f"{pre}.ln2.gamma"),
+                            st.grad(f"{pre}.ln2.beta"), D=D, M=B, row_id_stride=S, dx_masked=c.dhm, mask_mode=1,
+                            dropout_site=site0 + 2, **dk)
+            dff = c.dhm
+        else:
+            o.layernorm_bwd(row0(L.h2), st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, c.dh, st.grad(f"{pre}.ln2.gamma"),
+                            st.grad(f"{pre}.ln2.beta"), D=D, M=B, row_id_stride=S)
+            dff = c.dh
+        o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), c.dpre, N=4 * D, K=D, gate=row0(L.a), alpha=inv_keep)
+        o.gemm_nt(c.dpre, st.t(f"{pre}.ff1.weight"), c.dx1, N=D, K=4 * D, resid=c.dh)
+        dh1_rows = row0(self.sp_dh1)
+        if p > 0:
+            o.layernorm_bwd(row0(L.h1), st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, c.dx1, dh1_rows, st.grad(f"{pre}.ln1.gamma"),
+                            st.grad(f"{pre}.ln1.beta"), D=D, M=B, row_id_stride=S, dx_masked=c.dh1m, mask_mode=1,
+                            dropout_site=site0, **dk)
+            dproj = c.dh1m
+        else:
+            o.layernorm_bwd(row0(L.h1), st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, c.dx1, dh1_rows, st.grad(f"{pre}.ln1.gamma"),
+                            st.grad(f"{pre}.ln1.beta"), D=D, M=B, row_id_stride=S)
+            dproj = dh1_rows
+        # d(attention output): rows b*S of a buffer that is zero elsewhere
+        o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
+        o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D)
+        o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
+        o.gemm_wgrad_batch([
+            o.wgrad_problem(dff, row0(L.a), st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), M=B, N=D, K=4 * D),
+            o.wgrad_problem(c.dpre, row0(L.x1), st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), M=B, N=4 * D, K=D),
+            o.wgrad_problem(dproj, row0(L.att), st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), M=B, N=D, K=D),
+            o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
+        ])
+
     def backward(self):
         cfg, st, B, T = self.cfg, self.store, self.B, self.T
         De, Dd = cfg.e_model, cfg.d_model
@@ -507,8 +562,11 @@ class StepPlan:
         dy, tgt, nxt = self.d_enc_out, be.dx_a, be.dx_b
         for i in reversed(range(cfg.e_layers)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
-            self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
-                            3 * i, be)
+            if i == cfg.e_layers - 1:
+                self._top_encoder_layer_bwd(i, self.enc[i], x_in, tgt, be)
+            else:
+                self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
+                                3 * i, be)
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_e = dy
         if cfg.kind == "token":

@@ -120,12 +120,12 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5):
 
 
 def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, D=None, dx_masked=None, mask_mode=0, dropout_p=0.0,
-                  dropout_seed=0, dropout_site=0, dropout_seed_ptr=None):
-    M = x.shape[0]
+                  dropout_seed=0, dropout_site=0, dropout_seed_ptr=None, M=None, row_id_stride=1):
+    M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
     call("mst_layernorm_bwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ld(dy), ptr(dx),
          ld(dx), ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0), ptr(dgamma), ptr(dbeta), mask_mode,
-         dropout_p, dropout_seed, dropout_site, ptr(dropout_seed_ptr), stream())
+         dropout_p, dropout_seed, dropout_site, ptr(dropout_seed_ptr), row_id_stride, stream())
 
 
 # --------------------------------------------------------------------------- embedding / masks
