@@ -81,7 +81,7 @@ int mst_event_destroy(void* ev);
  *               lives at physical row (m / rpg)*stride + offset + (m % rpg)   (model.py:253 drops row 0)
  *   c_rows_per_group/...: same remap for C rows (model.py:244 concat after the initial state)
  *   dropout   : p in [0,1); if p > 0 the epilogue applies inverted dropout with the
- *               counter-based mask mst_dropout_keep(seed, site, m*N+n) (transformer.py:35,149,182)
+ *               counter-based mask keep(seed, site, row*N+n), row = PHYSICAL output row (transformer.py:35,149,182)
  *   self_resid: out = t + dropout(t) (decoder LN3(ff + dropout(ff)), transformer.py:199-200)
  * Epilogue order: t = alpha*(acc + bias + grpadd) -> act -> [u = dropout(t); self_resid: u += t]
  *                 -> + rowadd -> + resid -> gate.
@@ -179,7 +179,10 @@ int mst_mask_from_lengths(int64_t B, int64_t S, const int32_t* lens, int32_t add
 int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh,
                             const void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
                             const uint8_t* keymask, float* lse,
-                            void* out, int64_t ld_out, mst_stream_t stream);
+                            void* out, int64_t ld_out,
+                            int64_t q_limit /* produce only queries [0, q_limit); <= 0 or >= S: all. The row statistics
+                                               always cover every query (they normalise over the query axis) */,
+                            mst_stream_t stream);
 
 /* dqkv has the same layout as qkv; delta is fp32 scratch [B, H, S]. */
 int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh,
@@ -202,7 +205,9 @@ int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t 
  * ------------------------------------------------------------------------ */
 int mst_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ldx,
                       const float* gamma, const float* beta, float eps,
-                      void* y, int64_t ldy, float* mean, float* rstd, mst_stream_t stream);
+                      void* y, int64_t ldy, float* mean, float* rstd,
+                      int64_t row_id_stride /* statistics of row m are stored at index m*row_id_stride (1 = dense) */,
+                      mst_stream_t stream);
 
 int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ldx,
                       const float* gamma, const float* mean, const float* rstd,

@@ -123,6 +123,7 @@ struct AttnArgs {
   void* dqkv; int64_t ld_dqkv;
   float* delta;
   float scale;
+  int64_t q_limit;  // forward: only queries [0, q_limit) are produced (the top encoder layer needs query 0 alone)
 };
 
 // ------------------------------------------------------------------------------------ fwd_stats
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
   f32x16 o[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
+  const bool wave_active = q_wave0 < a.q_limit;  // inactive waves still stage tiles and meet the barriers
 
   for (int64_t k0 = 0; k0 < S; k0 += ATT_STAGE) {
     __syncthreads();
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
       padded = in && !vk;
     }
     const bool exact = __syncthreads_or(padded);  // wave-uniform: does this stage hold a padded key?
+    if (!wave_active) continue;
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t q = q_wave0 + acc_row(r, lane);
-        if (q < S) og[q * a.ld_out + col] = (T)o[d][r];
+        if (q < S && q < a.q_limit) og[q * a.ld_out + col] = (T)o[d][r];
       }
     }
   }
@@ -475,7 +478,8 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
   hipLaunchKernelGGL((attn_fwd_stats_kernel<T, DH>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_fwd_stats_kernel");
-  hipLaunchKernelGGL((attn_fwd_out_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  dim3 grid_o((unsigned)cdiv(a.q_limit, ATT_WG_ROWS), (unsigned)(a.B * a.H));
+  hipLaunchKernelGGL((attn_fwd_out_kernel<T, DH>), grid_o, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_fwd_out_kernel");
   return MST_OK;
 }
@@ -496,7 +500,7 @@ using namespace mst;
 extern "C" int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* qkv,
                                        int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
                                        const uint8_t* keymask, float* lse, void* out, int64_t ld_out,
-                                       mst_stream_t stream) {
+                                       int64_t q_limit, mst_stream_t stream) {
   int rc = attn_check(B, S, H, dh, ld_qkv, k_off, q_off, v_off);
   if (rc) return rc;
   MST_CHECK_ARG(qkv && keymask && lse && out, "mst_attn_keysoftmax_fwd: null pointer");
@@ -504,6 +508,7 @@ extern "C" int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t 
   AttnArgs a = {};
   a.B = B; a.S = S; a.H = H; a.qkv = qkv; a.ld_qkv = ld_qkv; a.k_off = k_off; a.q_off = q_off; a.v_off = v_off;
   a.keymask = keymask; a.lse = lse; a.out = out; a.ld_out = ld_out;
+  a.q_limit = (q_limit > 0 && q_limit < S) ? q_limit : S;
   a.scale = 1.f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(dtype, [&](auto tag) -> int {

@@ -222,9 +222,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = fmaxf((t[e] + bias8[e]) * alpha, relu_floor);
         if (has_drop || a.self_resid) {
-          uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (m*N + nc) starts a 4-decision word
+          uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
           if (has_drop) {
-            const uint64_t w = (uint64_t)(m * a.N + nc) >> 2;
+            const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
             keep8 = dropout_keep4(dseed, a.dropout_site, w, a.dropout_p) | (dropout_keep4(dseed, a.dropout_site, w + 1, a.dropout_p) << 4);
           }
 #pragma unroll

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t M, int D, co
                                                             const float* __restrict__ beta, float eps,
                                                             T* __restrict__ y, int64_t ldy,
                                                             float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out) {
+                                                            float* __restrict__ rstd_out, int64_t row_id_stride) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t M, int D, co
         store4<T>(y + m * ldy + c * 4, o);
       }
     }
-    if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+    if (lane == 0) { mean_out[m * row_id_stride] = mean; rstd_out[m * row_id_stride] = rstd; }
   }
 }
 
@@ -195,7 +195,7 @@ static int ln_check(int64_t M, int64_t D, int64_t ldx, int64_t ldy) {
 
 extern "C" int mst_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ldx, const float* gamma,
                                  const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
-                                 mst_stream_t stream) {
+                                 int64_t row_id_stride, mst_stream_t stream) {
   int rc = ln_check(M, D, ldx, ldy);
   if (rc) return rc;
   MST_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mst_layernorm_fwd: null pointer");
@@ -203,7 +203,7 @@ extern "C" int mst_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x,
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
-                       (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd);
+                       (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd, row_id_stride > 0 ? row_id_stride : 1);
     MST_CHECK_LAUNCH("layernorm_fwd_kernel");
     return MST_OK;
   });

@@ -357,10 +357,39 @@ class StepPlan:
     def _drop(self, p, site):
         return dict(dropout_p=p, dropout_site=site, dropout_seed_ptr=self.rng_state) if p > 0 else {}
 
+    def _top_encoder_layer_fwd(self, i, L, x_in):
+        """Last encoder layer: the model reads its output at position 0 only (model.py:97) and everything after the
+        attention mix is row-wise, so after the dense K/Q/V projection and the softmax row statistics (which
+        normalise over ALL queries) only query 0 is attended and only B rows go through W_proj, LN1, the FFN and LN2.
+        The other rows of these buffers are never produced nor read (backward: _top_encoder_layer_bwd)."""
+        cfg, st, B, S = self.cfg, self.store, self.B, self.T
+        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, 3 * i
+        pre = f"encoder.layer{i}"
+
+        def row0(buf):
+            return buf.view(B, S, -1)[:, 0, :]
+
+        o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
+        o.attn_fwd(L.qkv, self.keymask_e, L.lse, L.att, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
+        rows = (1, S, 0)  # output row b -> physical row b*S
+        o.gemm_nt(row0(L.att), st.h(f"{pre}.att.W_proj.weight"), L.h1, M=B, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
+                  resid=row0(x_in), c_remap=rows, **self._drop(p, site0))
+        o.layernorm_fwd(row0(L.h1), st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), row0(L.x1), L.mean1, L.rstd1, D=D, M=B,
+                        row_id_stride=S)
+        o.gemm_nt(row0(L.x1), st.h(f"{pre}.ff1.weight"), L.a, M=B, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU,
+                  c_remap=rows, **self._drop(p, site0 + 1))
+        o.gemm_nt(row0(L.a), st.h(f"{pre}.ff2.weight"), L.h2, M=B, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), resid=row0(L.x1),
+                  c_remap=rows, **self._drop(p, site0 + 2))
+        o.layernorm_fwd(row0(L.h2), st.p(f"{pre}.ln2.gamma"), st.p(f"{pre}.ln2.beta"), row0(L.x2), L.mean2, L.rstd2, D=D, M=B,
+                        row_id_stride=S)
+        return L.x2
+
     def _layer_fwd(self, side, i, L, x_in, keymask, D, H, S, p, site0):
         st = self.store
         pre = f"{side}.layer{i}"
         dh = D // H
+        if side == "encoder" and i == self.cfg.e_layers - 1:
+            return self._top_encoder_layer_fwd(i, L, x_in)
         o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
         o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
         o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),

@@ -101,9 +101,9 @@ def gemm_wgrad(A, B, dW, db=None, **kw):
 
 
 # --------------------------------------------------------------------------- attention
-def attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off):
+def attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off, q_limit=0):
     call("mst_attn_keysoftmax_fwd", dt(qkv), B, S, H, dh, ptr(qkv), ld(qkv), k_off, q_off, v_off, ptr(keymask),
-         ptr(lse), ptr(out), ld(out), stream())
+         ptr(lse), ptr(out), ld(out), q_limit, stream())
 
 
 def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off):
@@ -112,11 +112,11 @@ def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_
 
 
 # --------------------------------------------------------------------------- LayerNorm
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5):
-    M = x.shape[0]
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5, M=None, row_id_stride=1):
+    M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
     call("mst_layernorm_fwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(beta), eps, ptr(y), ld(y), ptr(mean),
-         ptr(rstd), stream())
+         ptr(rstd), row_id_stride, stream())
 
 
 def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, D=None, dx_masked=None, mask_mode=0, dropout_p=0.0,

@@ -231,6 +231,23 @@ def test_attention_fwd_bwd(gpu, B, S, H, dh):
     close(dqkv[:, q_off:q_off + D], g[:, q_off:q_off + D], 3e-2, 3e-2 * scale, "dQ")
 
 
+def test_attention_q_limit_produces_only_the_first_queries(gpu):
+    o = ops()
+    B, S, H, dh = 2, 70, 2, 32
+    D = H * dh
+    qkv = rnd((B * S, 3 * D), gpu, seed=34)
+    keymask = torch.ones(B, S, dtype=torch.uint8, device=gpu)
+    lse = torch.zeros(2, B, H, S, dtype=torch.float32, device=gpu)
+    full = torch.zeros(B * S, D, dtype=BF, device=gpu)
+    part = torch.full((B * S, D), 5.0, dtype=BF, device=gpu)
+    o.attn_fwd(qkv, keymask, lse, full, B, S, H, dh, 0, D, 2 * D)
+    o.attn_fwd(qkv, keymask, lse, part, B, S, H, dh, 0, D, 2 * D, q_limit=1)
+    torch.cuda.synchronize()
+    f3, p3 = full.view(B, S, D), part.view(B, S, D)
+    assert torch.equal(p3[:, 0], f3[:, 0])
+    assert (p3[:, 1:] == 5.0).all()
+
+
 def test_attention_padded_key_rows_are_uniform(gpu):
     """a padded key row is NOT excluded, it contributes V[k]/S to every query"""
     o = ops()
@@ -274,6 +291,23 @@ def test_layernorm_fwd_bwd(gpu, M, D):
     close(dx, xr.grad, 1e-2, 1e-2, "ln dx")
     close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dgamma")
     close(db, br.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dbeta")
+    # strided row subset (every 4th row), statistics indexed by the dense row id
+    if M % 4 == 0:
+        Ms = M // 4
+        xs, dys = x.view(Ms, 4 * D)[:, :D], dy.view(Ms, 4 * D)[:, :D]
+        y2 = torch.zeros(M, D, dtype=BF, device=gpu)
+        mean2 = torch.zeros(M, dtype=torch.float32, device=gpu)
+        rstd2 = torch.zeros(M, dtype=torch.float32, device=gpu)
+        o.layernorm_fwd(xs, gamma, beta, y2.view(Ms, 4 * D)[:, :D], mean2, rstd2, D=D, M=Ms, row_id_stride=4)
+        dx2 = torch.zeros(Ms, D, dtype=BF, device=gpu)
+        dg2 = torch.zeros(D, dtype=torch.float32, device=gpu)
+        db2 = torch.zeros(D, dtype=torch.float32, device=gpu)
+        o.layernorm_bwd(xs, gamma, mean2, rstd2, dys, dx2, dg2, db2, D=D, M=Ms, row_id_stride=4)
+        torch.cuda.synchronize()
+        assert torch.equal(y2[::4], y[::4]) and (y2.view(Ms, 4, D)[:, 1:] == 0).all()
+        assert torch.equal(mean2[::4], mean[::4]) and (mean2.view(Ms, 4)[:, 1:] == 0).all()
+        assert torch.equal(dx2, dx[::4])
+        close(db2, dy.float()[::4].sum(0), 1e-3, 1e-3 * math.sqrt(M), "strided dbeta")
 
 
 def test_layernorm_bwd_dropout_modes(gpu):
