@@ -23,7 +23,17 @@
 
 namespace mst {
 
-constexpr int ATT_STAGE = 64;   // rows staged in LDS per step
+// rows staged in LDS per step: the whole key (or query) range of a 256-long sequence in ONE stage, so a workgroup
+// pays one exposed global-load latency and two barriers instead of four of each (the kernels are latency-bound:
+// 60 % of wave cycles were waits with 64-row stages)
+#ifndef MST_ATT_STAGE
+#define MST_ATT_STAGE 64
+#endif
+template <int DH> struct Stage { static constexpr int ROWS = MST_ATT_STAGE; };
+// LDS row stride of the staged tiles: +8 elements (16 bytes). With rows of exactly DH*2 = 32/64/128 bytes the
+// 16-byte row-fragment reads of 16 different rows fall on 4 bank groups (4-way conflict, measured 57 % of LDS cycles
+// in attn_bwd_kv); 80-byte rows put them on 16 distinct ones and leave the transposed reads at most 2-way.
+template <int DH> struct LdsLd { static constexpr int V = DH + 8; };
 constexpr int ATT_WG_ROWS = 128;  // owner rows per workgroup (4 waves x 32)
 constexpr float MASK_VALUE = -1e9f;
 constexpr float NEG_BIG = -3.0e38f;
@@ -58,18 +68,20 @@ __device__ __forceinline__ i16x4 att_tr_read(const void* p) {
 template <typename T, int DH>
 __device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, int64_t ld, int64_t row0, int64_t S, int tid) {
   constexpr int CPR = DH / 8;
+  constexpr int ATT_STAGE = Stage<DH>::ROWS;
+#pragma unroll 4
   for (int c = tid; c < ATT_STAGE * CPR; c += 256) {
     const int r = c / CPR, ch = c % CPR;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row0 + r < S) v = *reinterpret_cast<const u32x4*>(g + (row0 + r) * ld + ch * 8);
-    *reinterpret_cast<u32x4*>(lds + r * DH + ch * 8) = v;
+    *reinterpret_cast<u32x4*>(lds + r * LdsLd<DH>::V + ch * 8) = v;
   }
 }
 
 // row fragment (A or B operand, k-contiguous) of rows [r0, r0+32) from an LDS tile with DH columns
 template <typename T, int DH>
 __device__ __forceinline__ typename Act<T>::vec8 lds_row_frag(const T* tile, int r0, int s, int lane) {
-  const u32x4 v = *reinterpret_cast<const u32x4*>(tile + (r0 + (lane & 31)) * DH + 16 * s + 8 * (lane >> 5));
+  const u32x4 v = *reinterpret_cast<const u32x4*>(tile + (r0 + (lane & 31)) * LdsLd<DH>::V + 16 * s + 8 * (lane >> 5));
   return __builtin_bit_cast(typename Act<T>::vec8, v);
 }
 
@@ -89,8 +101,8 @@ __device__ __forceinline__ typename Act<T>::vec8 lds_tr_frag(const T* tile, int 
   const int h = lane >> 5, i = lane & 15, q = i >> 2, p = i & 3;
   const int c0 = (DH >= 32) ? d0 + 16 * ((lane >> 4) & 1) : 0;
   const int rlo = r0 + 16 * s2 + 4 * h + q;
-  const i16x4 lo = att_tr_read(tile + rlo * DH + c0 + 4 * p);
-  const i16x4 hi = att_tr_read(tile + (rlo + 8) * DH + c0 + 4 * p);
+  const i16x4 lo = att_tr_read(tile + rlo * LdsLd<DH>::V + c0 + 4 * p);
+  const i16x4 hi = att_tr_read(tile + (rlo + 8) * LdsLd<DH>::V + c0 + 4 * p);
   const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(typename Act<T>::vec8, v);
 }
@@ -129,8 +141,9 @@ struct AttnArgs {
 // ------------------------------------------------------------------------------------ fwd_stats
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
+  constexpr int ATT_STAGE = Stage<DH>::ROWS;
   constexpr int KS = DH / 16;
-  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * LdsLd<DH>::V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
@@ -185,9 +198,10 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------ fwd_out
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
+  constexpr int ATT_STAGE = Stage<DH>::ROWS;
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
-  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
-  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * LdsLd<DH>::V];
+  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
@@ -272,9 +286,10 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------ bwd_kv
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+  constexpr int ATT_STAGE = Stage<DH>::ROWS;
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
-  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * DH];
-  __shared__ __attribute__((aligned(16))) T sdO[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * LdsLd<DH>::V];
+  __shared__ __attribute__((aligned(16))) T sdO[ATT_STAGE * LdsLd<DH>::V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
@@ -373,9 +388,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------ bwd_q
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+  constexpr int ATT_STAGE = Stage<DH>::ROWS;
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
-  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * DH];
-  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * DH];
+  __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * LdsLd<DH>::V];
+  __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sDs[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;

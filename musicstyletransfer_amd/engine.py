@@ -313,8 +313,15 @@ class StepPlan:
             t.delta = torch.zeros(B, H, S, **f32)
             return t
 
-        self.be = bwd_bufs(self.Me, De, cfg.e_heads, Se)
-        self.bd = bwd_bufs(self.Md, Dd, cfg.d_heads, Sd)
+        # one set per layer: a layer's weight-gradient GEMMs run on the side stream while the main stream already
+        # works on the next layer, so the operands they read must not be that layer's scratch
+        self.be_l = [bwd_bufs(self.Me, De, cfg.e_heads, Se) for _ in range(cfg.e_layers)]
+        self.bd_l = [bwd_bufs(self.Md, Dd, cfg.d_heads, Sd) for _ in range(cfg.d_layers)]
+        self.be, self.bd = self.be_l[0], self.bd_l[0]
+        self.side_stream = torch.cuda.Stream(device=dev)
+        # hipGraph on ROCm 7.2 replays such fork/join branches back to back on one queue (rocprofv3 kernel trace), so
+        # the fork buys nothing today; the plumbing (per-layer scratch, _side) stays for runtimes that overlap them
+        self.use_side_stream = False
         self.lat_scratch = torch.zeros(B * (Dd + 2 * Z), **f32)
         # Sparse gradient carriers, never used as ping-pong targets so their untouched rows stay zero:
         #   d_dec_out: d(decoder output) - rows 1..T written by the output-layer dgrad, row 0 always 0 (model.py:253)
@@ -500,13 +507,27 @@ class StepPlan:
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
         o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
-        # all four weight gradients of the layer in one launch
-        o.gemm_wgrad_batch([
+        # all four weight gradients of the layer in one launch, off the critical path
+        self._side(lambda: o.gemm_wgrad_batch([
             o.wgrad_problem(dff, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=D, K=4 * D),
             o.wgrad_problem(t.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * D, K=D),
             o.wgrad_problem(dproj, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=D, K=D),
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
-        ])
+        ]))
+
+    def _side(self, fn):
+        """Run `fn` (weight-gradient kernels: they feed nothing but the optimizer) on the side stream, ordered after
+        everything issued so far on the main stream; backward() joins the side stream before it returns. Captured
+        into the step's hipGraph as a fork/join, this lets the latency-bound wgrad kernels fill the issue slots the
+        equally latency-bound dgrad / attention chain leaves idle."""
+        if not self.use_side_stream:
+            return fn()
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.side_stream):
+            self.side_stream.wait_event(ev)
+            fn()
 
     def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t):
         """_layer_bwd for the LAST encoder layer, on the B rows (position 0 of each sample) that carry gradient."""
@@ -546,12 +567,12 @@ class StepPlan:
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
         o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D)
         o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
-        o.gemm_wgrad_batch([
+        self._side(lambda: o.gemm_wgrad_batch([
             o.wgrad_problem(dff, row0(L.a), st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), M=B, N=D, K=4 * D),
             o.wgrad_problem(c.dpre, row0(L.x1), st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), M=B, N=4 * D, K=D),
             o.wgrad_problem(dproj, row0(L.att), st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), M=B, N=D, K=D),
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
-        ])
+        ]))
 
     def backward(self):
         cfg, st, B, T = self.cfg, self.store, self.B, self.T
@@ -559,26 +580,25 @@ class StepPlan:
         Se, Sd = T, T + 1
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
         o.zero(st.g)
-        bd, be = self.bd, self.be
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
-        o.gemm_wgrad(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
-                     st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1))
-        dy, tgt, nxt = self.d_dec_out, bd.dx_a, bd.dx_b
+        self._side(lambda: o.gemm_wgrad(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
+                                        st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1)))
+        dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
         site_d = 3 * cfg.e_layers
         for i in reversed(range(cfg.d_layers)):
             x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d
             self._layer_bwd("decoder", i, self.dec[i], x_in, dy, tgt, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout,
-                            site_d + 3 * i, bd)
+                            site_d + 3 * i, self.bd_l[i])
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_d = dy  # gradient w.r.t. the decoder input [B, Sd, Dd]
         # ---- decoder input: rows 1..T -> embedding, row 0 -> latent block
         if cfg.kind == "token":
             o.embed_bwd(self.tokens, st.grad("decoder.embedding.weight"), d_x0_d.view(B, Sd, -1), 1, sq_d)
         else:
-            o.gemm_wgrad(self.roll, d_x0_d, st.grad("decoder.embedding.weight"), M=B * T, N=cfg.out_dim, K=Dd, scale=sq_d,
-                         b_remap=(T, Sd, 1))
+            self._side(lambda: o.gemm_wgrad(self.roll, d_x0_d, st.grad("decoder.embedding.weight"), M=B * T, N=cfg.out_dim,
+                                            K=Dd, scale=sq_d, b_remap=(T, Sd, 1)))
         # gradient w.r.t. the encoder output: zero except position 0 of every sample
         d_enc = self.d_enc_out
         o.latent_bwd(self.enc_out.view(B, Se, -1), st.p("encoder.latent_proj.weight"), self.eps,
@@ -588,14 +608,14 @@ class StepPlan:
                      st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"),
                      st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
                      enc_scale=self.gscale_enc / self.gscale)
-        dy, tgt, nxt = self.d_enc_out, be.dx_a, be.dx_b
+        dy, tgt, nxt = self.d_enc_out, self.be_l[0].dx_a, self.be_l[0].dx_b
         for i in reversed(range(cfg.e_layers)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
             if i == cfg.e_layers - 1:
-                self._top_encoder_layer_bwd(i, self.enc[i], x_in, tgt, be)
+                self._top_encoder_layer_bwd(i, self.enc[i], x_in, tgt, self.be_l[i])
             else:
                 self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
-                                3 * i, be)
+                                3 * i, self.be_l[i])
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_e = dy
         if cfg.kind == "token":
@@ -604,6 +624,8 @@ class StepPlan:
         else:
             o.gemm_wgrad(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim, K=De, scale=sq_e)
             o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
+        if self.use_side_stream:
+            torch.cuda.current_stream().wait_stream(self.side_stream)  # join: the optimizer reads every gradient
 
     def optimizer(self):
         st = self.store
