@@ -324,6 +324,13 @@ int mst_zero(void* ptr, int64_t bytes, mst_stream_t stream);
 /* device-resident per-step RNG seed: state = uint64[3] {seed for this step, step counter, base seed};
  * one launch per step advances it, so dropout masks and eps differ on every replay of a captured graph */
 int mst_rng_advance(uint64_t* state, mst_stream_t stream);
+/* Top-of-step bookkeeping in ONE launch (every kernel in the captured graph costs ~4.7 us): mst_rng_advance, Adam's
+ * step counter / bias-corrected lr (then call mst_adam_flat with advance_step = 0), mst_randn into eps_out, and the two
+ * mst_mask_from_lengths masks (model.py:246-247). Any pointer may be NULL to skip that part. */
+int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1, float beta2,
+                   float* eps_out, int64_t n_eps, uint32_t eps_site,
+                   const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se, int32_t add_e,
+                   uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream);
 /* eps ~ N(0,1) (replaces mx.nd.random_normal, model.py:292): Box-Muller over the counter hash;
  * effective seed = seed ^ (seed_ptr ? *seed_ptr : 0) */
 int mst_randn(int64_t n, float* out, uint64_t seed, const uint64_t* seed_ptr, uint32_t site, mst_stream_t stream);

@@ -104,6 +104,7 @@ SIGNATURES = {
     "mst_zero": (C.c_int, [vp, c_i64, vp]),
     "mst_rng_advance": (C.c_int, [vp, vp]),
     "mst_randn": (C.c_int, [c_i64, vp, c_u64, vp, c_u32, vp]),
+    "mst_step_begin": (C.c_int, [vp, vp, c_f32, c_f32, c_f32, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32, vp]),
 }
 
 

@@ -36,9 +36,69 @@ __global__ __launch_bounds__(256) void randn_kernel(int64_t n, float* __restrict
   }
 }
 
+// One launch at the top of every step (each kernel in the captured graph costs ~4.7 us however small):
+// advances the RNG state, advances Adam's step counter and bias-corrected learning rate, draws eps, and writes the
+// two padding masks from the sequence lengths (SequenceMask, model.py:246-247; the encoder's for the piano-roll ends).
+__global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1,
+                                                         float beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
+                                                         const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
+                                                         int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d) {
+  __shared__ uint64_t seed_s;
+  if (threadIdx.x == 0) {
+    uint64_t seed = 0;
+    if (rng_state) {
+      const uint64_t step = rng_state[1] + 1;
+      rng_state[1] = step;
+      uint64_t x = rng_state[2] ^ (step * 0x9E3779B97F4A7C15ull);
+      x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+      x ^= x >> 27; x *= 0x94D049BB133111EBull;
+      x ^= x >> 31;
+      rng_state[0] = x;
+      seed = x;
+    }
+    seed_s = seed;
+    if (adam_state) {
+      const int t = adam_state[0] + 1;
+      adam_state[0] = t;
+      const float c1 = 1.f - powf(beta1, (float)t), c2 = 1.f - powf(beta2, (float)t);
+      reinterpret_cast<float*>(adam_state)[1] = lr * sqrtf(c2) / c1;
+    }
+  }
+  __syncthreads();
+  const uint64_t s = seed_s;
+  if (eps_out) {
+    for (int64_t i = threadIdx.x; i < (n_eps + 1) / 2; i += 256) {
+      const uint32_t a = dropout_hash(s, eps_site, (uint64_t)(2 * i));
+      const uint32_t b = dropout_hash(s, eps_site, (uint64_t)(2 * i + 1));
+      const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+      const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+      const float r = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      eps_out[2 * i] = r * cs;
+      if (2 * i + 1 < n_eps) eps_out[2 * i + 1] = r * sn;
+    }
+  }
+  if (mask_e)
+    for (int64_t i = threadIdx.x; i < B * Se; i += 256) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
+  if (mask_d)
+    for (int64_t i = threadIdx.x; i < B * Sd; i += 256) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
+}
+
 }  // namespace mst
 
 using namespace mst;
+
+extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1, float beta2, float* eps_out,
+                              int64_t n_eps, uint32_t eps_site, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
+                              int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream) {
+  MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
+  MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
+                     eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d);
+  MST_CHECK_LAUNCH("step_begin_kernel");
+  return MST_OK;
+}
 
 extern "C" int mst_zero(void* ptr, int64_t bytes, mst_stream_t stream) {
   MST_CHECK_ARG(ptr != nullptr && bytes > 0, "mst_zero: bad argument");

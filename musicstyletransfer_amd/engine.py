@@ -258,15 +258,31 @@ class StepPlan:
         def act(rows, width):
             return torch.zeros(rows, roundup(width, 8), dtype=adt, device=dev)
 
-        # ---- inputs (static device buffers; the batcher copies into them)
+        # ---- inputs: ONE static device blob (so a batch arrives with a single copy) viewed as typed tensors
+        asz = torch.tensor([], dtype=adt).element_size()
         if cfg.kind == "token":
-            self.tokens = torch.zeros(B, T, dtype=torch.int32, device=dev)
-            self.labels = torch.zeros(B, T, dtype=torch.int32, device=dev)
+            seg = [("tokens", B * T * 4), ("labels", B * T * 4)]
         else:
-            self.roll = act(B * T, cfg.in_dim)
-            self.labels = torch.zeros(B * T, cfg.out_dim, dtype=torch.uint8, device=dev)
-        self.seq_lens = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.classes = torch.zeros(B, dtype=torch.int32, device=dev)
+            seg = [("roll", B * T * roundup(cfg.in_dim, 8) * asz), ("labels", B * T * cfg.out_dim)]
+        seg += [("seq_lens", B * 4), ("classes", B * 4)]
+        self.in_layout, off = {}, 0
+        for name, nbytes in seg:
+            self.in_layout[name] = (off, nbytes)
+            off = roundup(off + nbytes, 16)
+        self.inbuf = torch.zeros(off, dtype=torch.uint8, device=dev)
+
+        def inview(name, dtype, *shape):
+            a, n = self.in_layout[name]
+            return self.inbuf[a: a + n].view(dtype).view(*shape)
+
+        if cfg.kind == "token":
+            self.tokens = inview("tokens", torch.int32, B, T)
+            self.labels = inview("labels", torch.int32, B, T)
+        else:
+            self.roll = inview("roll", adt, B * T, roundup(cfg.in_dim, 8))
+            self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
+        self.seq_lens = inview("seq_lens", torch.int32, B)
+        self.classes = inview("classes", torch.int32, B)
         self.eps = torch.zeros(B, Z, **f32)
         self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D], dtype=torch.int64, device=dev)
 
@@ -340,6 +356,7 @@ class StepPlan:
         self.sp_datt = act(self.Me, De)
         self.graph = None
         self.graph_opt = None
+        self._tick_adam = False
 
     # ------------------------------------------------------------------------------ inputs
     def load_batch(self, x, seq_lens, classes, labels, eps=None):
@@ -359,6 +376,35 @@ class StepPlan:
         self.classes.copy_(dev(classes, torch.int32))
         if eps is not None:
             self.eps.copy_(dev(eps, torch.float32))
+
+    def pack_batch(self, x, seq_lens, classes, labels, pin=False):
+        """host-side blob with the layout of `inbuf` (what PinnedBatchPipeline stages and bench.py keeps resident)"""
+        cfg, B, T = self.cfg, self.B, self.T
+        blob = torch.zeros(self.inbuf.numel(), dtype=torch.uint8)
+
+        def put(name, t):
+            a, n = self.in_layout[name]
+            blob[a: a + n] = t.contiguous().view(-1).view(torch.uint8)
+
+        def as_t(a, dtype):
+            return (torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a.cpu()).to(dtype)
+
+        if cfg.kind == "token":
+            put("tokens", as_t(x, torch.int32).view(B, T))
+            put("labels", as_t(labels, torch.int32).view(B, T))
+        else:
+            ldp = roundup(cfg.in_dim, 8)
+            roll = torch.zeros(B * T, ldp, dtype=self.adt)
+            roll[:, : cfg.in_dim] = as_t(x, self.adt).view(B * T, cfg.in_dim)
+            put("roll", roll)
+            put("labels", as_t(labels, torch.uint8).view(B * T, cfg.out_dim))
+        put("seq_lens", as_t(seq_lens, torch.int32))
+        put("classes", as_t(classes, torch.int32))
+        return blob.pin_memory() if pin else blob
+
+    def load_packed(self, blob):
+        """one copy (host->device or device->device) of a pack_batch() blob into the step's input buffers"""
+        self.inbuf.copy_(blob, non_blocking=True)
 
     # ------------------------------------------------------------------------------ forward
     def _drop(self, p, site):
@@ -420,10 +466,12 @@ class StepPlan:
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
-        if cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps:
-            o.rng_advance(self.rng_state)
-        if self.internal_eps:
-            o.randn(self.eps, seed_ptr=self.rng_state, site=0x7FFF0000)
+        # one bookkeeping launch: RNG seed of this step, Adam's step count / lr_t, eps, both padding masks
+        need_rng = cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps
+        o.step_begin(rng_state=self.rng_state if need_rng else None,
+                     adam_state=st.step_state if self._tick_adam else None, lr=self.lr, beta1=self.opt["beta1"],
+                     beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None, lens=self.seq_lens,
+                     mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1)
         # ---- encoder input (model.py:81-91, transformer.py:270)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("encoder.embedding.weight"), self.pos_e, self.x0_e.view(B, Se, -1), 0, sq_e,
@@ -431,7 +479,6 @@ class StepPlan:
         else:
             o.gemm_nt(self.roll, st.t("encoder.embedding.weight"), self.x0_e, N=De, alpha=sq_e,
                       grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T)
-            o.mask_from_lengths(self.seq_lens, 0, self.keymask_e)
         x = self.x0_e
         for i, L in enumerate(self.enc):
             x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, 3 * i)
@@ -447,7 +494,6 @@ class StepPlan:
         else:
             o.gemm_nt(self.roll, st.t("decoder.embedding.weight"), self.x0_d, M=B * T, N=Dd, alpha=sq_d,
                       rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1))
-        o.mask_from_lengths(self.seq_lens, 1, self.keymask_d)  # model.py:246-247
         x = self.x0_d
         site_d = 3 * cfg.e_layers
         for i, L in enumerate(self.dec):
@@ -632,12 +678,12 @@ class StepPlan:
         clip = self.clip if self.clip is not None else -1.0
         if self.gscale == self.gscale_enc:
             o.adam_flat(st.w, st.g, st.m, st.v, st.w16, st.step_state, lr=self.lr,
-                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, **self.opt)
+                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, **self.opt)
         else:
             # encoder.* tensors come first in the flat buffers; everything from decoder.latent2hid on is decoder-side.
             # NOTE the latent_proj gradients are produced by latent_bwd at the encoder-side scale.
             cut = st.offsets["decoder.latent2hid.weight"]
-            rng = [(0, cut, self.gscale_enc, True), (cut, st.n, self.gscale, False)]
+            rng = [(0, cut, self.gscale_enc, False), (cut, st.n, self.gscale, False)]
             for a, b, gs, adv in rng:
                 o.adam_flat(st.w[a:b], st.g[a:b], st.m[a:b], st.v[a:b], st.w16[a:b], st.step_state, lr=self.lr,
                             rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv, **self.opt)
@@ -645,6 +691,7 @@ class StepPlan:
 
     # ------------------------------------------------------------------------------ step
     def fwd_bwd_kernels(self, is_train=True):
+        self._tick_adam = is_train  # the step counter / lr_t are advanced by forward()'s step_begin launch
         self.forward()
         self.losses(with_grad=is_train)
         if is_train:

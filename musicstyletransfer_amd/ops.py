@@ -238,6 +238,15 @@ def randn(out, seed=0, seed_ptr=None, site=0):
     call("mst_randn", out.numel(), ptr(out), seed, ptr(seed_ptr), site, stream())
 
 
+def step_begin(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, lens=None,
+               mask_e=None, add_e=0, mask_d=None, add_d=1):
+    B = lens.shape[0] if lens is not None else 0
+    call("mst_step_begin", ptr(rng_state), ptr(adam_state), lr, beta1, beta2, ptr(eps_out),
+         (eps_out.numel() if eps_out is not None else 0), eps_site, ptr(lens), B, ptr(mask_e),
+         (mask_e.shape[1] if mask_e is not None else 0), add_e, ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d,
+         stream())
+
+
 def selftest():
     flags = torch.zeros(4, dtype=torch.int32, device="cuda")
     call("mst_selftest", ptr(flags), stream())

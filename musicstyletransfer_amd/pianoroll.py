@@ -119,19 +119,16 @@ class SyntheticPianoRollDataset(_ArrayDataset):
 
 
 class PinnedBatchPipeline:
-    """Iterate a Dataset one batch ahead: batch i+1 is copied pinned-host -> device on a side stream while
-    step i runs; `next_into(plan)` makes the compute stream wait for that copy and hands the staged device
-    tensors to StepPlan.load_batch (a device-to-device copy into the graph's static inputs)."""
+    """Iterate a Dataset one batch ahead: batch i+1 is packed into ONE page-locked blob (engine.StepPlan.pack_batch) and
+    copied host -> device on a side stream while step i runs; `next_into` makes the compute stream wait for that copy and
+    moves the blob into the plan's static input buffer with a single device-to-device copy."""
 
-    def __init__(self, dataset, device, act_dtype, kind):
-        self.it, self.device, self.adt, self.kind = iter(dataset), device, act_dtype, kind
+    def __init__(self, dataset, device, plan_for):
+        """plan_for(B, T) -> StepPlan (shapes may change from batch to batch on the token path)"""
+        self.it, self.device, self.plan_for = iter(dataset), device, plan_for
         self.stream = torch.cuda.Stream(device=device)
         self.staged = None
         self._stage()
-
-    def _pin(self, a, dtype):
-        t = torch.as_tensor(np.ascontiguousarray(a)).to(dtype)
-        return t.pin_memory()
 
     def _stage(self):
         try:
@@ -139,23 +136,21 @@ class PinnedBatchPipeline:
         except StopIteration:
             self.staged = None
             return
-        x_dtype = torch.int32 if self.kind == "token" else self.adt
-        l_dtype = torch.int32 if self.kind == "token" else torch.uint8
-        host = (self._pin(b.data[0], x_dtype), self._pin(b.data[1], torch.int32), self._pin(b.data[2], torch.int32),
-                self._pin(b.label[0], l_dtype))
+        x = np.asarray(b.data[0])
+        plan = self.plan_for(x.shape[0], x.shape[1])
+        host = plan.pack_batch(x, b.data[1], b.data[2], b.label[0], pin=True)
         with torch.cuda.stream(self.stream):
-            dev = tuple(h.to(self.device, non_blocking=True) for h in host)
+            dev = host.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self.staged = (dev, ev, host, b)
+        self.staged = (plan, dev, ev, host, b)
 
-    def next_into(self, plan_for):
-        """plan_for(B, T) -> StepPlan; returns (plan, batch) or None at the end of the epoch"""
+    def next_into(self):
+        """returns (plan, batch) with the batch loaded into plan's inputs, or None at the end of the epoch"""
         if self.staged is None:
             return None
-        (x, lens, classes, labels), ev, _host, b = self.staged
+        plan, dev, ev, _host, b = self.staged
         torch.cuda.current_stream().wait_event(ev)
-        plan = plan_for(x.shape[0], x.shape[1])
-        plan.load_batch(x, lens, classes, labels)
+        plan.load_packed(dev)
         self._stage()
         return plan, b
