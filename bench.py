@@ -149,6 +149,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (launch with torch.distributed.run); WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the training step has no CPU fallback")
+    # MST_FORCE_DEVICE / MST_DIST_BACKEND exist to rehearse the multi-rank path on a one-GPU box (ranks share the
+    # card, gloo carries the all-reduce); the driver's multi-GPU runs leave them unset: one rank per GPU over RCCL
+    local_rank = int(os.environ.get("MST_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -156,7 +159,7 @@ def main():
     from musicstyletransfer_amd import ops as o
     from musicstyletransfer_amd import parallel
 
-    dist = parallel.init_process_group(world, rank) if world > 1 else None
+    dist = parallel.init_process_group(world, rank, backend=os.environ.get("MST_DIST_BACKEND")) if world > 1 else None
     adt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfg = E.VAEConfig(e_dropout=args.dropout, d_dropout=args.dropout, **CFG2)
     store = E.ParamStore(cfg, dev, adt, seed=1234)  # identical initial weights on every rank

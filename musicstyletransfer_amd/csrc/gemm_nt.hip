@@ -19,6 +19,144 @@ namespace mst {
 constexpr int BK = 64;           // K depth of one LDS tile (elements)
 constexpr int CHUNKS = BK / 8;   // 16-byte chunks per tile row
 
+// Shared epilogue of the GEMM kernels (called after a workgroup barrier: `smem` is free to reuse).
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
+__device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned char* smem,
+                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int frow = lane & 15, fq = lane >> 4;
+  // ------------------------------------------------------------------ epilogue
+  // The accumulators go to LDS as fp32 (one wave-row group of the tile per pass) and every thread then finishes
+  // 8 consecutive columns of a row at a time: bias / residual / gate / output move as 16-byte, row-contiguous
+  // accesses. The element loop is branch-free (absent features are neutral constants: bias 0, ReLU floor -inf,
+  // residual 0, gate 1); optional features cost one wave-uniform branch per 8-column chunk, and only tiles that
+  // cross the M or N edge take the guarded path. (Finishing elements in accumulator layout with per-element
+  // feature tests made the kernel issue-bound: ~2400 VALU per 128 MFMA.)
+  const int n_store = (int)(((a.N + 3) / 4 * 4) < a.ldc ? ((a.N + 3) / 4 * 4) : a.ldc);
+  const float inv_keep = dropout_inv_keep(a.dropout_p);
+  const uint64_t dseed = a.dropout_seed ^ ((a.dropout_p > 0.f && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
+  constexpr int LDS_F = BN + 4;   // fp32 row stride: rows stay 16-byte aligned, banks are spread
+  constexpr int CPR = BN / 8;     // 8-column chunks per tile row
+  static_assert(NT % CPR == 0, "a thread must keep its column chunk across rows");
+  float* sF = reinterpret_cast<float*>(smem);  // the K-loop's tiles are dead: every wave passed the loop's last barrier
+  const int ch = tid % CPR;
+  const int nc = (int)n0 + ch * 8;             // first column of this thread's chunk (N < 2^31)
+  const int N32 = (int)a.N;
+  const bool edge = (m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
+                    (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
+                    (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
+  const bool has_drop = a.dropout_p > 0.f;
+  const bool has_rowops = a.rowadd || a.grpadd;
+  const float relu_floor = (a.act == MST_ACT_RELU) ? 0.f : -INFINITY;
+  const float alpha = a.alpha;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && nc + e < N32) ? a.bias[nc + e] : 0.f;
+  const T* resid = reinterpret_cast<const T*>(a.resid);
+  const T* gate = reinterpret_cast<const T*>(a.gate);
+
+  for (int pass = 0; pass < WGM; ++pass) {
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          *reinterpret_cast<f32x4*>(sF + (i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+    }
+    __syncthreads();
+    if (nc < n_store) {
+#pragma unroll 2
+      for (int row = tid / CPR; row < WTM; row += NT / CPR) {
+        const int64_t m = m0 + pass * WTM + row;
+        if (m >= a.M) break;
+        const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8 + 4);
+        float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        float res[8], gt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { res[e] = 0.f; gt[e] = 1.f; }
+        if (resid) {
+          const T* rp = resid + m * a.ldr + nc;
+          if (!edge) {
+            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) res[e] = bits_to_f32<T>(p8.h[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (nc + e < a.ldr) res[e] = to_f32(rp[e]);
+          }
+        }
+        if (gate) {
+          const T* gp = gate + m * a.ldg + nc;
+          if (!edge) {
+            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gt[e] = bits_to_f32<T>(p8.h[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (nc + e < a.ldg) gt[e] = to_f32(gp[e]);
+          }
+        }
+        // t = alpha * (acc + bias [+ class row]) -> ReLU
+        if (has_rowops && a.grpadd) {
+          const float* ga_row = a.grpadd + (int64_t)a.grp_index[m / a.rowadd_period] * a.ldga + nc;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ga_row[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = fmaxf((t[e] + bias8[e]) * alpha, relu_floor);
+        if (has_drop || a.self_resid) {
+          uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
+          if (has_drop) {
+            const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
+            keep8 = dropout_keep4(dseed, a.dropout_site, w, a.dropout_p) | (dropout_keep4(dseed, a.dropout_site, w + 1, a.dropout_p) << 4);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
+            t[e] = a.self_resid ? t[e] + u : u;
+          }
+        }
+        if (has_rowops && a.rowadd) {
+          const float* ra_row = a.rowadd + (m % a.rowadd_period) * a.ldra + nc;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ra_row[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (gt[e] > 0.f) ? t[e] + res[e] : 0.f;
+        if (edge) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (nc + e >= N32) t[e] = 0.f;
+        }
+        if (C_F32) {
+          float* cp = reinterpret_cast<float*>(a.C) + pm * a.ldc + nc;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{t[0], t[1], t[2], t[3]};
+          if (nc + 8 <= n_store) *reinterpret_cast<f32x4*>(cp + 4) = f32x4{t[4], t[5], t[6], t[7]};
+        } else {
+          T* cp = reinterpret_cast<T*>(a.C) + pm * a.ldc + nc;
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)f32_to_bits<T>(t[2 * e]) | ((uint32_t)f32_to_bits<T>(t[2 * e + 1]) << 16);
+          if (!edge) {
+            *reinterpret_cast<u32x4*>(cp) = o;
+          } else {
+            *reinterpret_cast<u32x2*>(cp) = u32x2{o[0], o[1]};
+            if (nc + 8 <= n_store) *reinterpret_cast<u32x2*>(cp + 4) = u32x2{o[2], o[3]};
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
   constexpr int NT = WGM * WGN * 64;
@@ -139,132 +277,107 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
     __syncthreads();
   }
 
-  // ------------------------------------------------------------------ epilogue
-  // The accumulators go to LDS as fp32 (one wave-row group of the tile per pass) and every thread then finishes
-  // 8 consecutive columns of a row at a time: bias / residual / gate / output move as 16-byte, row-contiguous
-  // accesses. The element loop is branch-free (absent features are neutral constants: bias 0, ReLU floor -inf,
-  // residual 0, gate 1); optional features cost one wave-uniform branch per 8-column chunk, and only tiles that
-  // cross the M or N edge take the guarded path. (Finishing elements in accumulator layout with per-element
-  // feature tests made the kernel issue-bound: ~2400 VALU per 128 MFMA.)
-  const int n_store = (int)(((a.N + 3) / 4 * 4) < a.ldc ? ((a.N + 3) / 4 * 4) : a.ldc);
-  const float inv_keep = dropout_inv_keep(a.dropout_p);
-  const uint64_t dseed = a.dropout_seed ^ ((a.dropout_p > 0.f && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
-  constexpr int LDS_F = BN + 4;   // fp32 row stride: rows stay 16-byte aligned, banks are spread
-  constexpr int CPR = BN / 8;     // 8-column chunks per tile row
-  static_assert(NT % CPR == 0, "a thread must keep its column chunk across rows");
-  static_assert((size_t)WTM * LDS_F * 4 <= (size_t)2 * (BM + BN) * BK * 2, "epilogue staging must fit the K-loop's LDS");
-  float* sF = reinterpret_cast<float*>(smem);  // the K-loop's tiles are dead: every wave passed the loop's last barrier
-  const int ch = tid % CPR;
-  const int nc = (int)n0 + ch * 8;             // first column of this thread's chunk (N < 2^31)
-  const int N32 = (int)a.N;
-  const bool edge = (m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
-                    (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
-                    (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
-  const bool has_drop = a.dropout_p > 0.f;
-  const bool has_rowops = a.rowadd || a.grpadd;
-  const float relu_floor = (a.act == MST_ACT_RELU) ? 0.f : -INFINITY;
-  const float alpha = a.alpha;
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && nc + e < N32) ? a.bias[nc + e] : 0.f;
-  const T* resid = reinterpret_cast<const T*>(a.resid);
-  const T* gate = reinterpret_cast<const T*>(a.gate);
+  static_assert((size_t)(BM / WGM) * (BN + 4) * 4 <= (size_t)2 * (BM + BN) * BK * 2, "epilogue staging must fit the K-loop's LDS");
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
+}
 
-  for (int pass = 0; pass < WGM; ++pass) {
-    if (wm == pass) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4*>(sF + (i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
-    }
-    __syncthreads();
-    if (nc < n_store) {
-#pragma unroll 2
-      for (int row = tid / CPR; row < WTM; row += NT / CPR) {
-        const int64_t m = m0 + pass * WTM + row;
-        if (m >= a.M) break;
-        const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8 + 4);
-        float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        float res[8], gt[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { res[e] = 0.f; gt[e] = 1.f; }
-        if (resid) {
-          const T* rp = resid + m * a.ldr + nc;
-          if (!edge) {
-            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) res[e] = bits_to_f32<T>(p8.h[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (nc + e < a.ldr) res[e] = to_f32(rp[e]);
-          }
-        }
-        if (gate) {
-          const T* gp = gate + m * a.ldg + nc;
-          if (!edge) {
-            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gt[e] = bits_to_f32<T>(p8.h[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (nc + e < a.ldg) gt[e] = to_f32(gp[e]);
-          }
-        }
-        // t = alpha * (acc + bias [+ class row]) -> ReLU
-        if (has_rowops && a.grpadd) {
-          const float* ga_row = a.grpadd + (int64_t)a.grp_index[m / a.rowadd_period] * a.ldga + nc;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ga_row[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = fmaxf((t[e] + bias8[e]) * alpha, relu_floor);
-        if (has_drop || a.self_resid) {
-          uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
-          if (has_drop) {
-            const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
-            keep8 = dropout_keep4(dseed, a.dropout_site, w, a.dropout_p) | (dropout_keep4(dseed, a.dropout_site, w + 1, a.dropout_p) << 4);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
-            t[e] = a.self_resid ? t[e] + u : u;
-          }
-        }
-        if (has_rowops && a.rowadd) {
-          const float* ra_row = a.rowadd + (m % a.rowadd_period) * a.ldra + nc;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ra_row[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = (gt[e] > 0.f) ? t[e] + res[e] : 0.f;
-        if (edge) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (nc + e >= N32) t[e] = 0.f;
-        }
-        if (C_F32) {
-          float* cp = reinterpret_cast<float*>(a.C) + pm * a.ldc + nc;
-          *reinterpret_cast<f32x4*>(cp) = f32x4{t[0], t[1], t[2], t[3]};
-          if (nc + 8 <= n_store) *reinterpret_cast<f32x4*>(cp + 4) = f32x4{t[4], t[5], t[6], t[7]};
-        } else {
-          T* cp = reinterpret_cast<T*>(a.C) + pm * a.ldc + nc;
-          u32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[e] = (uint32_t)f32_to_bits<T>(t[2 * e]) | ((uint32_t)f32_to_bits<T>(t[2 * e + 1]) << 16);
-          if (!edge) {
-            *reinterpret_cast<u32x4*>(cp) = o;
-          } else {
-            *reinterpret_cast<u32x2*>(cp) = u32x2{o[0], o[1]};
-            if (nc + 8 <= n_store) *reinterpret_cast<u32x2*>(cp + 4) = u32x2{o[2], o[3]};
-          }
-        }
-      }
-    }
-    __syncthreads();
+// ---------------------------------------------------------------------------------------------------------------
+// Activation-streaming variant for short contractions (K == KC in {128, 256}: every Dense whose in_units is the model
+// width). The weight panel [BN, K] of the workgroup's column tile is loaded into LDS ONCE; each wave streams its own
+// 32 rows of A straight from global memory into registers as ready-made MFMA fragments (K is contiguous, so a fragment
+// is one 16-byte load) — all K/32 * 2 of them are issued before the first is used. There is no K loop over LDS tiles
+// and no barrier between the loads and the MFMAs: the register file (512 KiB per CU against 160 KiB of LDS) is the
+// in-flight buffer, which is what the tiled kernel lacked (its time was ~4.2 us per 2.1 GFLOP of main loop, i.e. one
+// exposed L2 latency per 64-deep tile at two workgroups per CU, whatever the tile shape).
+template <typename T, int BN, int KC, bool C_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(mst_gemm_args a) {
+  constexpr int BM = 128, WGM = 4, WGN = 1;
+  constexpr int TM = 2, TN = BN / 16, KS = KC / 32, CPRW = KC / 8;  // CPRW: 16-byte chunks per weight row
+  constexpr int SWZ = CPRW >= 16 ? 15 : 7;
+  typedef typename Act<T>::vec8 vec8;
+  static_assert((size_t)(BM / WGM) * (BN + 4) * 4 <= (size_t)BN * KC * 2, "epilogue staging must fit the weight panel's LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* sW = reinterpret_cast<u32x4*>(smem);  // [BN][CPRW], chunk index XOR (row & SWZ)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int64_t tiles_n = (a.N + BN - 1) / BN;
+  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  const int64_t nwg = tiles_m * tiles_n;
+  int64_t bid = blockIdx.x;
+  {  // same XCD-aware order as the tiled kernel: an XCD walks the N tiles of neighbouring M tiles
+    const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
   }
+  const int64_t m0 = (bid / tiles_n) * BM;
+  const int64_t n0 = (bid % tiles_n) * BN;
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // ---- this wave's A rows: every fragment of the whole contraction, issued up front
+  vec8 xf[TM][KS];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = m0 + wave * 32 + i * 16 + frow;
+    const bool ok = m < a.M;
+    const int64_t pm = remap_row(ok ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
+    const T* rp = A + pm * a.lda + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(rp + ks * 32) : zero4;
+      xf[i][ks] = __builtin_bit_cast(vec8, v);
+    }
+  }
+  // ---- weight panel -> LDS (through registers, in batches of 8 chunks per thread)
+  constexpr int W_CH = BN * CPRW / 256;
+#pragma unroll
+  for (int c0 = 0; c0 < W_CH; c0 += 8) {
+    u32x4 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + (c0 + u) * 256, row = c / CPRW, chn = c % CPRW;
+      const int64_t n = n0 + row;
+      w[u] = (n < a.N) ? *reinterpret_cast<const u32x4*>(B + n * a.ldb + chn * 8) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + (c0 + u) * 256, row = c / CPRW, chn = c % CPRW;
+      sW[row * CPRW + (chn ^ (row & SWZ))] = w[u];
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int kc = ks * 4 + fq;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 16 + frow;
+      const vec8 wf = __builtin_bit_cast(vec8, sW[row * CPRW + (kc ^ (row & SWZ))]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf, xf[i][ks], acc[j][i]);
+    }
+  }
+  __syncthreads();  // every wave is done with the weight panel: its LDS becomes the epilogue's staging area
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
+}
+
+template <typename T, int BN, int KC>
+static int launch_stream(const mst_gemm_args& a, hipStream_t s) {
+  const int64_t tiles = cdiv(a.M, 128) * cdiv(a.N, BN);
+  const size_t lds = (size_t)BN * KC * 2;
+  if (a.c_f32)
+    hipLaunchKernelGGL((gemm_nt_stream_kernel<T, BN, KC, true>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((gemm_nt_stream_kernel<T, BN, KC, false>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  MST_CHECK_LAUNCH("gemm_nt_stream_kernel");
+  return MST_OK;
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
@@ -306,6 +419,11 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     const int64_t big_tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
+    // short contraction + enough rows to fill the chip: stream A through registers against a resident weight panel
+    if (a.M >= 2048 && a.N >= 64) {
+      if (a.K == 256) return launch_stream<T, 128, 256>(a, s);
+      if (a.K == 128) return launch_stream<T, 128, 128>(a, s);
+    }
     if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });

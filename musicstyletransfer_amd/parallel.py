@@ -31,7 +31,7 @@ def init_process_group(world, rank, backend=None):
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
     return dist
 
