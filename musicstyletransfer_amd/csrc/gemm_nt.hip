@@ -281,105 +281,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Activation-streaming variant for short contractions (K == KC in {128, 256}: every Dense whose in_units is the model
-// width). The weight panel [BN, K] of the workgroup's column tile is loaded into LDS ONCE; each wave streams its own
-// 32 rows of A straight from global memory into registers as ready-made MFMA fragments (K is contiguous, so a fragment
-// is one 16-byte load) — all K/32 * 2 of them are issued before the first is used. There is no K loop over LDS tiles
-// and no barrier between the loads and the MFMAs: the register file (512 KiB per CU against 160 KiB of LDS) is the
-// in-flight buffer, which is what the tiled kernel lacked (its time was ~4.2 us per 2.1 GFLOP of main loop, i.e. one
-// exposed L2 latency per 64-deep tile at two workgroups per CU, whatever the tile shape).
-template <typename T, int BN, int KC, bool C_F32>
-__global__ __launch_bounds__(256, 2) void gemm_nt_stream_kernel(mst_gemm_args a) {
-  constexpr int BM = 128, WGM = 4, WGN = 1;
-  constexpr int TM = 2, TN = BN / 16, KS = KC / 32, CPRW = KC / 8;  // CPRW: 16-byte chunks per weight row
-  constexpr int SWZ = CPRW >= 16 ? 15 : 7;
-  typedef typename Act<T>::vec8 vec8;
-  static_assert((size_t)(BM / WGM) * (BN + 4) * 4 <= (size_t)BN * KC * 2, "epilogue staging must fit the weight panel's LDS");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* sW = reinterpret_cast<u32x4*>(smem);  // [BN][CPRW], chunk index XOR (row & SWZ)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int frow = lane & 15, fq = lane >> 4;
-  const int64_t tiles_n = (a.N + BN - 1) / BN;
-  const int64_t tiles_m = (a.M + BM - 1) / BM;
-  const int64_t nwg = tiles_m * tiles_n;
-  int64_t bid = blockIdx.x;
-  {  // same XCD-aware order as the tiled kernel: an XCD walks the N tiles of neighbouring M tiles
-    const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-  }
-  const int64_t m0 = (bid / tiles_n) * BM;
-  const int64_t n0 = (bid % tiles_n) * BN;
-  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
-  const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  // ---- this wave's A rows: every fragment of the whole contraction, issued up front
-  vec8 xf[TM][KS];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int64_t m = m0 + wave * 32 + i * 16 + frow;
-    const bool ok = m < a.M;
-    const int64_t pm = remap_row(ok ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
-    const T* rp = A + pm * a.lda + fq * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(rp + ks * 32) : zero4;
-      xf[i][ks] = __builtin_bit_cast(vec8, v);
-    }
-  }
-  // ---- weight panel -> LDS (through registers, in batches of 8 chunks per thread)
-  constexpr int W_CH = BN * CPRW / 256;
-#pragma unroll
-  for (int c0 = 0; c0 < W_CH; c0 += 8) {
-    u32x4 w[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + (c0 + u) * 256, row = c / CPRW, chn = c % CPRW;
-      const int64_t n = n0 + row;
-      w[u] = (n < a.N) ? *reinterpret_cast<const u32x4*>(B + n * a.ldb + chn * 8) : zero4;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + (c0 + u) * 256, row = c / CPRW, chn = c % CPRW;
-      sW[row * CPRW + (chn ^ (row & SWZ))] = w[u];
-    }
-  }
-  __syncthreads();
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int kc = ks * 4 + fq;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = j * 16 + frow;
-      const vec8 wf = __builtin_bit_cast(vec8, sW[row * CPRW + (kc ^ (row & SWZ))]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf, xf[i][ks], acc[j][i]);
-    }
-  }
-  __syncthreads();  // every wave is done with the weight panel: its LDS becomes the epilogue's staging area
-  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
-}
-
-template <typename T, int BN, int KC>
-static int launch_stream(const mst_gemm_args& a, hipStream_t s) {
-  const int64_t tiles = cdiv(a.M, 128) * cdiv(a.N, BN);
-  const size_t lds = (size_t)BN * KC * 2;
-  if (a.c_f32)
-    hipLaunchKernelGGL((gemm_nt_stream_kernel<T, BN, KC, true>), dim3((unsigned)tiles), dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL((gemm_nt_stream_kernel<T, BN, KC, false>), dim3((unsigned)tiles), dim3(256), lds, s, a);
-  MST_CHECK_LAUNCH("gemm_nt_stream_kernel");
-  return MST_OK;
-}
-
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -419,11 +320,6 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     const int64_t big_tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
-    // short contraction + enough rows to fill the chip: stream A through registers against a resident weight panel
-    if (a.M >= 2048 && a.N >= 64) {
-      if (a.K == 256) return launch_stream<T, 128, 256>(a, s);
-      if (a.K == 128) return launch_stream<T, 128, 128>(a, s);
-    }
     if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
