@@ -64,17 +64,64 @@ __device__ __forceinline__ i16x4 att_tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
 }
 
-// copy rows [row0, row0+ATT_STAGE) x DH of a [S, ld] matrix into LDS [ATT_STAGE][DH]; zero-fill rows >= S
+// Staging of rows [row0, row0+ATT_STAGE) x DH of a [S, ld] matrix is split in two so that it can be software-pipelined:
+// stage_load issues the global loads into registers (zero for rows >= S), stage_store writes them to the LDS tile
+// [ATT_STAGE][DH+8]. Every kernel below loads stage i+1 right after storing stage i, i.e. BEFORE it computes on
+// stage i, so the L2 / Infinity-Cache latency of the next tile runs under the current tile's MFMA + exp work
+// (measured before: 55-67 % of the wave cycles of these kernels were waits on exactly that latency, five exposed
+// round trips per workgroup).
+template <typename T, int DH> struct StageRegs {
+  static constexpr int CPR = DH / 8;
+  static constexpr int N = (Stage<DH>::ROWS * CPR + 255) / 256;
+  u32x4 v[N];
+};
 template <typename T, int DH>
-__device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, int64_t ld, int64_t row0, int64_t S, int tid) {
+__device__ __forceinline__ void stage_load(StageRegs<T, DH>& r, const T* __restrict__ g, int64_t ld, int64_t row0, int64_t S, int tid) {
   constexpr int CPR = DH / 8;
-  constexpr int ATT_STAGE = Stage<DH>::ROWS;
-#pragma unroll 4
-  for (int c = tid; c < ATT_STAGE * CPR; c += 256) {
-    const int r = c / CPR, ch = c % CPR;
+#pragma unroll
+  for (int i = 0; i < StageRegs<T, DH>::N; ++i) {
+    const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + r < S) v = *reinterpret_cast<const u32x4*>(g + (row0 + r) * ld + ch * 8);
-    *reinterpret_cast<u32x4*>(lds + r * LdsLd<DH>::V + ch * 8) = v;
+    if (c < Stage<DH>::ROWS * CPR && row0 + row < S) v = *reinterpret_cast<const u32x4*>(g + (row0 + row) * ld + ch * 8);
+    r.v[i] = v;
+  }
+}
+template <typename T, int DH>
+__device__ __forceinline__ void stage_store(T* lds, const StageRegs<T, DH>& r, int tid) {
+  constexpr int CPR = DH / 8;
+#pragma unroll
+  for (int i = 0; i < StageRegs<T, DH>::N; ++i) {
+    const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
+    if (c < Stage<DH>::ROWS * CPR) *reinterpret_cast<u32x4*>(lds + row * LdsLd<DH>::V + ch * 8) = r.v[i];
+  }
+}
+
+// per-key scalars of one stage (thread t < ATT_STAGE holds key k0 + t)
+struct KeyRegs { float rmax, logl, delta; bool in, valid; };
+__device__ __forceinline__ void key_load(KeyRegs& kr, const uint8_t* __restrict__ keymask, const float* __restrict__ lse,
+                                         const float* __restrict__ delta, int64_t plane, int64_t b, int64_t bh, int64_t S,
+                                         int64_t k, bool active) {
+  kr.in = active && k < S;
+  kr.valid = kr.in && keymask[b * S + k];
+  kr.rmax = kr.in ? lse[bh * S + k] : 0.f;
+  kr.logl = kr.in ? lse[plane + bh * S + k] : 0.f;
+  kr.delta = (kr.in && delta) ? delta[bh * S + k] : 0.f;
+}
+
+// Workgroup -> (row tile, batch*head). Linear workgroup ids are dealt round-robin to the 8 XCDs; when the batch is a
+// multiple of 8 the ids are remapped so that every tile of every head of one batch element runs on the same XCD:
+// the K / V rows that the tiles of a head share, and the other half of each 128-byte line (the neighbouring head),
+// are then re-read from that XCD's L2 instead of crossing the fabric again.
+__device__ __forceinline__ void attn_wg_coords(int64_t B, int64_t H, int& tile, int64_t& bh) {
+  const int64_t gx = gridDim.x;
+  if (B % 8 == 0) {
+    const int64_t lin = blockIdx.x + gx * blockIdx.y, xcd = lin % 8, j = lin / 8, G = H * gx;
+    const int64_t b = xcd + 8 * (j / G), r = j % G;
+    bh = b * H + r / gx;
+    tile = (int)(r % gx);
+  } else {
+    tile = blockIdx.x;
+    bh = blockIdx.y;
   }
 }
 
@@ -145,12 +192,16 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   constexpr int KS = DH / 16;
   __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * LdsLd<DH>::V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  int tile; int64_t bh;
+  attn_wg_coords(a.B, a.H, tile, bh);
+  const int64_t b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
-  const int64_t k_lane = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32 + (lane & 31);
+  const int64_t k_lane = (int64_t)tile * ATT_WG_ROWS + wave * 32 + (lane & 31);
+  StageRegs<T, DH> rq;
+  stage_load<T, DH>(rq, Qg, a.ld_qkv, 0, S, tid);
 
   typename Act<T>::vec8 kf[KS];
 #pragma unroll
@@ -160,7 +211,8 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   float m = NEG_BIG, l = 0.f;
   for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
     __syncthreads();
-    stage_rows<T, DH>(sQ, Qg, a.ld_qkv, q0, S, tid);
+    stage_store<T, DH>(sQ, rq, tid);
+    if (q0 + ATT_STAGE < S) stage_load<T, DH>(rq, Qg, a.ld_qkv, q0 + ATT_STAGE, S, tid);
     __syncthreads();
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
@@ -204,15 +256,22 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  int tile; int64_t bh;
+  attn_wg_coords(a.B, a.H, tile, bh);
+  const int64_t b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
   const int64_t plane = a.B * a.H * S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
   const T* Vg = base + a.v_off;
-  const int64_t q_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t q_wave0 = (int64_t)tile * ATT_WG_ROWS + wave * 32;
   const int64_t q_lane = q_wave0 + (lane & 31);
+  StageRegs<T, DH> rk, rv;
+  KeyRegs kr;
+  stage_load<T, DH>(rk, Kg, a.ld_qkv, 0, S, tid);
+  stage_load<T, DH>(rv, Vg, a.ld_qkv, 0, S, tid);
+  key_load(kr, a.keymask, a.lse, nullptr, plane, b, bh, S, tid, tid < ATT_STAGE);
 
   typename Act<T>::vec8 qf[KS];
 #pragma unroll
@@ -225,17 +284,18 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 
   for (int64_t k0 = 0; k0 < S; k0 += ATT_STAGE) {
     __syncthreads();
-    stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
-    stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    stage_store<T, DH>(sK, rk, tid);
+    stage_store<T, DH>(sV, rv, tid);
     int padded = 0;
     if (tid < ATT_STAGE) {
-      const int64_t k = k0 + tid;
-      const bool in = k < S;
-      const bool vk = in && a.keymask[b * S + k];
-      const float rm = in ? a.lse[bh * S + k] : 0.f, ll = in ? a.lse[plane + bh * S + k] : 0.f;
-      key_consts(in, vk, rm, ll, a.scale, sSk[tid], sCk[tid]);
-      sMadd[tid] = vk ? 0.f : MASK_VALUE; sMax[tid] = rm; sLogl[tid] = in ? ll : INFINITY;
-      padded = in && !vk;
+      key_consts(kr.in, kr.valid, kr.rmax, kr.logl, a.scale, sSk[tid], sCk[tid]);
+      sMadd[tid] = kr.valid ? 0.f : MASK_VALUE; sMax[tid] = kr.rmax; sLogl[tid] = kr.in ? kr.logl : INFINITY;
+      padded = kr.in && !kr.valid;
+    }
+    if (k0 + ATT_STAGE < S) {
+      stage_load<T, DH>(rk, Kg, a.ld_qkv, k0 + ATT_STAGE, S, tid);
+      stage_load<T, DH>(rv, Vg, a.ld_qkv, k0 + ATT_STAGE, S, tid);
+      key_load(kr, a.keymask, a.lse, nullptr, plane, b, bh, S, k0 + ATT_STAGE + tid, tid < ATT_STAGE);
     }
     const bool exact = __syncthreads_or(padded);  // wave-uniform: does this stage hold a padded key?
     if (!wave_active) continue;
@@ -291,15 +351,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T sQ[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) T sdO[ATT_STAGE * LdsLd<DH>::V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  int tile; int64_t bh;
+  attn_wg_coords(a.B, a.H, tile, bh);
+  const int64_t b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
   const T* Vg = base + a.v_off;
   const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
-  const int64_t k_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t k_wave0 = (int64_t)tile * ATT_WG_ROWS + wave * 32;
   const int64_t k_lane = k_wave0 + (lane & 31);
+  StageRegs<T, DH> rq, rdo;
+  stage_load<T, DH>(rq, Qg, a.ld_qkv, 0, S, tid);
+  stage_load<T, DH>(rdo, dOg, a.ld_dout, 0, S, tid);
 
   typename Act<T>::vec8 kf[KS], vf[KS];
 #pragma unroll
@@ -327,8 +392,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
     for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
       __syncthreads();
-      stage_rows<T, DH>(sQ, Qg, a.ld_qkv, q0, S, tid);
-      stage_rows<T, DH>(sdO, dOg, a.ld_dout, q0, S, tid);
+      stage_store<T, DH>(sQ, rq, tid);
+      stage_store<T, DH>(sdO, rdo, tid);
+      {  // next stage (wrapping to the first one for the second pass)
+        const int64_t qn = (q0 + ATT_STAGE < S) ? q0 + ATT_STAGE : 0;
+        if (qn != 0 || pass == 0) {
+          stage_load<T, DH>(rq, Qg, a.ld_qkv, qn, S, tid);
+          stage_load<T, DH>(rdo, dOg, a.ld_dout, qn, S, tid);
+        }
+      }
       __syncthreads();
 #pragma unroll
       for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
@@ -394,15 +466,23 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sDs[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  int tile; int64_t bh;
+  attn_wg_coords(a.B, a.H, tile, bh);
+  const int64_t b = bh / a.H, hd = bh % a.H;
   const int64_t S = a.S;
+  const int64_t plane = a.B * a.H * S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
   const T* Vg = base + a.v_off;
   const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
-  const int64_t q_wave0 = (int64_t)blockIdx.x * ATT_WG_ROWS + wave * 32;
+  const int64_t q_wave0 = (int64_t)tile * ATT_WG_ROWS + wave * 32;
   const int64_t q_lane = q_wave0 + (lane & 31);
+  StageRegs<T, DH> rk, rv;
+  KeyRegs kr;
+  stage_load<T, DH>(rk, Kg, a.ld_qkv, 0, S, tid);
+  stage_load<T, DH>(rv, Vg, a.ld_qkv, 0, S, tid);
+  key_load(kr, a.keymask, a.lse, a.delta, plane, b, bh, S, tid, tid < ATT_STAGE);
 
   typename Act<T>::vec8 qf[KS], dof[KS];
 #pragma unroll
@@ -416,18 +496,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 
   for (int64_t k0 = 0; k0 < S; k0 += ATT_STAGE) {
     __syncthreads();
-    stage_rows<T, DH>(sK, Kg, a.ld_qkv, k0, S, tid);
-    stage_rows<T, DH>(sV, Vg, a.ld_qkv, k0, S, tid);
+    stage_store<T, DH>(sK, rk, tid);
+    stage_store<T, DH>(sV, rv, tid);
     int padded = 0;
     if (tid < ATT_STAGE) {
-      const int64_t k = k0 + tid;
-      const bool in = k < S;
-      const bool vk = in && a.keymask[b * S + k];
-      const float rm = in ? a.lse[bh * S + k] : 0.f, ll = in ? a.lse[a.B * a.H * S + bh * S + k] : 0.f;
-      key_consts(in, vk, rm, ll, a.scale, sSk[tid], sCk[tid]);
-      sMadd[tid] = vk ? 0.f : MASK_VALUE; sMax[tid] = rm; sLogl[tid] = in ? ll : INFINITY;
-      sDs[tid] = in ? a.delta[bh * S + k] * a.scale : 0.f;
-      padded = in && !vk;
+      key_consts(kr.in, kr.valid, kr.rmax, kr.logl, a.scale, sSk[tid], sCk[tid]);
+      sMadd[tid] = kr.valid ? 0.f : MASK_VALUE; sMax[tid] = kr.rmax; sLogl[tid] = kr.in ? kr.logl : INFINITY;
+      sDs[tid] = kr.delta * a.scale;
+      padded = kr.in && !kr.valid;
+    }
+    if (k0 + ATT_STAGE < S) {
+      stage_load<T, DH>(rk, Kg, a.ld_qkv, k0 + ATT_STAGE, S, tid);
+      stage_load<T, DH>(rv, Vg, a.ld_qkv, k0 + ATT_STAGE, S, tid);
+      key_load(kr, a.keymask, a.lse, a.delta, plane, b, bh, S, k0 + ATT_STAGE + tid, tid < ATT_STAGE);
     }
     const bool exact = __syncthreads_or(padded);
 #pragma unroll

@@ -15,6 +15,13 @@ OBJ_DIR = os.path.join(HERE, "_obj")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# Per-file code generation switches. attention.hip: MFMA results feed VALU work (exp, scaling) at once, so the
+# accumulators should live in VGPRs, not AGPRs: no v_accvgpr_read copies and 150 instead of 184 registers per
+# lane (3 waves/SIMD instead of 2).
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+for _kv in os.environ.get("MST_EXTRA_FLAGS", "").split(";"):  # "file.hip=-flag -flag;..." for experiments
+    if "=" in _kv:
+        FILE_FLAGS.setdefault(_kv.split("=", 1)[0], []).extend(_kv.split("=", 1)[1].split())
 
 
 def hipcc():
@@ -31,6 +38,7 @@ def sources():
 def headers():
     hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")]
     hs.append(os.path.join(HERE, "..", "..", "include", "mst_hip.h"))
+    hs.append(os.path.abspath(__file__))  # flags live here
     return hs
 
 
@@ -43,7 +51,7 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-    cmd = [hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+    cmd = [hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
