@@ -295,13 +295,14 @@ int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_we
  * (gluon.Trainer.step → optimizer.Adam → adam_update; trainer.py:94-101,177):
  *   g = clip(grad * rescale + wd * w, ±clip)  (clip < 0: no clipping)
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g² ; w -= lr_t * m / (sqrt(v) + eps)
- *   lr_t = lr * sqrt(1-b2^t)/(1-b1^t); t lives in step_state[0] on the device and is advanced by a
+ *   lr_t = lr * sqrt(1-b2^t)/(1-b1^t), evaluated in double like the Python reference (lr, b1, b2 are doubles for
+ *   that reason: 1 - 0.999f is already 1.3e-5 off); t lives in step_state[0] on the device and is advanced by a
  *   1-thread kernel issued ahead of the update in the same stream, so a captured graph replays
  *   with the right bias correction.
  * Also refreshes the 16-bit shadow copy w16 (act dtype, same offsets).
  * ------------------------------------------------------------------------ */
 int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
-                  void* w16, float lr, float beta1, float beta2, float eps, float wd,
+                  void* w16, double lr, double beta1, double beta2, float eps, float wd,
                   float rescale, float clip, int32_t* step_state /* device int32[2]: {t, bits(lr_t)} */,
                   int advance_step /* 0: reuse the lr_t of the previous launch (second range of one step) */,
                   mst_stream_t stream);
@@ -321,13 +322,15 @@ int mst_dropout_mask(int64_t n, float p, uint64_t seed, uint32_t site, uint8_t* 
 
 /* stream-ordered memset to zero (gradient bucket, metric sums) */
 int mst_zero(void* ptr, int64_t bytes, mst_stream_t stream);
-/* device-resident per-step RNG seed: state = uint64[3] {seed for this step, step counter, base seed};
- * one launch per step advances it, so dropout masks and eps differ on every replay of a captured graph */
+/* device-resident per-step RNG seed: state = uint64[4] {seed for this step, step counter, base seed, 0};
+ * one launch per step advances it, so dropout masks and eps differ on every replay of a captured graph
+ * (word 3 is the workgroup arrival counter of mst_step_begin and is zero between launches) */
 int mst_rng_advance(uint64_t* state, mst_stream_t stream);
 /* Top-of-step bookkeeping in ONE launch (every kernel in the captured graph costs ~4.7 us): mst_rng_advance, Adam's
  * step counter / bias-corrected lr (then call mst_adam_flat with advance_step = 0), mst_randn into eps_out, and the two
- * mst_mask_from_lengths masks (model.py:246-247). Any pointer may be NULL to skip that part. */
-int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1, float beta2,
+ * mst_mask_from_lengths masks (model.py:246-247). Any pointer may be NULL to skip that part. rng_state is the
+ * uint64[4] state of mst_rng_advance. */
+int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2,
                    float* eps_out, int64_t n_eps, uint32_t eps_site,
                    const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se, int32_t add_e,
                    uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libmst_hip.so")
 MST_BF16, MST_F16, MST_F32 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
 
-c_i32, c_i64, c_f32, c_u64, c_u32 = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32
+c_i32, c_i64, c_f32, c_f64, c_u64, c_u32 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_uint32
 vp = C.c_void_p
 
 
@@ -94,7 +94,7 @@ SIGNATURES = {
     "mst_sigmoid_bce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, c_f32, C.c_int, vp, vp, vp, c_i64,
                                   vp, c_i64, c_f32, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
-    "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32,
+    "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
                                 vp, C.c_int, vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
     "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),
@@ -104,7 +104,7 @@ SIGNATURES = {
     "mst_zero": (C.c_int, [vp, c_i64, vp]),
     "mst_rng_advance": (C.c_int, [vp, vp]),
     "mst_randn": (C.c_int, [c_i64, vp, c_u64, vp, c_u32, vp]),
-    "mst_step_begin": (C.c_int, [vp, vp, c_f32, c_f32, c_f32, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32, vp]),
+    "mst_step_begin": (C.c_int, [vp, vp, c_f64, c_f64, c_f64, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32, vp]),
 }
 
 

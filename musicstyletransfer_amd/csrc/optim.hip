@@ -15,12 +15,12 @@
 namespace mst {
 
 // state[0] = step count t (int32), state[1] = bits of lr_t (float)
-__global__ void adam_tick_kernel(int32_t* state, float lr, float beta1, float beta2) {
+__global__ void adam_tick_kernel(int32_t* state, double lr, double beta1, double beta2) {
   const int t = state[0] + 1;
   state[0] = t;
-  const float c1 = 1.f - powf(beta1, (float)t);
-  const float c2 = 1.f - powf(beta2, (float)t);
-  reinterpret_cast<float*>(state)[1] = lr * sqrtf(c2) / c1;
+  const double c1 = 1.0 - pow(beta1, (double)t);
+  const double c2 = 1.0 - pow(beta2, (double)t);
+  reinterpret_cast<float*>(state)[1] = (float)(lr * sqrt(c2) / c1);
 }
 
 template <typename T>
@@ -123,8 +123,8 @@ static unsigned grid_for(int64_t n, int per_thread) {
   return (unsigned)g;
 }
 
-extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, float lr,
-                             float beta1, float beta2, float eps, float wd, float rescale, float clip,
+extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr,
+                             double beta1, double beta2, float eps, float wd, float rescale, float clip,
                              int32_t* step_state, int advance_step, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
   MST_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
@@ -137,7 +137,7 @@ extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, 
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,
-                       beta1, beta2, eps, wd, rescale, clip);
+                       (float)beta1, (float)beta2, eps, wd, rescale, clip);
     MST_CHECK_LAUNCH("adam_flat_kernel");
     return MST_OK;
   });

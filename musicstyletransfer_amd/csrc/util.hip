@@ -10,6 +10,7 @@
 namespace mst {
 
 // state[0] = seed used by this step's kernels, state[1] = step counter, state[2] = base seed
+// (state[3] = arrival counter of mst_step_begin, zero between launches)
 __global__ void rng_advance_kernel(uint64_t* state) {
   const uint64_t step = state[1] + 1;
   state[1] = step;
@@ -39,35 +40,35 @@ __global__ __launch_bounds__(256) void randn_kernel(int64_t n, float* __restrict
 // One launch at the top of every step (each kernel in the captured graph costs ~4.7 us however small):
 // advances the RNG state, advances Adam's step counter and bias-corrected learning rate, draws eps, and writes the
 // two padding masks from the sequence lengths (SequenceMask, model.py:246-247; the encoder's for the piano-roll ends).
-__global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1,
-                                                         float beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
+__device__ __forceinline__ uint64_t step_seed(uint64_t base, uint64_t step) {
+  uint64_t x = base ^ (step * 0x9E3779B97F4A7C15ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// Grid of several workgroups (the single-workgroup form took 29 us of the step). Every workgroup derives the new
+// seed itself from (base seed, step counter + 1); the state is written back by the workgroup that ARRIVES LAST at
+// rng_state[3], i.e. after every other workgroup has read the old counter.
+__global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1,
+                                                         double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
                                                          const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                                                          int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d) {
-  __shared__ uint64_t seed_s;
-  if (threadIdx.x == 0) {
-    uint64_t seed = 0;
-    if (rng_state) {
-      const uint64_t step = rng_state[1] + 1;
-      rng_state[1] = step;
-      uint64_t x = rng_state[2] ^ (step * 0x9E3779B97F4A7C15ull);
-      x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-      x ^= x >> 27; x *= 0x94D049BB133111EBull;
-      x ^= x >> 31;
-      rng_state[0] = x;
-      seed = x;
-    }
-    seed_s = seed;
-    if (adam_state) {
-      const int t = adam_state[0] + 1;
-      adam_state[0] = t;
-      const float c1 = 1.f - powf(beta1, (float)t), c2 = 1.f - powf(beta2, (float)t);
-      reinterpret_cast<float*>(adam_state)[1] = lr * sqrtf(c2) / c1;
-    }
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+  uint64_t step = 0, s = 0;
+  if (rng_state) {
+    step = rng_state[1] + 1;
+    s = step_seed(rng_state[2], step);
   }
-  __syncthreads();
-  const uint64_t s = seed_s;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && adam_state) {  // nobody else in this launch touches the Adam state
+    const int t = adam_state[0] + 1;
+    adam_state[0] = t;
+    const double c1 = 1.0 - pow(beta1, (double)t), c2 = 1.0 - pow(beta2, (double)t);  // double, like the reference
+    reinterpret_cast<float*>(adam_state)[1] = (float)(lr * sqrt(c2) / c1);
+  }
   if (eps_out) {
-    for (int64_t i = threadIdx.x; i < (n_eps + 1) / 2; i += 256) {
+    for (int64_t i = gid; i < (n_eps + 1) / 2; i += gsz) {
       const uint32_t a = dropout_hash(s, eps_site, (uint64_t)(2 * i));
       const uint32_t b = dropout_hash(s, eps_site, (uint64_t)(2 * i + 1));
       const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
@@ -80,21 +81,38 @@ __global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, in
     }
   }
   if (mask_e)
-    for (int64_t i = threadIdx.x; i < B * Se; i += 256) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
+    for (int64_t i = gid; i < B * Se; i += gsz) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
   if (mask_d)
-    for (int64_t i = threadIdx.x; i < B * Sd; i += 256) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
+    for (int64_t i = gid; i < B * Sd; i += gsz) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
+  if (rng_state) {
+    __syncthreads();  // every thread of this workgroup has read the old counter
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(rng_state + 3), 1ull);
+      if (arrived == (unsigned long long)gridDim.x - 1) {
+        rng_state[3] = 0;
+        rng_state[1] = step;
+        rng_state[0] = s;
+      }
+    }
+  }
 }
 
 }  // namespace mst
 
 using namespace mst;
 
-extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, float lr, float beta1, float beta2, float* eps_out,
+extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2, float* eps_out,
                               int64_t n_eps, uint32_t eps_site, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                               int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream) {
   MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
   MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
-  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
+  int64_t work = n_eps / 2;
+  if (mask_e && B * Se > work) work = B * Se;
+  if (mask_d && B * Sd > work) work = B * Sd;
+  int64_t grid = cdiv(work > 0 ? work : 1, 256 * 4);
+  if (grid > 128) grid = 128;
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
                      eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d);
   MST_CHECK_LAUNCH("step_begin_kernel");
   return MST_OK;

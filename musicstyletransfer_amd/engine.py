@@ -284,7 +284,7 @@ class StepPlan:
         self.seq_lens = inview("seq_lens", torch.int32, B)
         self.classes = inview("classes", torch.int32, B)
         self.eps = torch.zeros(B, Z, **f32)
-        self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D], dtype=torch.int64, device=dev)
+        self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D, 0], dtype=torch.int64, device=dev)
 
         self.pos_e = torch.from_numpy(positional_table(De, Se)).to(dev)
         self.pos_d = torch.from_numpy(positional_table(Dd, Sd)).to(dev)

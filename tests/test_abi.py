@@ -64,4 +64,4 @@ def test_invalid_arguments_fail_loudly(lib):
     assert rc == -1
     assert b"multiples of 8" in lib.mst_last_error()
     with pytest.raises(_lib.MstError):
-        _lib.call("mst_layernorm_fwd", 0, 4, 6, None, 8, None, None, 1e-5, None, 8, None, None, None)
+        _lib.call("mst_layernorm_fwd", 0, 4, 6, None, 8, None, None, 1e-5, None, 8, None, None, 1, None)

@@ -624,3 +624,32 @@ def test_graph_capture_and_events(gpu):
     torch.cuda.synchronize()
     want = ((a.float() + b.float()).to(BF).float() + b.float()).to(BF)
     assert torch.equal(y, want)
+
+
+def test_step_begin_matches_the_separate_kernels(gpu):
+    """mst_step_begin (many workgroups, last-arriver write-back) == rng_advance + randn + mask_from_lengths + Adam tick"""
+    o = ops()
+    B, Z, Se, Sd = 64, 64, 256, 257
+    lens = torch.tensor([(i * 37) % Se + 1 for i in range(B)], dtype=torch.int32, device=gpu)
+    st_a = torch.tensor([0, 0, 1234567, 0], dtype=torch.int64, device=gpu)
+    st_b = st_a.clone()
+    adam = torch.zeros(2, dtype=torch.int32, device=gpu)
+    for step in range(1, 4):
+        eps = torch.zeros(B, Z, device=gpu)
+        me = torch.full((B, Se), 7, dtype=torch.uint8, device=gpu)
+        md = torch.full((B, Sd), 7, dtype=torch.uint8, device=gpu)
+        o.step_begin(rng_state=st_a, adam_state=adam, lr=1e-3, eps_out=eps, eps_site=99, lens=lens, mask_e=me, add_e=0,
+                     mask_d=md, add_d=1)
+        o.rng_advance(st_b)
+        eps_ref = torch.zeros(B, Z, device=gpu)
+        o.randn(eps_ref, seed_ptr=st_b, site=99)
+        me_ref, md_ref = torch.zeros_like(me), torch.zeros_like(md)
+        o.mask_from_lengths(lens, 0, me_ref)
+        o.mask_from_lengths(lens, 1, md_ref)
+        torch.cuda.synchronize()
+        assert st_a.tolist() == st_b.tolist() and st_a[1].item() == step and st_a[3].item() == 0
+        assert torch.equal(eps, eps_ref) and torch.equal(me, me_ref) and torch.equal(md, md_ref)
+        assert adam[0].item() == step
+        want_lr = 1e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        assert abs(adam.view(torch.float32)[1].item() - want_lr) < 1e-6 * want_lr + 1e-12
+    assert abs(float(eps.mean())) < 0.06 and abs(float(eps.std()) - 1) < 0.05
