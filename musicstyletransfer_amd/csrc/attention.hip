@@ -19,6 +19,7 @@
 // Operands that a product needs "transposed" (V, dO, Q, K as the B operand of an X^T·B product) are
 // staged row-major in LDS and read with ds_read_tr16_b64.
 #include <math.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace mst {
@@ -247,6 +248,89 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   }
 }
 
+// One 32-key x 32-query tile of the query-owner kernels. Straight-line on purpose: EXACT is a template parameter (the
+// callers branch once per tile), so the compiler is free to issue the per-key constant reads ahead of the exps.
+template <typename T, int DH, bool EXACT>
+__device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
+                                             const float* sMax, const float* sLogl, int blk, float scale,
+                                             const typename Act<T>::vec8 (&qf)[DH / 16], f32x16 (&o)[(DH + 31) / 32], int lane) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  typename Act<T>::vec8 kfr[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) kfr[s] = lds_row_frag<T, DH>(sK, blk * 32, s, lane);
+  typename Act<T>::vec8 vfr[2][DB];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) vfr[s2][d] = lds_tr_frag<T, DH>(sV, blk * 32, s2, d * 32, lane);
+  f32x16 x = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(kfr[s], qf[s], x);
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {  // accumulator rows 4g..4g+3 are 4 consecutive keys: one 16-byte read per constant
+    const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>((EXACT ? sMadd : sSk) + kr);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>((EXACT ? sMax : sCk) + kr);
+    f32x4 c2 = c1;
+    if (EXACT) c2 = *reinterpret_cast<const f32x4*>(sLogl + kr);  // +inf for keys >= S: p = 0
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      x[4 * g4 + e] = EXACT ? exact_prob(x[4 * g4 + e], scale, c0[e], c1[e], c2[e]) : fast_exp2(fmaf(x[4 * g4 + e], c0[e], c1[e]));
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(pf, vfr[s2][d], o[d]);
+  }
+}
+
+// dQ tile: x = P * (dP*scale - delta*scale), then acc += x^T-product with the staged K rows
+template <typename T, int DH, bool EXACT>
+__device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
+                                           const float* sMax, const float* sLogl, const float* sDs, int blk, float scale,
+                                           const typename Act<T>::vec8 (&qf)[DH / 16], const typename Act<T>::vec8 (&dof)[DH / 16],
+                                           f32x16 (&acc)[(DH + 31) / 32], int lane) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  typename Act<T>::vec8 kfr[KS], vfr[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kfr[s] = lds_row_frag<T, DH>(sK, blk * 32, s, lane);
+    vfr[s] = lds_row_frag<T, DH>(sV, blk * 32, s, lane);
+  }
+  typename Act<T>::vec8 ktr[2][DB];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) ktr[s2][d] = lds_tr_frag<T, DH>(sK, blk * 32, s2, d * 32, lane);
+  f32x16 x = zero16<DH>(), dp = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    x = Act<T>::mfma32(kfr[s], qf[s], x);
+    dp = Act<T>::mfma32(vfr[s], dof[s], dp);
+  }
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
+    const f32x4 ds = *reinterpret_cast<const f32x4*>(sDs + kr);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>((EXACT ? sMadd : sSk) + kr);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>((EXACT ? sMax : sCk) + kr);
+    f32x4 c2 = c1;
+    if (EXACT) c2 = *reinterpret_cast<const f32x4*>(sLogl + kr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pr = EXACT ? exact_prob(x[4 * g4 + e], scale, c0[e], c1[e], c2[e]) : fast_exp2(fmaf(x[4 * g4 + e], c0[e], c1[e]));
+      x[4 * g4 + e] = pr * fmaf(dp[4 * g4 + e], scale, -ds[e]);
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, ktr[s2][d], acc[d]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ fwd_out
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
@@ -302,31 +386,8 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
-      f32x16 x = zero16<DH>();
-#pragma unroll
-      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sK, blk * 32, s, lane), qf[s], x);
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {  // accumulator rows 4g..4g+3 are 4 consecutive keys: one 16-byte read each
-        const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
-        if (!exact) {
-          const f32x4 sk = *reinterpret_cast<const f32x4*>(sSk + kr);
-          const f32x4 ck = *reinterpret_cast<const f32x4*>(sCk + kr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[4 * g4 + e] = fast_exp2(fmaf(x[4 * g4 + e], sk[e], ck[e]));
-        } else {
-          const f32x4 ma = *reinterpret_cast<const f32x4*>(sMadd + kr);
-          const f32x4 mx = *reinterpret_cast<const f32x4*>(sMax + kr);
-          const f32x4 ll = *reinterpret_cast<const f32x4*>(sLogl + kr);  // +inf for keys >= S: p = 0
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[4 * g4 + e] = exact_prob(x[4 * g4 + e], a.scale, ma[e], mx[e], ll[e]);
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
-#pragma unroll
-        for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(sV, blk * 32, s2, d * 32, lane), o[d]);
-      }
+      if (exact) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, blk, a.scale, qf, o, lane);
+      else fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, blk, a.scale, qf, o, lane);
     }
   }
   T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
@@ -514,38 +575,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
-      f32x16 x = zero16<DH>(), dp = zero16<DH>();
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        x = Act<T>::mfma32(lds_row_frag<T, DH>(sK, blk * 32, s, lane), qf[s], x);
-        dp = Act<T>::mfma32(lds_row_frag<T, DH>(sV, blk * 32, s, lane), dof[s], dp);
-      }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
-        const f32x4 ds = *reinterpret_cast<const f32x4*>(sDs + kr);
-        float pr[4];
-        if (!exact) {
-          const f32x4 sk = *reinterpret_cast<const f32x4*>(sSk + kr);
-          const f32x4 ck = *reinterpret_cast<const f32x4*>(sCk + kr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pr[e] = fast_exp2(fmaf(x[4 * g4 + e], sk[e], ck[e]));
-        } else {
-          const f32x4 ma = *reinterpret_cast<const f32x4*>(sMadd + kr);
-          const f32x4 mx = *reinterpret_cast<const f32x4*>(sMax + kr);
-          const f32x4 ll = *reinterpret_cast<const f32x4*>(sLogl + kr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pr[e] = exact_prob(x[4 * g4 + e], a.scale, ma[e], mx[e], ll[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[4 * g4 + e] = pr[e] * fmaf(dp[4 * g4 + e], a.scale, -ds[e]);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
-#pragma unroll
-        for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(sK, blk * 32, s2, d * 32, lane), acc[d]);
-      }
+      if (exact) bwd_q_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sDs, blk, a.scale, qf, dof, acc, lane);
+      else bwd_q_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sDs, blk, a.scale, qf, dof, acc, lane);
     }
   }
   T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + a.q_off;
@@ -562,6 +593,299 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ resident kernels
+// One workgroup per (batch, head) with the whole sequence resident in LDS: the two kernels of each direction become
+// two PHASES of one launch (every launch in the captured step costs ~4.7 us before its first wave does useful work,
+// and the streaming kernels above re-stage the other operand once per 128 owner rows). Rows are owned in blocks of
+// 32 by the waves of the workgroup round-robin (block ob -> wave ob % NW), first as keys (phase A: lane = key, the
+// softmax axis in-lane), then as queries (phase B: lane = query, contraction over keys from the accumulators). The
+// tile arithmetic is the streaming kernels' own (same functions, same operation order), so results are identical.
+// Used when the staged operands fit in LDS (choose_resident below); longer sequences take the streaming kernels.
+template <typename T, int DH>
+__device__ __forceinline__ void stage_all(T* lds, const T* __restrict__ g, int64_t ld, int64_t S, int SP, int tid, int nthr) {
+  constexpr int CPR = DH / 8;
+#pragma unroll 4
+  for (int c = tid; c < SP * CPR; c += nthr) {
+    const int row = c / CPR, ch = c % CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < S) v = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + ch * 8);
+    *reinterpret_cast<u32x4*>(lds + row * LdsLd<DH>::V + ch * 8) = v;
+  }
+}
+
+// (batch*head) of a 1-D grid; batch elements are dealt to the XCDs so that the heads of one element share an L2
+__device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
+  const int64_t lin = blockIdx.x;
+  if (B % 8 != 0) return lin;
+  const int64_t xcd = lin % 8, j = lin / 8;
+  return (xcd + 8 * (j / H)) * H + j % H;
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  const int64_t S = a.S;
+  const int NB = (int)((S + 31) / 32), SP = NB * 32;
+  T* sQ = reinterpret_cast<T*>(att_smem);
+  T* sK = sQ + SP * LD;
+  T* sV = sK + SP * LD;
+  float* sSk = reinterpret_cast<float*>(sV + SP * LD);
+  float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
+  const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
+  const int64_t plane = a.B * a.H * S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  stage_all<T, DH>(sQ, base + a.q_off, a.ld_qkv, S, SP, tid, nthr);
+  stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
+  stage_all<T, DH>(sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
+  __syncthreads();
+
+  // ---- phase A: softmax statistics of every key row (the arithmetic of attn_fwd_stats_kernel)
+  int padded = 0;
+  for (int ob = wave; ob < NB; ob += NW) {
+    const int64_t k_lane = ob * 32 + (lane & 31);
+    typename Act<T>::vec8 kf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf[s] = lds_row_frag<T, DH>(sK, ob * 32, s, lane);
+    const bool in = k_lane < S;
+    const bool vk = in && a.keymask[b * S + k_lane];
+    const float madd = vk ? 0.f : MASK_VALUE;
+    float m = NEG_BIG, l = 0.f;
+    for (int qt = 0; qt < NB; ++qt) {
+      f32x16 x = zero16<DH>();
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, qt * 32, s, lane), kf[s], x);
+      float t[16], tmax = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool valid = qt * 32 + acc_row(r, lane) < S;
+        t[r] = valid ? fmaf(x[r], a.scale, madd) : NEG_BIG;
+        tmax = fmaxf(tmax, t[r]);
+      }
+      const float m_new = fmaxf(m, tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
+      l = l * __expf(m - m_new) + sum;
+      m = m_new;
+    }
+    const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+    const float M = fmaxf(m, m2);
+    const float logl = __logf(l * __expf(m - M) + l2 * __expf(m2 - M));
+    if (lane < 32) {
+      if (in) {
+        a.lse[bh * S + k_lane] = M;
+        a.lse[plane + bh * S + k_lane] = logl;
+      }
+      key_consts(in, vk, in ? M : 0.f, in ? logl : 0.f, a.scale, sSk[k_lane], sCk[k_lane]);
+      sMadd[k_lane] = madd; sMax[k_lane] = in ? M : 0.f; sLogl[k_lane] = in ? logl : INFINITY;
+    }
+    padded |= (in && !vk);
+  }
+  const bool exact = __syncthreads_or(padded);  // does this sequence hold a padded key?
+
+  // ---- phase B: O = P^T V for the owned queries (attn_fwd_out_kernel's tiles)
+  for (int ob = wave; ob < NB; ob += NW) {
+    if ((int64_t)ob * 32 >= a.q_limit) break;
+    typename Act<T>::vec8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = lds_row_frag<T, DH>(sQ, ob * 32, s, lane);
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
+    if (exact) {
+      for (int kt = 0; kt < NB; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+    } else {
+      for (int kt = 0; kt < NB; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+    }
+    T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int col = d * 32 + (lane & 31);
+      if (col < DH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t q = ob * 32 + acc_row(r, lane);
+          if (q < S && q < a.q_limit) og[q * a.ld_out + col] = (T)o[d][r];
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  const int64_t S = a.S;
+  const int NB = (int)((S + 31) / 32), SP = NB * 32;
+  T* bufA = reinterpret_cast<T*>(att_smem);  // phase A: Q   phase B: K
+  T* bufB = bufA + SP * LD;                  // phase A: dO  phase B: V
+  float* sSk = reinterpret_cast<float*>(bufB + SP * LD);
+  float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sDs = sLogl + SP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
+  const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
+  const int64_t plane = a.B * a.H * S;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* Kg = base + a.k_off;
+  const T* Qg = base + a.q_off;
+  const T* Vg = base + a.v_off;
+  const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
+  T* dbase = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH;
+  stage_all<T, DH>(bufA, Qg, a.ld_qkv, S, SP, tid, nthr);
+  stage_all<T, DH>(bufB, dOg, a.ld_dout, S, SP, tid, nthr);
+  __syncthreads();
+
+  // ---- phase A: dV, delta, dK for the owned keys (attn_bwd_kv_kernel's two passes over the query tiles)
+  int padded = 0;
+  for (int ob = wave; ob < NB; ob += NW) {
+    const int64_t k_lane = ob * 32 + (lane & 31);
+    typename Act<T>::vec8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
+      vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
+    }
+    const bool in = k_lane < S;
+    const bool vk = in && a.keymask[b * S + k_lane];
+    const float rmax = in ? a.lse[bh * S + k_lane] : 0.f;
+    const float logl = in ? a.lse[plane + bh * S + k_lane] : INFINITY;
+    const float madd = vk ? 0.f : MASK_VALUE;
+    float sk2, ck2;
+    key_consts(in, vk, rmax, in ? logl : 0.f, a.scale, sk2, ck2);
+    const bool exact_w = __any(in && !vk);  // wave-uniform: one of this block's 32 keys is padded
+    padded |= (in && !vk);
+    f32x16 acc[DB];
+    float delta = 0.f, delta_s = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+      for (int qt = 0; qt < NB; ++qt) {
+        typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          qfr[s] = lds_row_frag<T, DH>(bufA, qt * 32, s, lane);
+          dofr[s] = lds_row_frag<T, DH>(bufB, qt * 32, s, lane);
+        }
+        const T* tr_src = (pass == 0) ? bufB : bufA;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) trf[s2][d] = lds_tr_frag<T, DH>(tr_src, qt * 32, s2, d * 32, lane);
+        f32x16 x = zero16<DH>(), dp = zero16<DH>();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          x = Act<T>::mfma32(qfr[s], kf[s], x);
+          dp = Act<T>::mfma32(dofr[s], vf[s], dp);
+        }
+        // query rows >= S need no guard: their staged Q and dO rows are zero
+        if (exact_w) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = exact_prob(x[r], a.scale, madd, rmax, logl);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = fast_exp2(fmaf(x[r], sk2, ck2));
+        }
+        if (pass == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) delta = fmaf(x[r], dp[r], delta);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] *= fmaf(dp[r], a.scale, -delta_s);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+          for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, trf[s2][d], acc[d]);
+        }
+      }
+      if (pass == 0) {
+        delta += __shfl_xor(delta, 32, 64);
+        if (lane < 32 && in) a.delta[bh * S + k_lane] = delta;
+        delta_s = delta * a.scale;
+      }
+      T* dst = dbase + (pass == 0 ? a.v_off : a.k_off);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const int col = d * 32 + (lane & 31);
+        if (col < DH) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t k = ob * 32 + acc_row(r, lane);
+            if (k < S) dst[k * a.ld_dqkv + col] = (T)acc[d][r];
+          }
+        }
+      }
+    }
+    if (lane < 32) {
+      sSk[k_lane] = sk2; sCk[k_lane] = ck2; sMadd[k_lane] = madd; sMax[k_lane] = rmax; sLogl[k_lane] = logl;
+      sDs[k_lane] = in ? delta_s : 0.f;
+    }
+  }
+  __syncthreads();  // every wave is done with the staged Q and dO
+  stage_all<T, DH>(bufA, Kg, a.ld_qkv, S, SP, tid, nthr);
+  stage_all<T, DH>(bufB, Vg, a.ld_qkv, S, SP, tid, nthr);
+  const bool exact = __syncthreads_or(padded);
+
+  // ---- phase B: dQ for the owned queries (attn_bwd_q_kernel's tiles)
+  for (int ob = wave; ob < NB; ob += NW) {
+    const int64_t q_lane = ob * 32 + (lane & 31);
+    typename Act<T>::vec8 qf[KS], dof[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
+      dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, S, s, lane);
+    }
+    f32x16 acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+    if (exact) {
+      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+    } else {
+      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+    }
+    T* dst = dbase + a.q_off;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int col = d * 32 + (lane & 31);
+      if (col < DH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t q = ob * 32 + acc_row(r, lane);
+          if (q < S) dst[q * a.ld_dqkv + col] = (T)acc[d][r];
+        }
+      }
+    }
+  }
+}
+
+// Waves per workgroup for the resident kernels, or 0 when the sequence does not fit: maximise (resident waves per CU)
+// x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU.
+static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes) {
+  const char* force = getenv("MST_ATTN_PATH");  // "stream" / "resident": pin the path (tests cover both)
+  if (force && force[0] == 's') return 0;
+  const size_t LDS_CU = 160 * 1024;
+  if (lds_bytes > LDS_CU - 1024) return 0;
+  const int NB = (int)cdiv(S, 32);
+  const int by_grid = (int)cdiv(n_wg, 256);
+  int best = 0;
+  double best_score = 0.0;
+  for (int nw = 1; nw <= 16 && nw <= NB; ++nw) {
+    int wgs = 16 / nw;
+    if ((size_t)wgs * lds_bytes > LDS_CU) wgs = (int)(LDS_CU / lds_bytes);
+    if (wgs > by_grid) wgs = by_grid;
+    if (wgs < 1) continue;
+    const double eff = (double)NB / (double)(nw * cdiv(NB, nw));
+    const double score = (double)(wgs * nw) * eff;
+    if (score >= best_score) { best_score = score; best = nw; }
+  }
+  return best;
+}
+template <int DH> static size_t res_lds_fwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 3 * SP * LdsLd<DH>::V * 2 + 5 * SP * 4; }
+template <int DH> static size_t res_lds_bwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 2 * SP * LdsLd<DH>::V * 2 + 6 * SP * 4; }
+
 static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off) {
   MST_CHECK_ARG(B > 0 && S > 0 && H > 0, "attention: B,S,H must be positive");
   MST_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "attention: head size must be 16, 32 or 64 (got %lld)", (long long)dh);
@@ -572,6 +896,19 @@ static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, i
 
 template <typename T, int DH>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = res_lds_fwd<DH>(a.S);
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds)) {
+    static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
+    if (lds > attr_lds) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("attn_fwd_res_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL((attn_fwd_res_kernel<T, DH>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
+    MST_CHECK_LAUNCH("attn_fwd_res_kernel");
+    return MST_OK;
+  }
   dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
   hipLaunchKernelGGL((attn_fwd_stats_kernel<T, DH>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_fwd_stats_kernel");
@@ -582,6 +919,19 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
 }
 template <typename T, int DH>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = res_lds_bwd<DH>(a.S);
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds)) {
+    static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
+    if (lds > attr_lds) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_res_kernel<T, DH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("attn_bwd_res_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL((attn_bwd_res_kernel<T, DH>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
+    MST_CHECK_LAUNCH("attn_bwd_res_kernel");
+    return MST_OK;
+  }
   dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_bwd_kv_kernel");
