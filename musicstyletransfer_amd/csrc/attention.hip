@@ -186,6 +186,71 @@ struct AttnArgs {
   int64_t q_limit;  // forward: only queries [0, q_limit) are produced (the top encoder layer needs query 0 alone)
 };
 
+// Online softmax statistics of one 32-query x 32-key tile, key on the lane.
+// stats_tile_exact keeps the reference's operation order, t = fl(x*scale + madd) then exp(t - max): needed when the
+// wave holds a padded key (madd = -1e9 swallows the logit, see key_consts). stats_tile_fast is for waves without one
+// (madd = 0 for every lane): it tracks the maximum of the raw products and works in the exp2 domain,
+//   m2 = max(x) * c,  l += exp2(x * c - m2),  c = scale * log2(e)
+// i.e. max, fma, v_exp, add per element instead of fma, select, max, sub, mul, v_exp, select, add.
+template <typename T, int DH>
+__device__ __forceinline__ void stats_tile_exact(const T* sQ, int r0, int64_t q_base, int64_t S, float scale, float madd,
+                                                 const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane) {
+  f32x16 x = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, r0, s, lane), kf[s], x);
+  float t[16], tmax = NEG_BIG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool valid = q_base + acc_row(r, lane) < S;
+    t[r] = valid ? fmaf(x[r], scale, madd) : NEG_BIG;
+    tmax = fmaxf(tmax, t[r]);
+  }
+  const float m_new = fmaxf(m, tmax);
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
+  l = l * __expf(m - m_new) + sum;
+  m = m_new;
+}
+template <typename T, int DH, bool GUARD>
+__device__ __forceinline__ void stats_tile_fast(const T* sQ, int r0, int64_t q_base, int64_t S, float c,
+                                                const typename Act<T>::vec8 (&kf)[DH / 16], float& m2, float& l, int lane) {
+  f32x16 x = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, r0, s, lane), kf[s], x);
+  if (GUARD) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (q_base + acc_row(r, lane) < S) ? x[r] : -INFINITY;
+  }
+  float tmax = x[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
+  const float m_new = fmaxf(m2, tmax * c);
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += fast_exp2(fmaf(x[r], c, -m_new));
+  l = l * fast_exp2(m2 - m_new) + sum;
+  m2 = m_new;
+}
+// Full statistics of the 32 keys on this wave's lanes over the query tiles [0, n_tiles) staged at sQ (tile t at rows
+// 32 t, global query index q0 + 32 t): updates the running (max, sum) pair, natural-log domain on entry and exit.
+constexpr float LN2 = 0.6931471805599453f;
+template <typename T, int DH>
+__device__ __forceinline__ void stats_sweep(const T* sQ, int n_tiles, int64_t q0, int64_t S, float scale, float madd, bool exact_w,
+                                            const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane) {
+  if (exact_w) {
+    for (int t = 0; t < n_tiles; ++t) stats_tile_exact<T, DH>(sQ, t * 32, q0 + t * 32, S, scale, madd, kf, m, l, lane);
+    return;
+  }
+  const float c = scale * LOG2E;
+  float m2 = (m > NEG_BIG) ? m * LOG2E : NEG_BIG;
+  for (int t = 0; t < n_tiles; ++t) {
+    if (q0 + t * 32 + 32 <= S) stats_tile_fast<T, DH, false>(sQ, t * 32, q0 + t * 32, S, c, kf, m2, l, lane);
+    else stats_tile_fast<T, DH, true>(sQ, t * 32, q0 + t * 32, S, c, kf, m2, l, lane);
+  }
+  m = (m2 > NEG_BIG) ? m2 * LN2 : NEG_BIG;
+}
+
 // ------------------------------------------------------------------------------------ fwd_stats
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
@@ -207,7 +272,9 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   typename Act<T>::vec8 kf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
-  const float madd = (k_lane < S && a.keymask[b * S + k_lane]) ? 0.f : MASK_VALUE;
+  const bool key_ok = k_lane < S && a.keymask[b * S + k_lane];
+  const float madd = key_ok ? 0.f : MASK_VALUE;
+  const bool exact_w = __any(!key_ok);  // a padded (or out-of-range) key on this wave: reference operation order
 
   float m = NEG_BIG, l = 0.f;
   for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
@@ -215,26 +282,8 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
     stage_store<T, DH>(sQ, rq, tid);
     if (q0 + ATT_STAGE < S) stage_load<T, DH>(rq, Qg, a.ld_qkv, q0 + ATT_STAGE, S, tid);
     __syncthreads();
-#pragma unroll
-    for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
-      if (q0 + blk * 32 >= S) break;
-      f32x16 x = zero16<DH>();
-#pragma unroll
-      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, blk * 32, s, lane), kf[s], x);
-      float t[16], tmax = NEG_BIG;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool valid = q0 + blk * 32 + acc_row(r, lane) < S;
-        t[r] = valid ? fmaf(x[r], a.scale, madd) : NEG_BIG;
-        tmax = fmaxf(tmax, t[r]);
-      }
-      const float m_new = fmaxf(m, tmax);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
-      l = l * __expf(m - m_new) + sum;
-      m = m_new;
-    }
+    const int64_t left = S - q0;
+    stats_sweep<T, DH>(sQ, (int)((left < ATT_STAGE ? left : ATT_STAGE) + 31) / 32, q0, S, a.scale, madd, exact_w, kf, m, l, lane);
   }
   // the two lane halves hold disjoint query subsets of the same key
   const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
@@ -593,6 +642,49 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   }
 }
 
+// One 32-query x 32-key tile of the key-owner backward. PASS 0: dV += P^T dO and delta += sum_q P dP;
+// PASS 1: dK += (P (dP s - delta s))^T Q. sQ / sdO are the staged query-side operands (rows >= S are zero, so query
+// rows beyond the sequence contribute nothing and need no guard).
+template <typename T, int DH, int PASS, bool EXACT>
+__device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, float scale, const typename Act<T>::vec8 (&kf)[DH / 16],
+                                            const typename Act<T>::vec8 (&vf)[DH / 16], float sk2, float ck2, float madd, float rmax,
+                                            float logl, float& delta, float delta_s, f32x16 (&acc)[(DH + 31) / 32], int lane) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qfr[s] = lds_row_frag<T, DH>(sQ, qt * 32, s, lane);
+    dofr[s] = lds_row_frag<T, DH>(sdO, qt * 32, s, lane);
+  }
+  const T* tr_src = (PASS == 0) ? sdO : sQ;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) trf[s2][d] = lds_tr_frag<T, DH>(tr_src, qt * 32, s2, d * 32, lane);
+  f32x16 x = zero16<DH>(), dp = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    x = Act<T>::mfma32(qfr[s], kf[s], x);
+    dp = Act<T>::mfma32(dofr[s], vf[s], dp);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pr = EXACT ? exact_prob(x[r], scale, madd, rmax, logl) : fast_exp2(fmaf(x[r], sk2, ck2));
+    if (PASS == 0) {
+      delta = fmaf(pr, dp[r], delta);
+      x[r] = pr;
+    } else {
+      x[r] = pr * fmaf(dp[r], scale, -delta_s);
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, trf[s2][d], acc[d]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ resident kernels
 // One workgroup per (batch, head) with the whole sequence resident in LDS: the two kernels of each direction become
 // two PHASES of one launch (every launch in the captured step costs ~4.7 us before its first wave does useful work,
@@ -652,24 +744,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
     const bool vk = in && a.keymask[b * S + k_lane];
     const float madd = vk ? 0.f : MASK_VALUE;
     float m = NEG_BIG, l = 0.f;
-    for (int qt = 0; qt < NB; ++qt) {
-      f32x16 x = zero16<DH>();
-#pragma unroll
-      for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, qt * 32, s, lane), kf[s], x);
-      float t[16], tmax = NEG_BIG;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool valid = qt * 32 + acc_row(r, lane) < S;
-        t[r] = valid ? fmaf(x[r], a.scale, madd) : NEG_BIG;
-        tmax = fmaxf(tmax, t[r]);
-      }
-      const float m_new = fmaxf(m, tmax);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
-      l = l * __expf(m - m_new) + sum;
-      m = m_new;
-    }
+    stats_sweep<T, DH>(sQ, NB, 0, S, a.scale, madd, __any(!vk), kf, m, l, lane);
     const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
     const float M = fmaxf(m, m2);
     const float logl = __logf(l * __expf(m - M) + l2 * __expf(m2 - M));
@@ -761,45 +836,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
       for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
-      for (int qt = 0; qt < NB; ++qt) {
-        typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          qfr[s] = lds_row_frag<T, DH>(bufA, qt * 32, s, lane);
-          dofr[s] = lds_row_frag<T, DH>(bufB, qt * 32, s, lane);
-        }
-        const T* tr_src = (pass == 0) ? bufB : bufA;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int d = 0; d < DB; ++d) trf[s2][d] = lds_tr_frag<T, DH>(tr_src, qt * 32, s2, d * 32, lane);
-        f32x16 x = zero16<DH>(), dp = zero16<DH>();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          x = Act<T>::mfma32(qfr[s], kf[s], x);
-          dp = Act<T>::mfma32(dofr[s], vf[s], dp);
-        }
-        // query rows >= S need no guard: their staged Q and dO rows are zero
-        if (exact_w) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = exact_prob(x[r], a.scale, madd, rmax, logl);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = fast_exp2(fmaf(x[r], sk2, ck2));
-        }
-        if (pass == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) delta = fmaf(x[r], dp[r], delta);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] *= fmaf(dp[r], a.scale, -delta_s);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
-#pragma unroll
-          for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, trf[s2][d], acc[d]);
-        }
+      // four straight-line tile loops (pass x exact) instead of branches inside one: the merged form shuffled the
+      // probability tile through 15 v_mov per tile to reconcile the two passes' register assignments
+      if (pass == 0) {
+        if (exact_w) for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        else for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+      } else {
+        if (exact_w) for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        else for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
       }
       if (pass == 0) {
         delta += __shfl_xor(delta, 32, 64);

@@ -198,7 +198,12 @@ def attn_reference(qkv, keymask, B, S, H, dh, k_off, q_off, v_off):
 
 @pytest.mark.parametrize("B,S,H,dh", [(2, 64, 2, 32), (3, 5, 2, 16), (2, 257, 8, 16), (2, 256, 8, 32), (1, 100, 1, 64),
                                      (1, 1024, 2, 32)])
-def test_attention_fwd_bwd(gpu, B, S, H, dh):
+@pytest.mark.parametrize("path", ["auto", "stream"])
+def test_attention_fwd_bwd(gpu, monkeypatch, B, S, H, dh, path):
+    """auto: the resident single-launch kernels when the sequence fits in LDS (all cases but S=1024), else the
+    streaming kernels; stream: the streaming kernels for every case"""
+    if path == "stream":
+        monkeypatch.setenv("MST_ATTN_PATH", "stream")
     o = ops()
     D = H * dh
     ldq = 3 * D
@@ -231,7 +236,10 @@ def test_attention_fwd_bwd(gpu, B, S, H, dh):
     close(dqkv[:, q_off:q_off + D], g[:, q_off:q_off + D], 3e-2, 3e-2 * scale, "dQ")
 
 
-def test_attention_q_limit_produces_only_the_first_queries(gpu):
+@pytest.mark.parametrize("path", ["auto", "stream"])
+def test_attention_q_limit_produces_only_the_first_queries(gpu, monkeypatch, path):
+    if path == "stream":
+        monkeypatch.setenv("MST_ATTN_PATH", "stream")
     o = ops()
     B, S, H, dh = 2, 70, 2, 32
     D = H * dh
@@ -248,8 +256,11 @@ def test_attention_q_limit_produces_only_the_first_queries(gpu):
     assert (p3[:, 1:] == 5.0).all()
 
 
-def test_attention_padded_key_rows_are_uniform(gpu):
+@pytest.mark.parametrize("path", ["auto", "stream"])
+def test_attention_padded_key_rows_are_uniform(gpu, monkeypatch, path):
     """a padded key row is NOT excluded, it contributes V[k]/S to every query"""
+    if path == "stream":
+        monkeypatch.setenv("MST_ATTN_PATH", "stream")
     o = ops()
     B, S, H, dh = 1, 32, 1, 16
     D = H * dh
