@@ -10,6 +10,7 @@
 // workgroups (≫256 of them) and partial tiles are accumulated with fp32 atomics into the flat
 // gradient bucket, which the step zeroes once. Several layers' problems go into ONE launch
 // (mst_wgrad_batch) so the split factor, and with it the atomic traffic, stays small.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace mst {
@@ -24,20 +25,13 @@ struct WgradBatch {
 
 constexpr int BMR = 64;  // m rows per LDS stage
 
-// XOR swizzle of the 16-byte chunk index inside a tile row, chosen so that ds_read_tr16_b64 — whose 32-lane half
-// reads rows r0..r0+3 and r0+8..r0+11 of the same 16 columns — touches 32 distinct 8-byte slots (all 64 banks).
-// Unswizzled row-major tiles measured 75 % of LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-//   256-byte rows (128 columns): chunk ^= ((row & 3) << 2) | ((row >> 2) & 3)
-//   128-byte rows ( 64 columns): chunk ^= (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)
-template <int COLS>
-__device__ __forceinline__ int swz(int row) {
-  if (COLS == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
-  return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
-}
-template <int COLS>
-__device__ __forceinline__ int swz_off(int row, int col) {  // element offset of (row, col) in a swizzled [rows][COLS] tile
-  return row * COLS + ((((col >> 3) ^ swz<COLS>(row)) << 3) | (col & 7));
-}
+// LDS tiles are row-major with rows padded by 16 elements (32 bytes). ds_read_tr16_b64 has each 16-lane group read
+// 4 consecutive rows x 32 bytes; with 288-byte (or 160-byte) rows those four pieces fall on four different 32-byte
+// bank windows, so the reads are conflict-free (unpadded 256-byte rows measured 75 % of LDS cycles as conflicts), and
+// every fragment address of a stage is ONE per-lane base plus a compile-time offset. (An XOR swizzle of the chunk
+// index is conflict-free too, but its offsets are not additive: the kernel spent 265 VALU instructions per 64-row
+// stage and wave, twice the MFMA time, mostly on LDS and global address arithmetic.)
+constexpr int LDS_PAD = 16;
 
 __device__ __forceinline__ i16x4 tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
@@ -52,21 +46,28 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   constexpr int A_CH = BMR * A_CPR / NT, B_CH = BMR * B_CPR / NT;
   static_assert(BMR * A_CPR % NT == 0 && BMR * B_CPR % NT == 0, "tile/threads mismatch");
   static_assert(NT % A_CPR == 0 && NT % B_CPR == 0, "column ownership must be loop-invariant");
-  static_assert((BN == 64 || BN == 128) && (BKO == 64 || BKO == 128), "swizzles exist for 64- and 128-column tiles");
   typedef typename Act<T>::vec8 vec8;
 
+  constexpr int LDA_S = BN + LDS_PAD, LDB_S = BKO + LDS_PAD;  // LDS row strides in elements
+  constexpr int A_RSTEP = NT / A_CPR, B_RSTEP = NT / B_CPR;   // row distance between a thread's consecutive chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* sA = reinterpret_cast<T*>(smem);          // [2][BMR][BN]
-  T* sB = sA + 2 * BMR * BN;                   // [2][BMR][BKO]
-  __shared__ float colsum[BN];
-
+  T* sA = reinterpret_cast<T*>(smem);          // [2][BMR][LDA_S]
+  T* sB = sA + 2 * BMR * LDA_S;                // [2][BMR][LDB_S]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WGK, wk = wave % WGK;
 
   // locate (problem, tile, split)
   const int64_t total_tiles = b.tile_prefix[b.n];
-  const int64_t tile_lin = blockIdx.x % total_tiles;
-  const int split_id = (int)(blockIdx.x / total_tiles);
+  // Workgroup ids are dealt round-robin to the 8 XCDs. Work items are numbered split-major (M-slab, then tile) and
+  // every XCD takes a contiguous eighth of them: the tiles of all problems that read the same rows then mostly share
+  // one XCD's L2, and the operands cross the fabric about once (117 MB for the encoder layer's four problems)
+  // instead of once per XCD that owns a tile needing them (312 MB with the tile-major order).
+  const int64_t n_items = total_tiles * b.split;
+  const int64_t per_xcd = (n_items + 7) / 8;
+  const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (item >= n_items) return;
+  const int64_t tile_lin = item % total_tiles;
+  const int split_id = (int)(item / total_tiles);
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < WG_MAXP; ++i)
@@ -85,56 +86,44 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
   const bool do_bias = (a.db != nullptr) && (k0 == 0);
 
-  int a_row[A_CH], a_col[A_CH], b_row[B_CH], b_col[B_CH];
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) { int c = tid + i * NT; a_row[i] = c / A_CPR; a_col[i] = (c % A_CPR) * 8; }
-#pragma unroll
-  for (int i = 0; i < B_CH; ++i) { int c = tid + i * NT; b_row[i] = c / B_CPR; b_col[i] = (c % B_CPR) * 8; }
+  // chunk ownership: thread tid stages chunks (row a_r0 + i*A_RSTEP, columns a_c..a_c+7), i < A_CH — the column is
+  // loop-invariant, so the edge test is one flag and the global pointer just advances by whole rows
+  const int a_r0 = tid / A_CPR, a_c = (tid % A_CPR) * 8;
+  const int b_r0 = tid / B_CPR, b_c = (tid % B_CPR) * 8;
+  const bool a_ok = n0 + a_c < a.N, b_ok = k0 + b_c < a.K;
+  const bool remap_a = a.a_rows_per_group > 0, remap_b = a.b_rows_per_group > 0;
+  const T* pa = A + (m_begin + a_r0) * a.lda + n0 + a_c;  // used when the rows are not remapped
+  const T* pb = B + (m_begin + b_r0) * a.ldb + k0 + b_c;
 
   u32x4 ra[A_CH], rb[B_CH];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  float bsum[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
   auto load_tile = [&](int64_t mb) {
+    const bool full = mb + BMR <= m_end;  // uniform: only the last stage of a slab can be partial
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int64_t m = mb + a_row[i], n = n0 + a_col[i];
-      if (m < m_end && n < a.N) {
-        int64_t pm = remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
-        ra[i] = *reinterpret_cast<const u32x4*>(A + pm * a.lda + n);
-      } else {
-        ra[i] = zero4;
-      }
+      const int64_t m = mb + a_r0 + i * A_RSTEP;
+      const T* src = remap_a ? A + remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) * a.lda + n0 + a_c
+                             : pa + (int64_t)i * A_RSTEP * a.lda;
+      ra[i] = (a_ok && (full || m < m_end)) ? *reinterpret_cast<const u32x4*>(src) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      int64_t m = mb + b_row[i], k = k0 + b_col[i];
-      if (m < m_end && k < a.K) {
-        int64_t pm = remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset);
-        rb[i] = *reinterpret_cast<const u32x4*>(B + pm * a.ldb + k);
-      } else {
-        rb[i] = zero4;
-      }
+      const int64_t m = mb + b_r0 + i * B_RSTEP;
+      const T* src = remap_b ? B + remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) * a.ldb + k0 + b_c
+                             : pb + (int64_t)i * B_RSTEP * a.ldb;
+      rb[i] = (b_ok && (full || m < m_end)) ? *reinterpret_cast<const u32x4*>(src) : zero4;
     }
+    pa += (int64_t)BMR * a.lda;
+    pb += (int64_t)BMR * a.ldb;
   };
+  T* const wA = sA + a_r0 * LDA_S + a_c;  // this thread's first chunk in buffer 0
+  T* const wB = sB + b_r0 * LDB_S + b_c;
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i)
-      *reinterpret_cast<u32x4*>(sA + buf * BMR * BN + swz_off<BN>(a_row[i], a_col[i])) = ra[i];
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(wA + buf * BMR * LDA_S + i * A_RSTEP * LDA_S) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i)
-      *reinterpret_cast<u32x4*>(sB + buf * BMR * BKO + swz_off<BKO>(b_row[i], b_col[i])) = rb[i];
-    if (do_bias) {
-      // every chunk this thread owns covers the same 8 columns (NT % A_CPR == 0)
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        Pack8 p; p.u = ra[i];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += bits_to_f32<T>(p.h[e]);
-      }
-    }
+    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(wB + buf * BMR * LDB_S + i * B_RSTEP * LDB_S) = rb[i];
   };
 
   f32x4 acc[TN][TK];
@@ -142,10 +131,21 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int i = 0; i < TK; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of A: one more MFMA per A fragment against an all-ones B fragment (every output
+  // column then holds the sum) on the waves of the first K tile — no VALU work at all
+  const bool bias_wave = do_bias && wk == 0;
+  f32x4 acc_b[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc_b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  vec8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (T)1.f;
 
   // tr-read lane roles: 16-lane group g = lane>>4 covers m rows 8g..8g+7 of a 32-row k-step;
   // lane i = lane&15 supplies the address of row (i>>2), columns 4*(i&3).. and receives column i.
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pcol = (li & 3) * 4;
+  const T* const fA = sA + (8 * g + q) * LDA_S + wn * WTN + pcol;  // + compile-time offsets below
+  const T* const fB = sB + (8 * g + q) * LDB_S + wk * WTK + pcol;
 
   const int64_t nsteps = (m_end - m_begin + BMR - 1) / BMR;
   load_tile(m_begin);
@@ -154,32 +154,34 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   for (int64_t t = 0; t < nsteps; ++t) {
     const int cur = (int)(t & 1);
     if (t + 1 < nsteps) load_tile(m_begin + (t + 1) * BMR);
-    const T* cA = sA + cur * BMR * BN;
-    const T* cB = sB + cur * BMR * BKO;
+    const T* cA = fA + cur * BMR * LDA_S;
+    const T* cB = fB + cur * BMR * LDB_S;
 #pragma unroll
     for (int ms = 0; ms < BMR / 32; ++ms) {
       vec8 af[TN], bf[TK];
-      const int r_lo = ms * 32 + 8 * g + q;  // block rows r..r+3 → elements 0..3; +4 → elements 4..7
+      // rows r..r+3 of the 16-lane group -> elements 0..3; rows r+4..r+7 -> elements 4..7
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int c = wn * WTN + j * 16 + pcol;
-        i16x4 lo = tr_read(cA + swz_off<BN>(r_lo, c));
-        i16x4 hi = tr_read(cA + swz_off<BN>(r_lo + 4, c));
-        i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const i16x4 lo = tr_read(cA + (ms * 32) * LDA_S + j * 16);
+        const i16x4 hi = tr_read(cA + (ms * 32 + 4) * LDA_S + j * 16);
+        const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[j] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll
       for (int i = 0; i < TK; ++i) {
-        const int c = wk * WTK + i * 16 + pcol;
-        i16x4 lo = tr_read(cB + swz_off<BKO>(r_lo, c));
-        i16x4 hi = tr_read(cB + swz_off<BKO>(r_lo + 4, c));
-        i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const i16x4 lo = tr_read(cB + (ms * 32) * LDB_S + i * 16);
+        const i16x4 hi = tr_read(cB + (ms * 32 + 4) * LDB_S + i * 16);
+        const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bf[i] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TK; ++i) acc[j][i] = Act<T>::mfma16(af[j], bf[i], acc[j][i]);
+      if (bias_wave) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc_b[j] = Act<T>::mfma16(af[j], ones, acc_b[j]);
+      }
     }
     if (t + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
@@ -199,27 +201,34 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
     }
   }
 
-  if (do_bias) {
-    for (int i = tid; i < BN; i += NT) colsum[i] = 0.f;
-    __syncthreads();
+  if (bias_wave && li == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&colsum[a_col[0] + e], bsum[e]);
-    __syncthreads();
-    for (int i = tid; i < BN; i += NT)
-      if (n0 + i < a.N) atomicAdd(a.db + n0 + i, colsum[i] * a.scale);
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + wn * WTN + j * 16 + 4 * g + r;
+        if (n < a.N) atomicAdd(a.db + n, acc_b[j][r] * a.scale);
+      }
   }
 }
 
 template <typename T>
 static int launch_wgrad(const WgradBatch& b, bool big, hipStream_t s) {
-  const int64_t total = b.tile_prefix[b.n] * b.split;
+  const int64_t total = cdiv(b.tile_prefix[b.n] * b.split, 8) * 8;  // padded to whole XCD rounds (see the kernel)
   if (big) {
     constexpr int BN = 128, BKO = 128;
-    size_t lds = (size_t)2 * BMR * (BN + BKO) * 2;
+    size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
+    static bool opted = false;  // 73.7 KB of dynamic LDS: above the 64 KB default
+    if (!opted) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BN, BKO, 2, 2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("wgrad_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted = true;
+    }
     hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 2, 2>), dim3((unsigned)total), dim3(256), lds, s, b);
   } else {
     constexpr int BN = 64, BKO = 64;
-    size_t lds = (size_t)2 * BMR * (BN + BKO) * 2;
+    size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
     hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 2, 2>), dim3((unsigned)total), dim3(256), lds, s, b);
   }
   MST_CHECK_LAUNCH("wgrad_kernel");
@@ -267,7 +276,8 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
   // aim for >= 1024 workgroups, at least 2 LDS stages (128 rows) per workgroup
   // 128x128 tiles run 2 workgroups per CU at most (register file), 64x64 tiles 5: aim for one full wave of
   // workgroups, no more — every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
-  int64_t split = cdiv(big ? 512 : 1024, tiles);
+  int64_t split = (big ? 512 : 1024) / tiles;  // floor: a 513th workgroup would start a second round (105 vs 83 us)
+  if (const char* e = getenv("MST_WGRAD_SPLIT")) split = atoi(e);  // TEMP experiment
   int64_t max_split = cdiv(maxM, 2 * BMR);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;

@@ -1,4 +1,5 @@
-"""GPU micro-benchmark of the GEMM entry points on the step's shapes (not a test)."""
+"""GPU micro-benchmark of the GEMM entry points on the step's shapes (not a test).
+usage: bench_gemm.py [iters] [wgrad]   (second argument: only the weight-gradient batch, e.g. under rocprofv3 --pmc)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,7 +7,12 @@ from musicstyletransfer_amd import ops as o
 BF = torch.bfloat16
 dev = torch.device("cuda", 0)
 
-def timeit(fn, iters=30):
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+ONLY_WGRAD = len(sys.argv) > 2 and sys.argv[2] == "wgrad"
+
+
+def timeit(fn, iters=None):
+    iters = iters or ITERS
     fn(); torch.cuda.synchronize()
     e0, e1 = o.Event(), o.Event()
     e0.record()
@@ -17,7 +23,7 @@ def timeit(fn, iters=30):
 def run():
     M = 16384
     print(f"{'case':44s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s(alg)':>10s}")
-    for name, N, K, kw in [("qkv fwd  N768 K256 bias", 768, 256, dict(bias=True)),
+    for name, N, K, kw in [] if ONLY_WGRAD else [("qkv fwd  N768 K256 bias", 768, 256, dict(bias=True)),
                            ("proj fwd N256 K256 bias+resid", 256, 256, dict(bias=True, resid=True)),
                            ("ff1 fwd  N1024 K256 bias+relu", 1024, 256, dict(bias=True, relu=True)),
                            ("ff1 fwd  + dropout 0.2", 1024, 256, dict(bias=True, relu=True, drop=0.2)),
