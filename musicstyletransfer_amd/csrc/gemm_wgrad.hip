@@ -10,7 +10,6 @@
 // workgroups (≫256 of them) and partial tiles are accumulated with fp32 atomics into the flat
 // gradient bucket, which the step zeroes once. Several layers' problems go into ONE launch
 // (mst_wgrad_batch) so the split factor, and with it the atomic traffic, stays small.
-#include <stdlib.h>
 #include "common.hpp"
 
 namespace mst {
@@ -92,30 +91,35 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const int b_r0 = tid / B_CPR, b_c = (tid % B_CPR) * 8;
   const bool a_ok = n0 + a_c < a.N, b_ok = k0 + b_c < a.K;
   const bool remap_a = a.a_rows_per_group > 0, remap_b = a.b_rows_per_group > 0;
-  const T* pa = A + (m_begin + a_r0) * a.lda + n0 + a_c;  // used when the rows are not remapped
-  const T* pb = B + (m_begin + b_r0) * a.ldb + k0 + b_c;
+  // interior tile of a problem without row remap: plain loads, no per-chunk select (uniform flag)
+  const bool plain = !remap_a && !remap_b && n0 + BN <= a.N && k0 + BKO <= a.K;
+  const int a_off = (int)(a_r0 * a.lda) + a_c, b_off = (int)(b_r0 * a.ldb) + b_c;  // per-thread element offsets
 
   u32x4 ra[A_CH], rb[B_CH];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   auto load_tile = [&](int64_t mb) {
     const bool full = mb + BMR <= m_end;  // uniform: only the last stage of a slab can be partial
+    if (plain && full) {
+      // uniform row pointer (scalar registers) + the thread's 32-bit offset
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const u32x4*>(A + (mb + i * A_RSTEP) * a.lda + n0 + a_off);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(B + (mb + i * B_RSTEP) * a.ldb + k0 + b_off);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int64_t m = mb + a_r0 + i * A_RSTEP;
-      const T* src = remap_a ? A + remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) * a.lda + n0 + a_c
-                             : pa + (int64_t)i * A_RSTEP * a.lda;
-      ra[i] = (a_ok && (full || m < m_end)) ? *reinterpret_cast<const u32x4*>(src) : zero4;
+      const int64_t pm = remap_a ? remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : m;
+      ra[i] = (a_ok && m < m_end) ? *reinterpret_cast<const u32x4*>(A + pm * a.lda + n0 + a_c) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int64_t m = mb + b_r0 + i * B_RSTEP;
-      const T* src = remap_b ? B + remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) * a.ldb + k0 + b_c
-                             : pb + (int64_t)i * B_RSTEP * a.ldb;
-      rb[i] = (b_ok && (full || m < m_end)) ? *reinterpret_cast<const u32x4*>(src) : zero4;
+      const int64_t pm = remap_b ? remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) : m;
+      rb[i] = (b_ok && m < m_end) ? *reinterpret_cast<const u32x4*>(B + pm * a.ldb + k0 + b_c) : zero4;
     }
-    pa += (int64_t)BMR * a.lda;
-    pb += (int64_t)BMR * a.ldb;
   };
   T* const wA = sA + a_r0 * LDA_S + a_c;  // this thread's first chunk in buffer 0
   T* const wB = sB + b_r0 * LDB_S + b_c;
@@ -141,36 +145,32 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (T)1.f;
 
-  // tr-read lane roles: 16-lane group g = lane>>4 covers m rows 8g..8g+7 of a 32-row k-step;
-  // lane i = lane&15 supplies the address of row (i>>2), columns 4*(i&3).. and receives column i.
+  // tr-read lane roles: lane i = lane&15 of 16-lane group g = lane>>4 supplies the address of one row, columns
+  // 4*(i&3).., and receives column i. Which 8 of a k-step's 32 rows feed group g's k slots is free as long as A and B
+  // agree; rows 4g..4g+3 (elements 0..3) and 16+4g..16+4g+3 (elements 4..7) make the two groups of a 32-lane half
+  // cover all eight 32-byte bank windows of the padded rows (rows 8g.. had them collide pairwise: 33 % conflict cycles).
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pcol = (li & 3) * 4;
-  const T* const fA = sA + (8 * g + q) * LDA_S + wn * WTN + pcol;  // + compile-time offsets below
-  const T* const fB = sB + (8 * g + q) * LDB_S + wk * WTK + pcol;
+  const T* const fA = sA + (4 * g + q) * LDA_S + wn * WTN + pcol;  // + compile-time offsets below
+  const T* const fB = sB + (4 * g + q) * LDB_S + wk * WTK + pcol;
 
   const int64_t nsteps = (m_end - m_begin + BMR - 1) / BMR;
-  load_tile(m_begin);
-  store_tile(0);
-  __syncthreads();
-  for (int64_t t = 0; t < nsteps; ++t) {
-    const int cur = (int)(t & 1);
-    if (t + 1 < nsteps) load_tile(m_begin + (t + 1) * BMR);
+  auto compute = [&](int cur) {
     const T* cA = fA + cur * BMR * LDA_S;
     const T* cB = fB + cur * BMR * LDB_S;
 #pragma unroll
     for (int ms = 0; ms < BMR / 32; ++ms) {
       vec8 af[TN], bf[TK];
-      // rows r..r+3 of the 16-lane group -> elements 0..3; rows r+4..r+7 -> elements 4..7
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const i16x4 lo = tr_read(cA + (ms * 32) * LDA_S + j * 16);
-        const i16x4 hi = tr_read(cA + (ms * 32 + 4) * LDA_S + j * 16);
+        const i16x4 hi = tr_read(cA + (ms * 32 + 16) * LDA_S + j * 16);
         const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[j] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll
       for (int i = 0; i < TK; ++i) {
         const i16x4 lo = tr_read(cB + (ms * 32) * LDB_S + i * 16);
-        const i16x4 hi = tr_read(cB + (ms * 32 + 4) * LDB_S + i * 16);
+        const i16x4 hi = tr_read(cB + (ms * 32 + 16) * LDB_S + i * 16);
         const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bf[i] = __builtin_bit_cast(vec8, v);
       }
@@ -183,6 +183,18 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
         for (int j = 0; j < TN; ++j) acc_b[j] = Act<T>::mfma16(af[j], ones, acc_b[j]);
       }
     }
+  };
+  // One stage of global loads in flight, staged through registers into the other LDS buffer. (Two stages in flight —
+  // a second register set, 256 VGPRs — measured the same 58 us: with conflict-free reads the kernel is bound by LDS
+  // bandwidth, 8 waves x (32 transposed 512-byte reads + 8 1-KiB writes) per 64-row stage keep the CU's LDS busy
+  // ~100 % of the time; fewer LDS bytes per MFMA needs a larger per-wave tile than 64x64.)
+  load_tile(m_begin);
+  store_tile(0);
+  __syncthreads();
+  for (int64_t t = 0; t < nsteps; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nsteps) load_tile(m_begin + (t + 1) * BMR);
+    compute(cur);
     if (t + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
   }
@@ -277,7 +289,6 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
   // 128x128 tiles run 2 workgroups per CU at most (register file), 64x64 tiles 5: aim for one full wave of
   // workgroups, no more — every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
   int64_t split = (big ? 512 : 1024) / tiles;  // floor: a 513th workgroup would start a second round (105 vs 83 us)
-  if (const char* e = getenv("MST_WGRAD_SPLIT")) split = atoi(e);  // TEMP experiment
   int64_t max_split = cdiv(maxM, 2 * BMR);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
