@@ -99,21 +99,26 @@ def dominant_kernel_roofline(plan, o, iters=50):
     cands = {
         "gemm_nt_kernel[enc ff1 fwd: M=16384 N=1024 K=256]": (
             lambda: o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU),
-            2.0 * M * 4 * De * De, 6 * cfg.e_layers),  # same-sized GEMMs per step: ff1/ff2 fwd + 2 dgrads each, per layer
+            2.0 * M * 4 * De * De, 6 * cfg.e_layers,  # same-sized GEMMs per step: ff1/ff2 fwd + 2 dgrads each, per layer
+            2.0 * (M * De + 4 * De * De + M * 4 * De) + 4.0 * 4 * De,  # x1 + W + a (16-bit) + fp32 bias
+            "gemm_nt_kernel<128,128,2,2>@%d" % (((M + 127) // 128) * ((4 * De + 127) // 128) * 256)),
         "wgrad_kernel[enc layer: 4 problems, M=16384]": (
             lambda: o.gemm_wgrad_batch([
                 o.wgrad_problem(plan.be.dh, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=De, K=4 * De),
                 o.wgrad_problem(plan.be.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * De, K=De),
                 o.wgrad_problem(plan.be.dh1, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=De, K=De),
                 o.wgrad_problem(plan.be.dqkv, plan.x0_e, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * De, K=De)]),
-            2.0 * M * 12 * De * De, cfg.e_layers),
+            2.0 * M * 12 * De * De, cfg.e_layers,
+            2.0 * M * (De + 4 * De + 4 * De + De + De + De + 3 * De + De) + 4.0 * 12 * De * De,  # 8 operand reads + fp32 dW
+            "wgrad_kernel<128,128,2,2>@122880"),
         "attn_bwd(kv+q)[enc: B*H=512, S=256, dh=32]": (
             lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, plan.be.datt, plan.be.dqkv, plan.be.delta, plan.B, plan.T,
                                cfg.e_heads, De // cfg.e_heads, 0, De, 2 * De),
-            2.0 * 4 * plan.B * plan.T * plan.T * De, cfg.e_layers),  # algorithmic: 2x the forward's 4*S^2*D per sample
+            2.0 * 4 * plan.B * plan.T * plan.T * De, cfg.e_layers,  # algorithmic: 2x the forward's 4*S^2*D per sample
+            2.0 * M * (3 * De + De + 3 * De), "attn_bwd_res_kernel<32>@262144"),  # qkv + dO in, dqkv out
     }
     best = None
-    for name, (fn, flops, per_step) in cands.items():
+    for name, (fn, flops, per_step, nbytes, pmc_key) in cands.items():
         fn()
         torch.cuda.synchronize()
         e0, e1 = o.Event(), o.Event()
@@ -123,13 +128,27 @@ def dominant_kernel_roofline(plan, o, iters=50):
         e1.record()
         e1.sync()
         ms = e0.elapsed_ms(e1) / iters
-        rec = dict(kernel=name, ms=ms, flops=flops, share_ms=ms * per_step)
+        rec = dict(kernel=name, ms=ms, flops=flops, share_ms=ms * per_step, bytes=nbytes, pmc_key=pmc_key)
         if best is None or rec["share_ms"] > best["share_ms"]:
             best = rec
-    achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": best["kernel"], "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": best["ms"],
-            "algorithmic_flops_per_launch": best["flops"]}
+    # Which roof binds? Algorithmic intensity (flops / compulsory bytes) against the ridge PEAK_MFMA / PEAK_HBM.
+    tflops = best["flops"] / (best["ms"] * 1e-3) / 1e12
+    gbs = best["bytes"] / (best["ms"] * 1e-3) / 1e9
+    ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = best["flops"] / best["bytes"] < ridge
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (tools/make_profile_summary.py), not measured here
+        with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+            traffic = json.load(f)["bytes_per_launch"].get(best["pmc_key"])
+    except (OSError, ValueError, KeyError):
+        pass
+    out = {"bound": "hbm" if hbm_bound else "mfma", "kernel": best["kernel"],
+           "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
+           "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_MFMA_TFLOPS),
+           "traffic": traffic, "avg_launch_ms": best["ms"], "algorithmic_bytes_per_launch": best["bytes"],
+           "algorithmic_flops_per_launch": best["flops"], "tflops": tflops, "mfma_frac": tflops / PEAK_MFMA_TFLOPS,
+           "intensity_flop_per_byte": best["flops"] / best["bytes"], "ridge_flop_per_byte": ridge}
+    return out
 
 
 def main():
