@@ -265,7 +265,9 @@ int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma
 int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V,
                    const void* logits, int64_t ld, const int32_t* labels,
                    float* loss, float* probs, int64_t ldp,
-                   void* dlogits, int64_t ldd, float gscale, mst_stream_t stream);
+                   void* dlogits, int64_t ldd, float gscale,
+                   int pre_zeroed /* 1: loss[] is already zero (mst_step_begin's zero list), skip the memset node */,
+                   mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K14: sigmoid + BinaryCrossEntropy (loss.py:27-80), piano-roll head.
@@ -281,7 +283,8 @@ int mst_sigmoid_bce(int dtype, int64_t B, int64_t T, int64_t P,
                     const void* logits, int64_t ld, const uint8_t* labels,
                     float label_smoothing, int downweight, int32_t* npos,
                     float* loss, void* probs, int64_t ldp,
-                    void* dlogits, int64_t ldd, float gscale, mst_stream_t stream);
+                    void* dlogits, int64_t ldd, float gscale,
+                    int pre_zeroed /* as in mst_softmax_ce */, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K15/K21: total[b] = recon[b] + kl_weight * kl[b]; metric_acc[0] += sum_b kl, [1] += sum_b total,
@@ -328,12 +331,14 @@ int mst_zero(void* ptr, int64_t bytes, mst_stream_t stream);
 int mst_rng_advance(uint64_t* state, mst_stream_t stream);
 /* Top-of-step bookkeeping in ONE launch (every kernel in the captured graph costs ~4.7 us): mst_rng_advance, Adam's
  * step counter / bias-corrected lr (then call mst_adam_flat with advance_step = 0), mst_randn into eps_out, and the two
- * mst_mask_from_lengths masks (model.py:246-247). Any pointer may be NULL to skip that part. rng_state is the
- * uint64[4] state of mst_rng_advance. */
+ * mst_mask_from_lengths masks (model.py:246-247), and two optional buffers to clear (16-byte aligned, sizes multiples
+ * of 16: the per-sample loss sums and the gradient bucket, instead of two memset nodes). Any pointer may be NULL to
+ * skip that part. rng_state is the uint64[4] state of mst_rng_advance. */
 int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2,
                    float* eps_out, int64_t n_eps, uint32_t eps_site,
                    const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se, int32_t add_e,
-                   uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream);
+                   uint8_t* mask_d, int64_t Sd, int32_t add_d,
+                   void* zero_a, int64_t zero_a_bytes, void* zero_b, int64_t zero_b_bytes, mst_stream_t stream);
 /* eps ~ N(0,1) (replaces mx.nd.random_normal, model.py:292): Box-Muller over the counter hash;
  * effective seed = seed ^ (seed_ptr ? *seed_ptr : 0) */
 int mst_randn(int64_t n, float* out, uint64_t seed, const uint64_t* seed_ptr, uint32_t site, mst_stream_t stream);

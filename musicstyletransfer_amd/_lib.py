@@ -90,9 +90,9 @@ SIGNATURES = {
                                  vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),
     "mst_reparam_kl_bwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, c_f32, vp, vp, vp]),
-    "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, vp]),
+    "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, C.c_int, vp]),
     "mst_sigmoid_bce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, c_f32, C.c_int, vp, vp, vp, c_i64,
-                                  vp, c_i64, c_f32, vp]),
+                                  vp, c_i64, c_f32, C.c_int, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
                                 vp, C.c_int, vp]),
@@ -104,7 +104,8 @@ SIGNATURES = {
     "mst_zero": (C.c_int, [vp, c_i64, vp]),
     "mst_rng_advance": (C.c_int, [vp, vp]),
     "mst_randn": (C.c_int, [c_i64, vp, c_u64, vp, c_u32, vp]),
-    "mst_step_begin": (C.c_int, [vp, vp, c_f64, c_f64, c_f64, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32, vp]),
+    "mst_step_begin": (C.c_int, [vp, vp, c_f64, c_f64, c_f64, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32,
+                                 vp, c_i64, vp, c_i64, vp]),
 }
 
 

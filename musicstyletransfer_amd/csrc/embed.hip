@@ -65,22 +65,44 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(int64_t BT, int64_t 
   }
 }
 
-// dst[idx[b], d] += alpha * sum_{t<T} X[b, s_off + t, d]; grid = (cdiv(D,256), B)
+// dst[idx[b], d] += alpha * sum_{t<T} X[b, s_off + t, d].
+// grid = (chunks of GC_ROWS frames, B). A thread owns 8 consecutive columns (one 16-byte load per row) of every RG-th
+// row of the chunk; the RG row groups are combined through LDS and each column ends in ONE atomic per workgroup.
+// (One 2-byte load per lane and an atomic per 32 frames measured 15 us for 8.4 MB.)
+constexpr int GC_ROWS = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void group_colsum_kernel(int64_t T_len, int D, const T* __restrict__ X, int64_t ldx,
                                                            int64_t S_out, int64_t s_off,
                                                            const int32_t* __restrict__ idx, float* __restrict__ dst,
                                                            int64_t ldd, float alpha) {
-  // grid = (cdiv(D,256), B, chunks of 32 frames): each thread sums one column over its chunk, one atomic each
+  extern __shared__ float gc_part[];  // [RG][D]
+  const int cpr = D / 8;              // 16-byte chunks per row (host guarantees D % 8 == 0, cpr <= 256)
+  const int RG = 256 / cpr;           // row groups
   const int64_t b = blockIdx.y;
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const int64_t t0 = (int64_t)blockIdx.z * 32;
-  const int64_t t1 = t0 + 32 < T_len ? t0 + 32 : T_len;
-  const T* base = X + (b * S_out + s_off) * ldx + d;
-  float acc = 0.f;
-  for (int64_t t = t0; t < t1; ++t) acc += to_f32(base[t * ldx]);
-  atomicAdd(dst + (int64_t)idx[b] * ldd + d, alpha * acc);
+  const int tid = threadIdx.x, ch = tid % cpr, rg = tid / cpr;
+  const int64_t t0 = (int64_t)blockIdx.x * GC_ROWS;
+  const int64_t t1 = t0 + GC_ROWS < T_len ? t0 + GC_ROWS : T_len;
+  const T* base = X + (b * S_out + s_off) * ldx + ch * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (rg < RG) {
+#pragma unroll 4
+    for (int64_t t = t0 + rg; t < t1; t += RG) {
+      Pack8 p;
+      p.u = *reinterpret_cast<const u32x4*>(base + t * ldx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bits_to_f32<T>(p.h[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gc_part[rg * D + ch * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float v = 0.f;
+    for (int r = 0; r < RG; ++r) v += gc_part[r * D + d];
+    atomicAdd(dst + (int64_t)idx[b] * ldd + d, alpha * v);
+  }
 }
 
 __global__ __launch_bounds__(256) void mask_from_lengths_kernel(int64_t B, int64_t S, const int32_t* __restrict__ lens,
@@ -118,9 +140,12 @@ extern "C" int mst_group_colsum(int dtype, int64_t B, int64_t T, int64_t D, cons
                                 mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && T > 0 && D > 0 && X && idx && dst, "mst_group_colsum: bad argument");
   MST_CHECK_ARG(B <= 65535, "mst_group_colsum: B too large for grid.y");
+  MST_CHECK_ARG(D % 8 == 0 && D <= 2048 && ldx % 8 == 0 && ((uintptr_t)X % 16 == 0),
+                "mst_group_colsum: D must be a multiple of 8 (<= 2048), rows 16-byte aligned");
+  const size_t lds = sizeof(float) * (size_t)(256 / (D / 8)) * (size_t)D;
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) TT;
-    hipLaunchKernelGGL((group_colsum_kernel<TT>), dim3((unsigned)cdiv(D, 256), (unsigned)B, (unsigned)cdiv(T, 32)), dim3(256), 0, (hipStream_t)stream, T,
+    hipLaunchKernelGGL((group_colsum_kernel<TT>), dim3((unsigned)cdiv(T, GC_ROWS), (unsigned)B), dim3(256), lds, (hipStream_t)stream, T,
                        (int)D, (const TT*)X, ldx, S_out, s_off, idx, dst, ldd, alpha);
     MST_CHECK_LAUNCH("group_colsum_kernel");
     return MST_OK;

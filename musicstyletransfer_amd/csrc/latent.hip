@@ -18,6 +18,30 @@
 namespace mst {
 
 constexpr int LAT_THREADS = 1024;  // 16 waves: these kernels are B workgroups of dependent dot products (latency-bound)
+constexpr int OPW = 8;             // outputs a wave works on at once
+
+// out[j] = sum_d x[d] * W[j, d] for j < n_out: wave w takes outputs [w*U, w*U+U), then strides by n_waves*U;
+// `emit(j, value)` runs on lane 0
+template <int U, typename F>
+__device__ __forceinline__ void wave_dots(const float* x, int n_in, const float* __restrict__ W, int n_out, int wave, int n_waves,
+                                          int lane, F&& emit) {
+  for (int j0 = wave * U; j0 < n_out; j0 += n_waves * U) {
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.f;
+    for (int d = lane; d < n_in; d += 64) {
+      const float xv = x[d];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + u < n_out) acc[u] = fmaf(xv, W[(int64_t)(j0 + u) * n_in + d], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float v = wave_sum(acc[u]);
+      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, int Dd, const T* __restrict__ enc_out,
@@ -40,13 +64,9 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int d = tid; d < De; d += LAT_THREADS) h0[d] = to_f32(enc_out[b * enc_stride + d]);
   __syncthreads();
-  // one wave per output, lanes across the contraction (coalesced weight rows)
-  for (int j = wave; j < 2 * Z; j += NW) {
-    float acc = 0.f;
-    for (int d = lane; d < De; d += 64) acc += h0[d] * Wl[(int64_t)j * De + d];
-    acc = wave_sum(acc);
-    if (lane == 0) lat[j] = acc + bl[j];
-  }
+  // one wave per output, lanes across the contraction (coalesced weight rows); OPW outputs at a time so that their
+  // weight loads are all in flight together (one output at a time was eight dependent L2 round trips per wave)
+  wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
   __syncthreads();
   float klacc = 0.f;
   for (int i = tid; i < Z; i += LAT_THREADS) {
@@ -68,105 +88,137 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
     kl[b] = t;
   }
   const int c = classes[b];
-  for (int j = wave; j < Dd; j += NW) {
-    float acc = 0.f;
-    for (int i = lane; i < Z; i += 64) acc += zs[i] * Wh[(int64_t)j * Z + i];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
-      dec_in[b * dec_stride + j] = from_f32<T>(v);
-    }
-  }
+  wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, [&](int j, float acc) {
+    const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
+    dec_in[b * dec_stride + j] = from_f32<T>(v);
+  });
 }
 
-// per-sample backward vectors: t = alpha_d * g0, dz, dlat = [dmu | dsigma], dh0
+// per-sample backward vectors: t = alpha_d * g0, dz, dlat = [dmu | dsigma], dh0.
+// Columns of the weight matrices are contracted (consecutive threads read consecutive columns, coalesced); each
+// output is split over NP row parts that are combined through LDS, so a thread's dependent FMA chain is
+// rows / NP long instead of rows.
 template <typename T>
-__global__ __launch_bounds__(256) void latent_bwd_vec_kernel(int De, int Z, int Dd, const float* __restrict__ Wl,
-                                                             const float* __restrict__ eps,
-                                                             const float* __restrict__ Wh,
-                                                             const float* __restrict__ mu,
-                                                             const float* __restrict__ sigma,
-                                                             const T* __restrict__ d_dec_in, int64_t dec_stride,
-                                                             float alpha_d, float kl_weight, float gscale,
-                                                             float enc_scale, float* __restrict__ tvec, float* __restrict__ dlat,
-                                                             T* __restrict__ d_enc_out, int64_t denc_stride) {
+__global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int Z, int Dd, const float* __restrict__ Wl,
+                                                                     const float* __restrict__ eps,
+                                                                     const float* __restrict__ Wh,
+                                                                     const float* __restrict__ mu,
+                                                                     const float* __restrict__ sigma,
+                                                                     const T* __restrict__ d_dec_in, int64_t dec_stride,
+                                                                     float alpha_d, float kl_weight, float gscale,
+                                                                     float enc_scale, float* __restrict__ tvec,
+                                                                     float* __restrict__ dlat, T* __restrict__ d_enc_out,
+                                                                     int64_t denc_stride) {
   extern __shared__ float sm[];
-  float* t = sm;            // [Dd]
-  float* dl = sm + Dd;      // [2Z]
+  float* t = sm;             // [Dd]
+  float* dl = sm + Dd;       // [2Z]
+  float* part = dl + 2 * Z;  // [LAT_THREADS] partial sums
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
-  for (int j = tid; j < Dd; j += 256) {
+  for (int j = tid; j < Dd; j += LAT_THREADS) {
     const float v = alpha_d * to_f32(d_dec_in[b * dec_stride + j]);
     t[j] = v;
     tvec[b * Dd + j] = v;
   }
   __syncthreads();
-  // dz[i] = sum_j t[j] * Wh[j,i]: thread (i, part) sums a quarter of j (consecutive threads read consecutive
-  // Wh columns), the parts are combined through LDS
-  float* part = dl + 2 * Z;  // [4][max(Z, De)] scratch
-  const int nparts = 4;
-  for (int w = tid; w < Z * nparts; w += 256) {
-    const int i = w % Z, pt = w / Z;
-    float acc = 0.f;
-    for (int j = pt; j < Dd; j += nparts) acc += t[j] * Wh[(int64_t)j * Z + i];
-    part[pt * Z + i] = acc;
+  // dz[i] = sum_j t[j] * Wh[j,i]: thread (i, part) sums every np-th j
+  {
+    const int np = LAT_THREADS / Z > 0 ? LAT_THREADS / Z : 1;  // parts per output (16 at Z = 64)
+    for (int i0 = 0; i0 < Z; i0 += LAT_THREADS) {             // one round unless Z > 1024
+      const int i = i0 + tid % (Z < LAT_THREADS ? Z : LAT_THREADS), pt = tid / (Z < LAT_THREADS ? Z : LAT_THREADS);
+      float acc = 0.f;
+      if (i < Z && pt < np)
+        for (int j = pt; j < Dd; j += np) acc = fmaf(t[j], Wh[(int64_t)j * Z + i], acc);
+      part[tid] = acc;
+      __syncthreads();
+      if (tid < Z - i0 && tid < LAT_THREADS) {
+        const int zc = Z < LAT_THREADS ? Z : LAT_THREADS;
+        float a = 0.f;
+        for (int p2 = 0; p2 < np && p2 * zc + tid < LAT_THREADS; ++p2) a += part[p2 * zc + tid];
+        const int ii = i0 + tid;
+        const float m = mu[b * Z + ii], s2 = sigma[b * Z + ii];
+        // gscale: loss scale of everything upstream of here (the encoder); enc_scale = gscale / (loss scale the
+        // incoming decoder-side gradient carries). Both are 1 unless fp16 loss scaling is on.
+        const float dm = kl_weight * gscale * m + enc_scale * a;
+        const float ds = kl_weight * gscale * (s2 - 1.f / s2) + enc_scale * eps[b * Z + ii] * a;
+        dl[ii] = dm;
+        dl[Z + ii] = ds;
+        dlat[b * 2 * Z + ii] = dm;
+        dlat[b * 2 * Z + Z + ii] = ds;
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  for (int i = tid; i < Z; i += 256) {
-    const float acc = (part[i] + part[Z + i]) + (part[2 * Z + i] + part[3 * Z + i]);
-    const float m = mu[b * Z + i], s = sigma[b * Z + i];
-    // gscale: loss scale of everything upstream of here (the encoder); enc_scale = gscale / (loss scale the
-    // incoming decoder-side gradient carries). Both are 1 unless fp16 loss scaling is on.
-    const float dm = kl_weight * gscale * m + enc_scale * acc;
-    const float ds = kl_weight * gscale * (s - 1.f / s) + enc_scale * eps[b * Z + i] * acc;
-    dl[i] = dm;
-    dl[Z + i] = ds;
-    dlat[b * 2 * Z + i] = dm;
-    dlat[b * 2 * Z + Z + i] = ds;
-  }
-  __syncthreads();
-  // dh0[d] = sum_j dlat[j] * Wl[j,d]
-  for (int d = tid; d < De; d += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < 2 * Z; ++j) acc += dl[j] * Wl[(int64_t)j * De + d];
-    d_enc_out[b * denc_stride + d] = from_f32<T>(acc);
+  // dh0[d] = sum_j dlat[j] * Wl[j,d], same split
+  {
+    const int dc = De < LAT_THREADS ? De : LAT_THREADS;
+    const int np = LAT_THREADS / dc > 0 ? LAT_THREADS / dc : 1;  // 4 at De = 256
+    for (int d0 = 0; d0 < De; d0 += LAT_THREADS) {
+      const int d = d0 + tid % dc, pt = tid / dc;
+      float acc = 0.f;
+      if (d < De && pt < np)
+        for (int j = pt; j < 2 * Z; j += np) acc = fmaf(dl[j], Wl[(int64_t)j * De + d], acc);
+      part[tid] = acc;
+      __syncthreads();
+      if (tid < dc && d0 + tid < De) {
+        float a = 0.f;
+        for (int p2 = 0; p2 < np; ++p2) a += part[p2 * dc + tid];
+        d_enc_out[b * denc_stride + d0 + tid] = from_f32<T>(a);
+      }
+      __syncthreads();
+    }
   }
 }
 
-// parameter gradients: out[j, i] += sum_b L[b, j] * R[b, i]; obias[j] += sum_b L[b, j]
+// parameter gradients: out[j, i] += sum_b L[b, j] * R[b, i]; obias[j] += sum_b L[b, j]. One output per thread, the
+// batch loop unrolled 8-fold on independent accumulators (the loop is load-latency bound).
 template <typename RT>
-__global__ __launch_bounds__(256) void batch_outer_kernel(int64_t B, int J, int I, const float* __restrict__ L,
-                                                          const RT* __restrict__ R, int64_t r_stride,
-                                                          float* __restrict__ out, float* __restrict__ obias) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void batch_outer(int64_t idx, int64_t B, int J, int I, const float* __restrict__ L,
+                                            const RT* __restrict__ R, int64_t r_stride, float* __restrict__ out,
+                                            float* __restrict__ obias) {
   if (idx < (int64_t)J * I) {
     const int j = (int)(idx / I), i = (int)(idx % I);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // independent chains: the loop is load-latency bound
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
     int64_t b = 0;
-    for (; b + 4 <= B; b += 4) {
-      a0 += L[(b + 0) * J + j] * to_f32(R[(b + 0) * r_stride + i]);
-      a1 += L[(b + 1) * J + j] * to_f32(R[(b + 1) * r_stride + i]);
-      a2 += L[(b + 2) * J + j] * to_f32(R[(b + 2) * r_stride + i]);
-      a3 += L[(b + 3) * J + j] * to_f32(R[(b + 3) * r_stride + i]);
+    for (; b + 8 <= B; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = fmaf(L[(b + u) * J + j], to_f32(R[(b + u) * r_stride + i]), a[u]);
     }
-    for (; b < B; ++b) a0 += L[b * J + j] * to_f32(R[b * r_stride + i]);
-    out[idx] += (a0 + a1) + (a2 + a3);
+    for (; b < B; ++b) a[0] = fmaf(L[b * J + j], to_f32(R[b * r_stride + i]), a[0]);
+    out[idx] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   if (obias && idx < J) {
-    float acc = 0.f;
-    for (int64_t b = 0; b < B; ++b) acc += L[b * J + idx];
-    obias[idx] += acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t b = 0;
+    for (; b + 4 <= B; b += 4) {
+      a0 += L[(b + 0) * J + idx]; a1 += L[(b + 1) * J + idx]; a2 += L[(b + 2) * J + idx]; a3 += L[(b + 3) * J + idx];
+    }
+    for (; b < B; ++b) a0 += L[b * J + idx];
+    obias[idx] += (a0 + a1) + (a2 + a3);
   }
 }
 
-__global__ __launch_bounds__(256) void class_scatter_kernel(int64_t B, int J, const float* __restrict__ L,
-                                                            const int32_t* __restrict__ classes,
-                                                            float* __restrict__ dcls, int64_t ld) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx < B * J) {
-    const int64_t b = idx / J;
-    const int j = (int)(idx % J);
-    atomicAdd(dcls + (int64_t)classes[b] * ld + j, L[idx]);
+// ONE launch for the three parameter-gradient pieces of the latent block (they were three ~5-14 us launches):
+// blocks [0, n_wl): dWl[2Z, De] += dlat^T h0, dbl; blocks [n_wl, n_wl + n_wh): dWh[Dd, Z] += t^T z, dbh;
+// the rest: dcls_d[class_b, :] += t[b, :]
+template <typename T>
+__global__ __launch_bounds__(256) void latent_param_grads_kernel(int64_t B, int De, int Z, int Dd, const float* __restrict__ dlat,
+                                                                 const T* __restrict__ enc_out, int64_t enc_stride,
+                                                                 const float* __restrict__ tvec, const float* __restrict__ z,
+                                                                 const int32_t* __restrict__ classes, float* __restrict__ dWl,
+                                                                 float* __restrict__ dbl, float* __restrict__ dWh,
+                                                                 float* __restrict__ dbh, float* __restrict__ dcls, int64_t ld_cls,
+                                                                 int n_wl, int n_wh) {
+  const int blk = blockIdx.x;
+  if (blk < n_wl) {
+    batch_outer<T>((int64_t)blk * 256 + threadIdx.x, B, 2 * Z, De, dlat, enc_out, enc_stride, dWl, dbl);
+  } else if (blk < n_wl + n_wh) {
+    batch_outer<float>((int64_t)(blk - n_wl) * 256 + threadIdx.x, B, Dd, Z, tvec, z, Z, dWh, dbh);
+  } else {
+    const int64_t idx = (int64_t)(blk - n_wl - n_wh) * 256 + threadIdx.x;
+    if (idx < B * Dd) atomicAdd(dcls + (int64_t)classes[idx / Dd] * ld_cls + idx % Dd, tvec[idx]);
   }
 }
 
@@ -208,26 +260,19 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   hipStream_t s = (hipStream_t)stream;
   float* tvec = scratch;            // [B, Dd]
   float* dlat = scratch + B * Dd;   // [B, 2Z]
-  const size_t lds = sizeof(float) * (Dd + 2 * Z + 4 * Z);
-  int rc = dispatch_act(dtype, [&](auto tag) -> int {
+  MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd: latent size above %d", LAT_THREADS);
+  const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
+  const int n_wl = (int)cdiv(2 * Z * De, 256), n_wh = (int)cdiv(Dd * Z, 256), n_cls = (int)cdiv(B * Dd, 256);
+  return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(256), lds, s, (int)De, (int)Z, (int)Dd, Wl, eps,
-                       Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec, dlat,
-                       (T*)d_enc_out, denc_sample_stride);
+    hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
+                       eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
+                       dlat, (T*)d_enc_out, denc_sample_stride);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
-    // dWl[2Z, De] += dlat^T · h0 ; dbl += sum_b dlat
-    hipLaunchKernelGGL((batch_outer_kernel<T>), dim3((unsigned)cdiv(2 * Z * De, 256)), dim3(256), 0, s, B, (int)(2 * Z),
-                       (int)De, dlat, (const T*)enc_out, enc_sample_stride, dWl, dbl);
-    MST_CHECK_LAUNCH("batch_outer_kernel(Wl)");
+    hipLaunchKernelGGL((latent_param_grads_kernel<T>), dim3((unsigned)(n_wl + n_wh + n_cls)), dim3(256), 0, s, B, (int)De, (int)Z,
+                       (int)Dd, dlat, (const T*)enc_out, enc_sample_stride, tvec, z, classes, dWl, dbl, dWh, dbh, dcls_d, ld_cls,
+                       n_wl, n_wh);
+    MST_CHECK_LAUNCH("latent_param_grads_kernel");
     return MST_OK;
   });
-  if (rc) return rc;
-  // dWh[Dd, Z] += t^T · z ; dbh += sum_b t
-  hipLaunchKernelGGL((batch_outer_kernel<float>), dim3((unsigned)cdiv(Dd * Z, 256)), dim3(256), 0, s, B, (int)Dd, (int)Z, tvec,
-                     z, Z, dWh, dbh);
-  MST_CHECK_LAUNCH("batch_outer_kernel(Wh)");
-  hipLaunchKernelGGL(class_scatter_kernel, dim3((unsigned)cdiv(B * Dd, 256)), dim3(256), 0, s, B, (int)Dd, tvec, classes,
-                     dcls_d, ld_cls);
-  MST_CHECK_LAUNCH("class_scatter_kernel");
-  return MST_OK;
 }

@@ -54,7 +54,8 @@ __device__ __forceinline__ uint64_t step_seed(uint64_t base, uint64_t step) {
 __global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1,
                                                          double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
                                                          const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
-                                                         int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d) {
+                                                         int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d,
+                                                         u32x4* zero_a, int64_t n16_a, u32x4* zero_b, int64_t n16_b) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
   uint64_t step = 0, s = 0;
   if (rng_state) {
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(256) void step_begin_kernel(uint64_t* rng_state, in
     for (int64_t i = gid; i < B * Se; i += gsz) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
   if (mask_d)
     for (int64_t i = gid; i < B * Sd; i += gsz) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  for (int64_t i = gid; i < n16_a; i += gsz) zero_a[i] = z4;
+  for (int64_t i = gid; i < n16_b; i += gsz) zero_b[i] = z4;
   if (rng_state) {
     __syncthreads();  // every thread of this workgroup has read the old counter
     if (threadIdx.x == 0) {
@@ -104,16 +108,24 @@ using namespace mst;
 
 extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2, float* eps_out,
                               int64_t n_eps, uint32_t eps_site, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
-                              int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, mst_stream_t stream) {
+                              int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, void* zero_a, int64_t zero_a_bytes,
+                              void* zero_b, int64_t zero_b_bytes, mst_stream_t stream) {
+  MST_CHECK_ARG((!zero_a || ((uintptr_t)zero_a % 16 == 0 && zero_a_bytes % 16 == 0)) &&
+                    (!zero_b || ((uintptr_t)zero_b % 16 == 0 && zero_b_bytes % 16 == 0)),
+                "mst_step_begin: zero buffers must be 16-byte aligned with sizes that are multiples of 16");
   MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
   MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
   int64_t work = n_eps / 2;
   if (mask_e && B * Se > work) work = B * Se;
   if (mask_d && B * Sd > work) work = B * Sd;
+  const int64_t n16_a = zero_a ? zero_a_bytes / 16 : 0, n16_b = zero_b ? zero_b_bytes / 16 : 0;
+  if (n16_a > work) work = n16_a;
+  if (n16_b > work) work = n16_b;
   int64_t grid = cdiv(work > 0 ? work : 1, 256 * 4);
-  if (grid > 128) grid = 128;
+  if (grid > 512) grid = 512;
   hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
-                     eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d);
+                     eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
+                     n16_b);
   MST_CHECK_LAUNCH("step_begin_kernel");
   return MST_OK;
 }

@@ -308,7 +308,10 @@ class StepPlan:
         self.x0_d = act(self.Md, Dd)
         self.dec = layers(cfg.d_layers, self.Md, Dd, cfg.d_heads, Sd)
         self.mu, self.sigma, self.z = torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32)
-        self.kl, self.recon, self.total = torch.zeros(B, **f32), torch.zeros(B, **f32), torch.zeros(B, **f32)
+        self.kl, self.total = torch.zeros(B, **f32), torch.zeros(B, **f32)
+        # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B)
+        self._recon_buf = torch.zeros((B + 3) // 4 * 4, **f32)
+        self.recon = self._recon_buf[:B]
         self.metric_acc = torch.zeros(3, **f32)  # [sum kl, sum total, count]  (trainer.py:115-116)
         self.logits = act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
@@ -471,7 +474,8 @@ class StepPlan:
         o.step_begin(rng_state=self.rng_state if need_rng else None,
                      adam_state=st.step_state if self._tick_adam else None, lr=self.lr, beta1=self.opt["beta1"],
                      beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None, lens=self.seq_lens,
-                     mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1)
+                     mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
+                     zero_a=self._recon_buf, zero_b=st.g if self._tick_adam else None)
         # ---- encoder input (model.py:81-91, transformer.py:270)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("encoder.embedding.weight"), self.pos_e, self.x0_e.view(B, Se, -1), 0, sq_e,
@@ -508,10 +512,11 @@ class StepPlan:
         dl = self.dlogits if with_grad else None
         if cfg.kind == "token":
             o.softmax_ce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, probs=self.probs, dlogits=dl,
-                         gscale=self.gscale)
+                         gscale=self.gscale, pre_zeroed=True)
         else:
             o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
-                          downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale)
+                          downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale,
+                          pre_zeroed=True)
         o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
 
     # ------------------------------------------------------------------------------ backward
@@ -625,7 +630,7 @@ class StepPlan:
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
-        o.zero(st.g)
+        # (the gradient bucket was cleared by forward()'s step_begin launch)
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))

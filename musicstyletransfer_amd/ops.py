@@ -186,17 +186,17 @@ def reparam_kl_bwd(mu, sigma, eps, dz, kl_weight, dmu, dsigma):
 
 
 # --------------------------------------------------------------------------- loss heads
-def softmax_ce(logits, labels, loss, B, T, V, probs=None, dlogits=None, gscale=1.0):
+def softmax_ce(logits, labels, loss, B, T, V, probs=None, dlogits=None, gscale=1.0, pre_zeroed=False):
     call("mst_softmax_ce", dt(logits), B, T, V, ptr(logits), ld(logits), ptr(labels), ptr(loss), ptr(probs),
          (ld(probs) if probs is not None else 0), ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale,
-         stream())
+         1 if pre_zeroed else 0, stream())
 
 
 def sigmoid_bce(logits, labels, loss, B, T, P, label_smoothing=0.0, downweight=False, npos=None, probs=None,
-                dlogits=None, gscale=1.0):
+                dlogits=None, gscale=1.0, pre_zeroed=False):
     call("mst_sigmoid_bce", dt(logits), B, T, P, ptr(logits), ld(logits), ptr(labels), label_smoothing,
          1 if downweight else 0, ptr(npos), ptr(loss), ptr(probs), (ld(probs) if probs is not None else 0),
-         ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale, stream())
+         ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale, 1 if pre_zeroed else 0, stream())
 
 
 def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None):
@@ -239,12 +239,13 @@ def randn(out, seed=0, seed_ptr=None, site=0):
 
 
 def step_begin(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, lens=None,
-               mask_e=None, add_e=0, mask_d=None, add_d=1):
+               mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None):
     B = lens.shape[0] if lens is not None else 0
+    nbytes = lambda t: t.numel() * t.element_size() if t is not None else 0
     call("mst_step_begin", ptr(rng_state), ptr(adam_state), lr, beta1, beta2, ptr(eps_out),
          (eps_out.numel() if eps_out is not None else 0), eps_site, ptr(lens), B, ptr(mask_e),
          (mask_e.shape[1] if mask_e is not None else 0), add_e, ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d,
-         stream())
+         ptr(zero_a), nbytes(zero_a), ptr(zero_b), nbytes(zero_b), stream())
 
 
 def selftest():

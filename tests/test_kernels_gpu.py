@@ -386,6 +386,20 @@ def test_embed_fwd_bwd(gpu):
     close(dcls, rc, 1e-4, 1e-3, "dcls")
 
 
+@pytest.mark.parametrize("B,T,D,s_off", [(5, 100, 256, 0), (3, 7, 40, 1), (64, 256, 128, 0)])
+def test_group_colsum(gpu, B, T, D, s_off):
+    """class-embedding gradient: per-sample sums over frames, scattered to the sample's class row"""
+    o = ops()
+    S_out = T + s_off
+    X = rnd((B, S_out, D), gpu, seed=60)
+    idx = torch.tensor([(7 * i) % 4 for i in range(B)], dtype=torch.int32, device=gpu)
+    dst = torch.zeros(4, D, device=gpu)
+    o.group_colsum(X, T, D, s_off, idx, dst, 1.5)
+    torch.cuda.synchronize()
+    want = torch.zeros(4, D, device=gpu).index_add_(0, idx.long(), 1.5 * X[:, s_off:].float().sum(1))
+    close(dst, want, 1e-5, 1e-3, "group_colsum")
+
+
 # ------------------------------------------------------------------------------------------ latent
 def test_latent_fwd_bwd(gpu):
     o = ops()

@@ -12,6 +12,7 @@ def run(kind, dims, B, T, seed, dtype=torch.bfloat16):
     store = E.ParamStore(ecfg, gpu, dtype, params_np=params)
     plan = E.StepPlan(store, B, T, lr=1e-3, want_probs=True)
     plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
+    plan._tick_adam = True  # forward() then clears the gradient bucket (and advances the Adam step counter)
     plan.forward(); plan.losses(True); plan.backward(); torch.cuda.synchronize()
     g = store.to_numpy("g")
     print(f"--- {kind} dims={dims} B={B} T={T} gscale={plan.gscale}")
