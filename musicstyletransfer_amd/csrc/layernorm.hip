@@ -9,11 +9,12 @@
 // fully coalesced 512-byte wave access), all statistics in fp32 registers, two-pass variance.
 // Backward also produces the dropout-masked copy of dx that the producing GEMM's dgrad/wgrad
 // consume when dropout is enabled (mask regenerated from the counter RNG, never stored).
+#include <type_traits>
 #include "common.hpp"
 
 namespace mst {
 
-constexpr int LN_MAXV = 4;  // 4 elements * 64 lanes * LN_MAXV = D up to 1024
+constexpr int LN_MAXV = 4;  // 4 elements * 64 lanes * LN_MAXV = D up to 1024 (kernel template parameter NV <= LN_MAXV)
 
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float v[4]) {
@@ -31,7 +32,10 @@ __device__ __forceinline__ void store4(T* p, const float v[4]) {
   *reinterpret_cast<u32x2*>(p) = o;
 }
 
-template <typename T>
+// NV = 64-lane vector groups per row (D <= 256 NV): 1 for D <= 256, 2 for <= 512, 4 for <= 1024. R = rows a wave works
+// on at once: all R rows' loads are issued before the first reduction, so a wave pays one memory round trip per R
+// rows instead of one per row (the kernels are pure streaming with 2-4 rows per wave at configs[1]).
+template <typename T, int NV, int R>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t M, int D, const T* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
@@ -42,47 +46,70 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t M, int D, co
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int nvec = D / 4;
-  for (int64_t m = wave_global; m < M; m += nwaves) {
-    float v[LN_MAXV][4];
-    float s = 0.f;
+  const float inv_d = 1.f / (float)D;
+  for (int64_t m0 = wave_global; m0 < M; m0 += nwaves * R) {
+    float v[R][NV][4];
+    float s[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + i * 64;
-      if (c < nvec) {
-        load4<T>(x + m * ldx + c * 4, v[i]);
-        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    for (int r = 0; r < R; ++r) {
+      const int64_t m = m0 + r * nwaves;
+      s[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[r][i][e] = 0.f;
+        if (m < M && c < nvec) {
+          load4<T>(x + m * ldx + c * 4, v[r][i]);
+          s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        }
       }
     }
-    const float mean = wave_sum(s) / (float)D;
-    float ss = 0.f;
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + i * 64;
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (lane + i * 64 < nvec) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean[r]; ss += d * d; }
+        }
+      }
+      s[r] = ss;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = 1.f / sqrtf(wave_sum(s[r]) * inv_d + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
       if (c < nvec) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; ss += d * d; }
+        for (int r = 0; r < R; ++r) {
+          const int64_t m = m0 + r * nwaves;
+          if (m < M) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * g[e] + b[e];
+            store4<T>(y + m * ldy + c * 4, o);
+          }
+        }
       }
     }
-    const float var = wave_sum(ss) / (float)D;
-    const float rstd = 1.f / sqrtf(var + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + i * 64;
-      if (c < nvec) {
-        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-        f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        store4<T>(y + m * ldy + c * 4, o);
-      }
+    for (int r = 0; r < R; ++r) {
+      const int64_t m = m0 + r * nwaves;
+      if (lane == 0 && m < M) { mean_out[m * row_id_stride] = mean[r]; rstd_out[m * row_id_stride] = rstd[r]; }
     }
-    if (lane == 0) { mean_out[m * row_id_stride] = mean; rstd_out[m * row_id_stride] = rstd; }
   }
 }
 
 // mask_mode: 0 = dx only; 1 = dx and dxm = dx * keep/(1-p); 2 = dx <- dx * (1 + keep/(1-p))
-template <typename T>
+template <typename T, int NV, int R>
 __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, const T* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
@@ -105,65 +132,90 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
   const int64_t wave_global = (int64_t)blockIdx.x * NW + wave;
   const int64_t nwaves = (int64_t)gridDim.x * NW;
   const int nvec = D / 4;
-  const float inv_keep = dropout_inv_keep(p);
-  float dg[LN_MAXV][4], db[LN_MAXV][4];
+  const float inv_keep = dropout_inv_keep(p), inv_d = 1.f / (float)D;
+  float dg[NV][4], db[NV][4], gm[NV][4];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+    if (c < nvec) g4 = *reinterpret_cast<const f32x4*>(gamma + c * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gm[i][e] = g4[e]; }
+  }
 
-  for (int64_t m = wave_global; m < M; m += nwaves) {
+  for (int64_t m0 = wave_global; m0 < M; m0 += nwaves * R) {
     // rows may be a strided subset of the forward's rows (e.g. position 0 of every sample): statistics and the
     // dropout counter are indexed by the forward's row id
-    const int64_t rid = m * row_id_stride;
-    const float mean = mean_in[rid], rstd = rstd_in[rid];
-    float xh[LN_MAXV][4], g[LN_MAXV][4];
-    float s1 = 0.f, s2 = 0.f;
+    float xh[R][NV][4], g[R][NV][4], mean[R], rstd[R], s1[R], s2[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + i * 64;
-      if (c < nvec) {
-        float xv[4], dv[4];
-        load4<T>(x + m * ldx + c * 4, xv);
-        load4<T>(dy + m * ldy + c * 4, dv);
-        f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+    for (int r = 0; r < R; ++r) {
+      const int64_t m = m0 + r * nwaves;
+      const bool live = m < M;
+      mean[r] = live ? mean_in[m * row_id_stride] : 0.f;
+      rstd[r] = live ? rstd_in[m * row_id_stride] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][e] = (xv[e] - mean) * rstd;
-          g[i][e] = dv[e] * gm[e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
-          dg[i][e] += dv[e] * xh[i][e];
-          db[i][e] += dv[e];
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xh[r][i][e] = 0.f; g[r][i][e] = 0.f; }
+        if (live && c < nvec) {
+          load4<T>(x + m * ldx + c * 4, xh[r][i]);   // raw x for now
+          load4<T>(dy + m * ldy + c * 4, g[r][i]);   // raw dy for now
         }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + i * 64;
-      if (c < nvec) {
-        float o[4], om[4];
-        uint32_t keep4 = 0xFu;  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
-        if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(rid * D + c * 4) >> 2, p);
+    for (int r = 0; r < R; ++r) {
+      s1[r] = 0.f; s2[r] = 0.f;
+      const bool live = m0 + r * nwaves < M;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-          if (mask_mode != 0) {
-            float k = (p > 0.f) ? (((keep4 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
-            if (mask_mode == 1) om[e] = o[e] * k; else o[e] = o[e] * (1.f + k);
+      for (int i = 0; i < NV; ++i) {
+        if (live && lane + i * 64 < nvec) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xhv = (xh[r][i][e] - mean[r]) * rstd[r], dv = g[r][i][e], gv = dv * gm[i][e];
+            xh[r][i][e] = xhv;
+            g[r][i][e] = gv;
+            s1[r] += gv;
+            s2[r] += gv * xhv;
+            dg[i][e] += dv * xhv;
+            db[i][e] += dv;
           }
         }
-        store4<T>(dx + m * ld_dx + c * 4, o);
-        if (mask_mode == 1) store4<T>(dxm + m * ld_dxm + c * 4, om);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { s1[r] = wave_sum(s1[r]) * inv_d; s2[r] = wave_sum(s2[r]) * inv_d; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t m = m0 + r * nwaves;
+      if (m >= M) continue;
+      const int64_t rid = m * row_id_stride;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+          float o[4], om[4];
+          uint32_t keep4 = 0xFu;  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
+          if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(rid * D + c * 4) >> 2, p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = rstd[r] * (g[r][i][e] - s1[r] - xh[r][i][e] * s2[r]);
+            if (mask_mode != 0) {
+              const float k = (p > 0.f) ? (((keep4 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
+              if (mask_mode == 1) om[e] = o[e] * k; else o[e] = o[e] * (1.f + k);
+            }
+          }
+          store4<T>(dx + m * ld_dx + c * 4, o);
+          if (mask_mode == 1) store4<T>(dxm + m * ld_dxm + c * 4, om);
+        }
       }
     }
   }
   // cross-wave reduction of the parameter gradients, then one atomic per column per workgroup
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    int c = lane + i * 64;
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
     if (c < nvec) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -179,6 +231,14 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
     atomicAdd(dgamma + d, a);
     atomicAdd(dbeta + d, b);
   }
+}
+
+// NV by row width, R by how many rows each wave gets
+template <typename F>
+static int ln_dispatch_nv(int64_t D, F&& f) {
+  if (D <= 256) return f(std::integral_constant<int, 1>());
+  if (D <= 512) return f(std::integral_constant<int, 2>());
+  return f(std::integral_constant<int, 4>());
 }
 
 }  // namespace mst
@@ -200,12 +260,20 @@ extern "C" int mst_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x,
   if (rc) return rc;
   MST_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mst_layernorm_fwd: null pointer");
   const unsigned grid = (unsigned)(cdiv(M, 4) < 2048 ? cdiv(M, 4) : 2048);
+  const bool multi = M > (int64_t)grid * 4;  // more than one row per wave: work on two at a time
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
-                       (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd, row_id_stride > 0 ? row_id_stride : 1);
-    MST_CHECK_LAUNCH("layernorm_fwd_kernel");
-    return MST_OK;
+    return ln_dispatch_nv(D, [&](auto nv) -> int {
+      constexpr int NV = decltype(nv)::value;
+      if (multi)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
+                           (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd, row_id_stride > 0 ? row_id_stride : 1);
+      else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, (int)D,
+                           (const T*)x, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd, row_id_stride > 0 ? row_id_stride : 1);
+      MST_CHECK_LAUNCH("layernorm_fwd_kernel");
+      return MST_OK;
+    });
   });
 }
 
@@ -228,13 +296,24 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
   if (nw < 1) nw = 1;
   const unsigned grid = (unsigned)(cdiv(M, 4 * nw) < 256 ? cdiv(M, 4 * nw) : 256);
   const size_t lds = (size_t)2 * nw * D * sizeof(float);
+  const int64_t rows_per_wave = cdiv(M, (int64_t)grid * nw);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
-                       (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
-                       dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
-                       row_id_stride > 0 ? row_id_stride : 1);
-    MST_CHECK_LAUNCH("layernorm_bwd_kernel");
-    return MST_OK;
+    return ln_dispatch_nv(D, [&](auto nv) -> int {
+      constexpr int NV = decltype(nv)::value;
+      constexpr int RB = NV == 1 ? 2 : 1;  // rows in flight per wave, bounded by the 128 registers of a 1024-thread block
+      if (rows_per_wave > 1 && RB > 1)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV, RB>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
+                           (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
+                           dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
+                           row_id_stride > 0 ? row_id_stride : 1);
+      else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV, 1>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
+                           (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
+                           dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
+                           row_id_stride > 0 ? row_id_stride : 1);
+      MST_CHECK_LAUNCH("layernorm_bwd_kernel");
+      return MST_OK;
+    });
   });
 }
