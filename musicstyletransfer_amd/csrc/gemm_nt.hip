@@ -320,6 +320,10 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     const int64_t big_tiles = cdiv(a.M, 128) * cdiv(a.N, 128);
+    // Tile shape is second-order here: 64x64, 128x64, 64x128 and 128x128 tiles measured within 5 % of each other on
+    // every GEMM of the step (time = 4.7 us fixed + 1.7 us per 8.4 MB of output + 4.2 us per 2.1 GFLOP: with K <= 1024
+    // a tile's main loop is 2-16 stages of one exposed L2 round trip each, at 12 TB/s of L2->LDS traffic for the
+    // K = 1024 shapes). 128x128 is used where it still leaves >= 1.5 workgroups per CU.
     if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
