@@ -104,8 +104,8 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t rpg, int64_t str
   return rpg > 0 ? (m / rpg) * stride + off + (m % rpg) : m;
 }
 
-// Counter-based dropout RNG: one 64-bit mix per element → keep decision.
-// Both forward and backward regenerate the mask from (seed, site, index); nothing is stored.
+// Counter-based RNG. dropout_hash (one 64-bit mix per draw) feeds the Gaussian eps; the dropout masks use the cheaper
+// 32-bit mix below. Forward and backward regenerate a mask from (seed, site, index); nothing is stored.
 __host__ __device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint32_t site, uint64_t idx) {
   uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx * 0xD1B54A32D192ED03ull);
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
@@ -113,23 +113,34 @@ __host__ __device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint32_
   x ^= x >> 32;
   return (uint32_t)x;
 }
-// Four keep decisions from ONE 64-bit mix (16 bits each): element idx uses bit (idx & 3) of the word drawn
-// for idx >> 2. keep iff field >= thr with thr = floor(p * 65536); the inverted-dropout scale uses the exact keep
-// probability (65536 - thr) / 65536 so the mask is unbiased.
+// Dropout keep decisions: TWO per 32-bit word (16 bits each), i.e. two words per group of four elements — element idx
+// uses field (idx & 1) of word idx >> 1; keep iff field >= thr with thr = floor(p * 65536); the inverted-dropout scale
+// uses the exact keep probability (65536 - thr) / 65536 (p = 0.2 -> 1.25000), so the mask is unbiased. A word is a
+// multiplicative scramble of the index, the launch key, and one multiply-xorshift round (7 VALU per two elements; the
+// former 64-bit two-round mix cost ~30 per four and was a quarter of the FFN1 epilogue).
+// The per-launch key folds the 64-bit step seed and the site, so (seed, site, index) still identifies an element.
 __host__ __device__ __forceinline__ uint32_t dropout_thr(float p) { return (uint32_t)(p * 65536.0f); }
 __host__ __device__ __forceinline__ float dropout_inv_keep(float p) {
   return p > 0.f ? 65536.0f / (65536.0f - (float)dropout_thr(p)) : 1.f;
 }
+__host__ __device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t site) {
+  const uint64_t k = (seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1))) * 0xD6E8FEB86659FD93ull;
+  return (uint32_t)(k >> 32) ^ (uint32_t)k;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint64_t idx2) {
+  uint32_t x = ((uint32_t)idx2 * 0x9E3779B1u) ^ key ^ ((uint32_t)(idx2 >> 32) * 0x85EBCA6Bu);
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  return x;
+}
+// bit e of the result = keep decision of element 4*idx4 + e
+__host__ __device__ __forceinline__ uint32_t dropout_keep4k(uint32_t key, uint64_t idx4, uint32_t thr) {
+  const uint32_t x0 = dropout_word(key, 2 * idx4), x1 = dropout_word(key, 2 * idx4 + 1);
+  return (uint32_t)((x0 & 0xFFFFu) >= thr) | ((uint32_t)((x0 >> 16) >= thr) << 1) | ((uint32_t)((x1 & 0xFFFFu) >= thr) << 2) |
+         ((uint32_t)((x1 >> 16) >= thr) << 3);
+}
 __host__ __device__ __forceinline__ uint32_t dropout_keep4(uint64_t seed, uint32_t site, uint64_t idx4, float p) {
-  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx4 * 0xD1B54A32D192ED03ull);
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  const uint32_t thr = dropout_thr(p);
-  uint32_t m = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) m |= (uint32_t)(((uint32_t)(x >> (16 * e)) & 0xFFFFu) >= thr) << e;
-  return m;
+  return dropout_keep4k(dropout_key(seed, site), idx4, dropout_thr(p));
 }
 __host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, float p) {
   return (dropout_keep4(seed, site, idx >> 2, p) >> (idx & 3)) & 1u;

@@ -40,6 +40,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const int n_store = (int)(((a.N + 3) / 4 * 4) < a.ldc ? ((a.N + 3) / 4 * 4) : a.ldc);
   const float inv_keep = dropout_inv_keep(a.dropout_p);
   const uint64_t dseed = a.dropout_seed ^ ((a.dropout_p > 0.f && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
+  const uint32_t dkey = dropout_key(dseed, a.dropout_site), dthr = dropout_thr(a.dropout_p);
   constexpr int LDS_F = BN + 4;   // fp32 row stride: rows stay 16-byte aligned, banks are spread
   constexpr int CPR = BN / 8;     // 8-column chunks per tile row
   static_assert(NT % CPR == 0, "a thread must keep its column chunk across rows");
@@ -52,7 +53,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
                     (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
   const bool has_drop = a.dropout_p > 0.f;
   const bool has_rowops = a.rowadd || a.grpadd;
-  const float relu_floor = (a.act == MST_ACT_RELU) ? 0.f : -INFINITY;
+  const bool relu = a.act == MST_ACT_RELU;
   const float alpha = a.alpha;
   float bias8[8];
 #pragma unroll
@@ -78,44 +79,31 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8 + 4);
         float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        float res[8], gt[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { res[e] = 0.f; gt[e] = 1.f; }
-        if (resid) {
-          const T* rp = resid + m * a.ldr + nc;
-          if (!edge) {
-            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) res[e] = bits_to_f32<T>(p8.h[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (nc + e < a.ldr) res[e] = to_f32(rp[e]);
-          }
-        }
-        if (gate) {
-          const T* gp = gate + m * a.ldg + nc;
-          if (!edge) {
-            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gt[e] = bits_to_f32<T>(p8.h[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (nc + e < a.ldg) gt[e] = to_f32(gp[e]);
-          }
-        }
+        // Optional features are wave-uniform branches per 8-column chunk (a branch costs less than 8 neutral
+        // operations; per-ELEMENT tests in accumulator layout had made the kernel issue-bound).
         // t = alpha * (acc + bias [+ class row]) -> ReLU
         if (has_rowops && a.grpadd) {
           const float* ga_row = a.grpadd + (int64_t)a.grp_index[m / a.rowadd_period] * a.ldga + nc;
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ga_row[e];
         }
+        if (a.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = fmaxf((t[e] + bias8[e]) * alpha, relu_floor);
+          for (int e = 0; e < 8; ++e) t[e] += bias8[e];
+        }
+        if (alpha != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] *= alpha;
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
+        }
         if (has_drop || a.self_resid) {
           uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
           if (has_drop) {
             const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
-            keep8 = dropout_keep4(dseed, a.dropout_site, w, a.dropout_p) | (dropout_keep4(dseed, a.dropout_site, w + 1, a.dropout_p) << 4);
+            keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -128,8 +116,28 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (nc + e < N32) t[e] += ra_row[e];
         }
+        if (resid) {
+          const T* rp = resid + m * a.ldr + nc;
+          if (!edge) {
+            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = (gt[e] > 0.f) ? t[e] + res[e] : 0.f;
+            for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (nc + e < a.ldr) t[e] += to_f32(rp[e]);
+          }
+        }
+        if (gate) {  // ReLU backward: pass where the forward activation was positive
+          const T* gp = gate + m * a.ldg + nc;
+          if (!edge) {
+            Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (bits_to_f32<T>(p8.h[e]) > 0.f) ? t[e] : 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (nc + e < a.ldg) t[e] = (to_f32(gp[e]) > 0.f) ? t[e] : 0.f;
+          }
+        }
         if (edge) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (nc + e >= N32) t[e] = 0.f;

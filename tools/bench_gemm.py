@@ -9,6 +9,7 @@ dev = torch.device("cuda", 0)
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 ONLY_WGRAD = len(sys.argv) > 2 and sys.argv[2] == "wgrad"
+ONLY = sys.argv[2] if len(sys.argv) > 2 and not ONLY_WGRAD else None  # substring filter on the GEMM cases
 
 
 def timeit(fn, iters=None):
@@ -34,6 +35,8 @@ def run():
                            ("dec ff1 N512 K128", 512, 128, dict(bias=True, relu=True)),
                            ("dec proj N128 K128", 128, 128, dict(bias=True, resid=True)),
                            ("plain N256 K256", 256, 256, dict())]:
+        if ONLY and ONLY not in name:
+            continue
         A = torch.randn(M, K, device=dev).to(BF); W = torch.randn(N, K, device=dev).to(BF) * 0.05
         C = torch.zeros(M, N, dtype=BF, device=dev)
         bias = torch.randn(N, device=dev) if kw.get("bias") else None
@@ -45,6 +48,8 @@ def run():
         us = timeit(fn)
         byts = 2 * (M * K + M * N + N * K) + (2 * M * N if resid is not None else 0) + (2 * M * N if gate is not None else 0)
         print(f"{name:44s} {us:8.1f} {2*M*N*K/us/1e6:8.1f} {byts/us/1e3:10.0f}")
+    if ONLY:
+        return
     # wgrad: one encoder layer
     D = 256
     dh, a = torch.randn(M, D, device=dev).to(BF), torch.randn(M, 4 * D, device=dev).to(BF)
