@@ -16,8 +16,9 @@
 
 namespace mst {
 
-constexpr int BK = 64;           // K depth of one LDS tile (elements)
-constexpr int CHUNKS = BK / 8;   // 16-byte chunks per tile row
+// K depth of one LDS tile: template parameter BK (elements), CHUNKS = BK / 8 16-byte chunks per tile row. 64 for the
+// big launches; 256 for the skinny ones (M <= 64, K >= 512: a handful of workgroups whose time is the number of
+// dependent K tiles, each one exposed memory round trip).
 
 // Shared epilogue of the GEMM kernels (called after a workgroup barrier: `smem` is free to reuse).
 template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
@@ -165,8 +166,9 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
+  constexpr int CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
   constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 sub-tiles per wave
@@ -289,15 +291,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int BK = 64>
 static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
+  if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
+    static bool opted[2] = {false, false};
+    if (!opted[a.c_f32 ? 1 : 0]) {
+      const void* fn = a.c_f32 ? reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK>)
+                               : reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK>);
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted[a.c_f32 ? 1 : 0] = true;
+    }
+  }
   if (a.c_f32)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, true>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK>), grid, block, lds, s, a);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, false>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK>), grid, block, lds, s, a);
   MST_CHECK_LAUNCH("gemm_nt_kernel");
   return MST_OK;
 }
@@ -333,6 +345,7 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // a tile's main loop is 2-16 stages of one exposed L2 round trip each, at 12 TB/s of L2->LDS traffic for the
     // K = 1024 shapes). 128x128 is used where it still leaves >= 1.5 workgroups per CU.
     if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
+    if (a.M <= 64 && a.K >= 512 && a.K % 256 == 0) return launch_gemm<T, 64, 64, 2, 2, 256>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
 }

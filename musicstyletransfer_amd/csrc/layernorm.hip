@@ -294,7 +294,11 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
   int nw = (int)(32768 / (8 * D));  // reduction buffer 2 * nw * D floats <= 32 KiB
   if (nw > 16) nw = 16;
   if (nw < 1) nw = 1;
-  const unsigned grid = (unsigned)(cdiv(M, 4 * nw) < 256 ? cdiv(M, 4 * nw) : 256);
+  // ~4 rows per wave when there are enough rows to fill the chip, one row per wave for small M (the top encoder
+  // layer's B rows used to run on ONE workgroup: 11 us)
+  int64_t wgs = cdiv(M, 4 * nw);
+  if (wgs < 64) wgs = cdiv(M, nw) < 64 ? cdiv(M, nw) : 64;
+  const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
   const size_t lds = (size_t)2 * nw * D * sizeof(float);
   const int64_t rows_per_wave = cdiv(M, (int64_t)grid * nw);
   return dispatch_act(dtype, [&](auto tag) -> int {
