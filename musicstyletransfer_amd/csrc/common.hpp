@@ -133,6 +133,18 @@ __host__ __device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint64_t
   x ^= x >> 15;
   return x;
 }
+// the same word for an index below 2^32 (the high-half term of dropout_word vanishes)
+__host__ __device__ __forceinline__ uint32_t dropout_word32(uint32_t key, uint32_t idx2) {
+  uint32_t x = (idx2 * 0x9E3779B1u) ^ key;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_keep4k32(uint32_t key, uint32_t idx4, uint32_t thr) {
+  const uint32_t x0 = dropout_word32(key, 2 * idx4), x1 = dropout_word32(key, 2 * idx4 + 1);
+  return (uint32_t)((x0 & 0xFFFFu) >= thr) | ((uint32_t)((x0 >> 16) >= thr) << 1) | ((uint32_t)((x1 & 0xFFFFu) >= thr) << 2) |
+         ((uint32_t)((x1 >> 16) >= thr) << 3);
+}
 // bit e of the result = keep decision of element 4*idx4 + e
 __host__ __device__ __forceinline__ uint32_t dropout_keep4k(uint32_t key, uint64_t idx4, uint32_t thr) {
   const uint32_t x0 = dropout_word(key, 2 * idx4), x1 = dropout_word(key, 2 * idx4 + 1);

@@ -54,6 +54,8 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
                     (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
   const bool has_drop = a.dropout_p > 0.f;
   const bool has_rowops = a.rowadd || a.grpadd;
+  const bool fast = !C_F32 && !edge && !has_rowops && a.c_rows_per_group <= 0 && (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
+                    nc + 8 <= n_store;
   const bool relu = a.act == MST_ACT_RELU;
   const float alpha = a.alpha;
   float bias8[8];
@@ -71,6 +73,68 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
           *reinterpret_cast<f32x4*>(sF + (i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
     }
     __syncthreads();
+    // Fast path (interior tile, 16-bit output, no row remap / row-indexed adds, < 2^32 output elements): the row
+    // loop carries pointers and a 32-bit dropout counter forward by constant strides. At two waves per SIMD the
+    // epilogue is VALU-bound (measured per workgroup: 7.7 us of a 13.9 us life in FFN1, most of it 64-bit address
+    // and counter arithmetic per 8-column chunk).
+    if (fast) {
+      constexpr int RSTEP = NT / CPR;
+      const int row0 = tid / CPR;
+      const int64_t mf = m0 + pass * WTM + row0;
+      T* cp = reinterpret_cast<T*>(a.C) + mf * a.ldc + nc;
+      const T* rp = resid ? resid + mf * a.ldr + nc : nullptr;
+      const T* gp = gate ? gate + mf * a.ldg + nc : nullptr;
+      uint32_t w = (uint32_t)((uint64_t)(mf * a.N + nc) >> 2);
+      const uint32_t wstep = (uint32_t)((uint64_t)(RSTEP * a.N) >> 2);
+      const float* sp = sF + row0 * LDS_F + ch * 8;
+#pragma unroll 2
+      for (int row = row0; row < WTM; row += RSTEP) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] += bias8[e];
+        }
+        if (alpha != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] *= alpha;
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
+        }
+        if (has_drop || a.self_resid) {
+          uint32_t keep8 = 0xFFu;
+          if (has_drop) keep8 = dropout_keep4k32(dkey, w, dthr) | (dropout_keep4k32(dkey, w + 1, dthr) << 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
+            t[e] = a.self_resid ? t[e] + u : u;
+          }
+        }
+        if (rp) {
+          Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
+          rp += (int64_t)RSTEP * a.ldr;
+        }
+        if (gp) {  // ReLU backward: pass where the forward activation was positive
+          Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = (bits_to_f32<T>(p8.h[e]) > 0.f) ? t[e] : 0.f;
+          gp += (int64_t)RSTEP * a.ldg;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (uint32_t)f32_to_bits<T>(t[2 * e]) | ((uint32_t)f32_to_bits<T>(t[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4*>(cp) = o;
+        cp += (int64_t)RSTEP * a.ldc;
+        w += wstep;
+        sp += RSTEP * LDS_F;
+      }
+    } else
     if (nc < n_store) {
 #pragma unroll 2
       for (int row = tid / CPR; row < WTM; row += NT / CPR) {
