@@ -132,7 +132,8 @@ typedef struct mst_wgrad_args {
 } mst_wgrad_args;
 
 int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream);
-/* up to 8 problems (host array) in ONE launch: keeps the M-split, and with it the atomic traffic, small */
+/* up to 16 problems (host array) in ONE launch — the engine hands over every weight gradient of the backward pass at
+ * once: one resident round of workgroups, the M-split (and with it the fp32-atomic traffic) as small as it gets */
 int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------

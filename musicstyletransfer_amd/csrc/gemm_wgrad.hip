@@ -14,7 +14,7 @@
 
 namespace mst {
 
-constexpr int WG_MAXP = 8;
+constexpr int WG_MAXP = 16;  // problems per launch (the whole backward pass of configs[1] is 15)
 struct WgradBatch {
   int n;
   int split;                      // M split factor shared by all problems

@@ -332,15 +332,13 @@ class StepPlan:
             t.delta = torch.zeros(B, H, S, **f32)
             return t
 
-        # one set per layer: a layer's weight-gradient GEMMs run on the side stream while the main stream already
-        # works on the next layer, so the operands they read must not be that layer's scratch
+        # one set per layer: every weight gradient of the step is computed by ONE launch at the end of backward(), so the
+        # operands it reads (dh, dpre, dh1, dqkv of each layer) must survive until then. (Running them on a forked
+        # stream instead bought nothing: hipGraph on ROCm 7.2 replays fork/join branches back to back on one queue.)
         self.be_l = [bwd_bufs(self.Me, De, cfg.e_heads, Se) for _ in range(cfg.e_layers)]
         self.bd_l = [bwd_bufs(self.Md, Dd, cfg.d_heads, Sd) for _ in range(cfg.d_layers)]
         self.be, self.bd = self.be_l[0], self.bd_l[0]
-        self.side_stream = torch.cuda.Stream(device=dev)
-        # hipGraph on ROCm 7.2 replays such fork/join branches back to back on one queue (rocprofv3 kernel trace), so
-        # the fork buys nothing today; the plumbing (per-layer scratch, _side) stays for runtimes that overlap them
-        self.use_side_stream = False
+        self._wgrads = []
         self.lat_scratch = torch.zeros(B * (Dd + 2 * Z), **f32)
         # Sparse gradient carriers, never used as ping-pong targets so their untouched rows stay zero:
         #   d_dec_out: d(decoder output) - rows 1..T written by the output-layer dgrad, row 0 always 0 (model.py:253)
@@ -558,27 +556,14 @@ class StepPlan:
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
         o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
-        # all four weight gradients of the layer in one launch, off the critical path
-        self._side(lambda: o.gemm_wgrad_batch([
+        # the layer's four weight gradients: deferred to the ONE wgrad launch at the end of backward() (their operands
+        # live in this layer's own scratch `t` and in the forward activations, so nothing is overwritten meanwhile)
+        self._wgrads += [
             o.wgrad_problem(dff, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=D, K=4 * D),
             o.wgrad_problem(t.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * D, K=D),
             o.wgrad_problem(dproj, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=D, K=D),
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
-        ]))
-
-    def _side(self, fn):
-        """Run `fn` (weight-gradient kernels: they feed nothing but the optimizer) on the side stream, ordered after
-        everything issued so far on the main stream; backward() joins the side stream before it returns. Captured
-        into the step's hipGraph as a fork/join, this lets the latency-bound wgrad kernels fill the issue slots the
-        equally latency-bound dgrad / attention chain leaves idle."""
-        if not self.use_side_stream:
-            return fn()
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        with torch.cuda.stream(self.side_stream):
-            self.side_stream.wait_event(ev)
-            fn()
+        ]
 
     def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t):
         """_layer_bwd for the LAST encoder layer, on the B rows (position 0 of each sample) that carry gradient."""
@@ -618,12 +603,12 @@ class StepPlan:
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
         o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D)
         o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
-        self._side(lambda: o.gemm_wgrad_batch([
+        self._wgrads += [
             o.wgrad_problem(dff, row0(L.a), st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), M=B, N=D, K=4 * D),
             o.wgrad_problem(c.dpre, row0(L.x1), st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), M=B, N=4 * D, K=D),
             o.wgrad_problem(dproj, row0(L.att), st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), M=B, N=D, K=D),
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
-        ]))
+        ]
 
     def backward(self):
         cfg, st, B, T = self.cfg, self.store, self.B, self.T
@@ -634,8 +619,8 @@ class StepPlan:
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
-        self._side(lambda: o.gemm_wgrad(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
-                                        st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1)))
+        self._wgrads = [o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
+                                        st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1))]
         dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
         site_d = 3 * cfg.e_layers
         for i in reversed(range(cfg.d_layers)):
@@ -648,8 +633,8 @@ class StepPlan:
         if cfg.kind == "token":
             o.embed_bwd(self.tokens, st.grad("decoder.embedding.weight"), d_x0_d.view(B, Sd, -1), 1, sq_d)
         else:
-            self._side(lambda: o.gemm_wgrad(self.roll, d_x0_d, st.grad("decoder.embedding.weight"), M=B * T, N=cfg.out_dim,
-                                            K=Dd, scale=sq_d, b_remap=(T, Sd, 1)))
+            self._wgrads.append(o.wgrad_problem(self.roll, d_x0_d, st.grad("decoder.embedding.weight"), M=B * T, N=cfg.out_dim,
+                                                K=Dd, scale=sq_d, b_remap=(T, Sd, 1)))
         # gradient w.r.t. the encoder output: zero except position 0 of every sample
         d_enc = self.d_enc_out
         o.latent_bwd(self.enc_out.view(B, Se, -1), st.p("encoder.latent_proj.weight"), self.eps,
@@ -673,10 +658,13 @@ class StepPlan:
             o.embed_bwd(self.tokens, st.grad("encoder.embedding.weight"), d_x0_e.view(B, Se, -1), 0, sq_e,
                         classes=self.classes, dcls=st.grad("encoder.class2hid.weight"))
         else:
-            o.gemm_wgrad(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim, K=De, scale=sq_e)
+            self._wgrads.append(o.wgrad_problem(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim,
+                                                K=De, scale=sq_e))
             o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
-        if self.use_side_stream:
-            torch.cuda.current_stream().wait_stream(self.side_stream)  # join: the optimizer reads every gradient
+        # every Dense weight / bias gradient of the step in ONE launch (15 problems at configs[1]): one resident round
+        # of workgroups with the smallest possible M-split instead of six launches with their own ramps and tails
+        o.gemm_wgrad_batch(self._wgrads)
+        self._wgrads = []
 
     def optimizer(self):
         st = self.store

@@ -90,10 +90,15 @@ def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=
     return w
 
 
+WGRAD_MAX_PROBLEMS = 16
+
+
 def gemm_wgrad_batch(problems):
-    """dW_i[N,K] += A_i^T @ B_i for up to 8 problems in one launch."""
-    arr = (WgradArgs * len(problems))(*problems)
-    call("mst_gemm_wgrad_batch", arr, len(problems), stream())
+    """dW_i[N,K] += A_i^T @ B_i for a list of problems, 16 per launch."""
+    for i in range(0, len(problems), WGRAD_MAX_PROBLEMS):
+        chunk = problems[i:i + WGRAD_MAX_PROBLEMS]
+        arr = (WgradArgs * len(chunk))(*chunk)
+        call("mst_gemm_wgrad_batch", arr, len(chunk), stream())
 
 
 def gemm_wgrad(A, B, dW, db=None, **kw):

@@ -54,6 +54,16 @@ def main():
     timeit("step_begin", lambda: o.step_begin(rng_state=rng, adam_state=adam, lr=1e-3, eps_out=eps, lens=lens, mask_e=me, mask_d=md))
     gbuf = torch.zeros(1885440, device=dev)
     timeit("zero(grad bucket 7.5 MB)", lambda: o.zero(gbuf))
+    M, D = 16384, 256
+    x = r(M, D).to(BF); dy = r(M, D).to(BF); gam = r(D); bet = r(D)
+    yl = torch.zeros(M, D, dtype=BF, device=dev); mean = torch.zeros(M, device=dev); rstd = torch.zeros(M, device=dev)
+    timeit("layernorm_fwd 16384x256", lambda: o.layernorm_fwd(x, gam, bet, yl, mean, rstd))
+    dxl, dxm = torch.zeros(M, D, dtype=BF, device=dev), torch.zeros(M, D, dtype=BF, device=dev)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    seedp = torch.zeros(4, dtype=torch.int64, device=dev)
+    timeit("layernorm_bwd 16384x256 mask_mode 0", lambda: o.layernorm_bwd(x, gam, mean, rstd, dy, dxl, dg, db))
+    timeit("layernorm_bwd 16384x256 mask_mode 1", lambda: o.layernorm_bwd(x, gam, mean, rstd, dy, dxl, dg, db, dx_masked=dxm, mask_mode=1,
+                                                                         dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=1))
     y = torch.zeros(1024, dtype=BF, device=dev); a1 = torch.zeros(1024, dtype=BF, device=dev)
     timeit("add_act(1024)  [launch floor]", lambda: o.add_act(a1, a1, y))
 
