@@ -225,9 +225,31 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 }
 
 template <typename T>
-static int launch_wgrad(const WgradBatch& b, bool big, hipStream_t s) {
+static int launch_wgrad(const WgradBatch& b, int big, hipStream_t s) {
   const int64_t total = cdiv(b.tile_prefix[b.n] * b.split, 8) * 8;  // padded to whole XCD rounds (see the kernel)
-  if (big) {
+  if (big == 3) {
+    constexpr int BN = 256, BKO = 256;
+    size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
+    static bool opted = false;
+    if (!opted) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BN, BKO, 4, 2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("wgrad_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 4, 2>), dim3((unsigned)total), dim3(512), lds, s, b);
+  } else if (big == 2) {
+    constexpr int BN = 256, BKO = 128;
+    size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
+    static bool opted = false;
+    if (!opted) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BN, BKO, 4, 2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("wgrad_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 4, 2>), dim3((unsigned)total), dim3(512), lds, s, b);
+  } else if (big) {
     constexpr int BN = 128, BKO = 128;
     size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
     static bool opted = false;  // 73.7 KB of dynamic LDS: above the 64 KB default
@@ -278,17 +300,23 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
     if (list[i].M > maxM) maxM = list[i].M;
   }
   // tile size: 128x128 when that still leaves enough tiles to fill the chip at a modest split
-  const bool big = out_elems >= (int64_t)128 * 128 * 24;
-  const int bn = big ? 128 : 64;
+  // Tile shape by total output size (enough tiles for one resident round at a split of a few): the kernel is bound
+  // by operand traffic into the CUs, so bytes per FLOP decide: 64x64 tiles (4 waves, up to 5 workgroups per CU),
+  // 128x128 (4 waves, 2 per CU), 256x128 and 256x256 (8 waves, 1 per CU). Whole step of configs[1] (2.2 M outputs):
+  // 1.000 / 0.982 / 0.971 ms per step with 128x128 / 256x128 / 256x256.
+  int big = 0;
+  if (out_elems >= (int64_t)256 * 256 * 24) big = 3;
+  else if (out_elems >= (int64_t)256 * 128 * 36) big = 2;  // (a 0.79 M-output batch measured 58 us with 128x128, 62 with 256x128)
+  else if (out_elems >= (int64_t)128 * 128 * 24) big = 1;
+  const int bn = big >= 2 ? 256 : (big ? 128 : 64), bk = big == 3 ? 256 : (big ? 128 : 64);
   b.tile_prefix[0] = 0;
   for (int i = 0; i < n; ++i)
-    b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bn);
+    b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bk);
   for (int i = n + 1; i <= WG_MAXP; ++i) b.tile_prefix[i] = b.tile_prefix[n];
   const int64_t tiles = b.tile_prefix[n];
-  // aim for >= 1024 workgroups, at least 2 LDS stages (128 rows) per workgroup
-  // 128x128 tiles run 2 workgroups per CU at most (register file), 64x64 tiles 5: aim for one full wave of
-  // workgroups, no more — every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
-  int64_t split = (big ? 512 : 1024) / tiles;  // floor: a 513th workgroup would start a second round (105 vs 83 us)
+  // one full resident round of workgroups, no more: floor, because the workgroup that does not fit starts a second
+  // round (105 vs 83 us), and every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
+  int64_t split = (big >= 2 ? 256 : (big ? 512 : 1024)) / tiles;
   int64_t max_split = cdiv(maxM, 2 * BMR);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
