@@ -188,6 +188,8 @@ def main():
     host = synthetic_batches(4, B_LOCAL, T_LEN, CFG2["in_dim"], seed=1234 + rank)
     resident = [plan.pack_batch(hb["x"], hb["seq_lens"], hb["classes"], hb["labels"]).to(dev) for hb in host]
     reduce_fn = parallel.make_grad_allreduce(dist) if world > 1 else None
+    # data parallel: the early part of the gradient bucket is all-reduced while the rest of backward runs
+    reducer = parallel.GradReducer(dist) if world > 1 and os.environ.get("MST_DP_OVERLAP", "1") != "0" else None
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -197,11 +199,11 @@ def main():
         feed(0)
         plan.step_kernels(True, reduce_fn=reduce_fn)  # first step eager (HIP module loads), then capture
         torch.cuda.synchronize()
-        plan.capture(True, split_optimizer=world > 1)
+        plan.capture(True, split_optimizer=world > 1, overlap=reducer is not None)
 
         def one_step(i):
             feed(i)
-            plan.run(reduce_fn=reduce_fn)
+            plan.run(reduce_fn=reduce_fn, reducer=reducer)
 
         for i in range(args.warmup):
             one_step(i)

@@ -64,6 +64,8 @@ class Trainer:
         self.rank = int(os.environ.get("RANK", "0"))
         self.dist = parallel.init_process_group(self.world, self.rank) if self.world > 1 else None
         self.reduce_fn = parallel.make_grad_allreduce(self.dist) if self.dist is not None else None
+        # data parallel: asynchronous two-range all-reduce overlapped with the tail of backward (engine.StepPlan.capture)
+        self.reducer = parallel.GradReducer(self.dist) if self.dist is not None else None
         self._initialize_model()
         self._initialize_optimizers()
         # the step runs (and is captured) on its own stream: the legacy default stream cannot be captured
@@ -119,12 +121,12 @@ class Trainer:
                 if not hasattr(plan, "_graphs"):
                     plan._graphs = {}
                 self.stream.synchronize()
-                plan.capture(is_train, split_optimizer=self.world > 1)
-                plan._graphs[is_train] = (plan.graph, plan.graph_opt)
+                plan.capture(is_train, split_optimizer=self.world > 1, overlap=self.world > 1)
+                plan._graphs[is_train] = (plan.graph, plan.graph_late, plan.graph_opt)
                 self._captured.add(key)
             else:
-                plan.graph, plan.graph_opt = plan._graphs[is_train]
-                plan.run(reduce_fn=self.reduce_fn if is_train else None)
+                plan.graph, plan.graph_late, plan.graph_opt = plan._graphs[is_train]
+                plan.run(reduce_fn=self.reduce_fn if is_train else None, reducer=self.reducer if is_train else None)
         self._last = (plan, labels)
 
     def fit(self, dataset, model_folder: str, epochs: int, validation_dataset=None):

@@ -356,6 +356,7 @@ class StepPlan:
         self.sp_dh1 = act(self.Me, De)
         self.sp_datt = act(self.Me, De)
         self.graph = None
+        self.graph_late = None
         self.graph_opt = None
         self._tick_adam = False
 
@@ -611,10 +612,27 @@ class StepPlan:
         ]
 
     def backward(self):
+        self.backward_early(flush=False)
+        self.backward_late()
+
+    def grad_cut(self):
+        """Offset that splits the flat gradient bucket by the time its entries are final: [cut, n) — the top encoder
+        layer, latent_proj and every decoder tensor — is complete after backward_early(flush=True); [0, cut) — the
+        remaining encoder layers, the encoder embedding and class table — after backward_late(). 0 when the encoder has
+        a single layer (nothing is early)."""
+        cfg, st = self.cfg, self.store
+        if cfg.e_layers < 2:
+            return 0
+        return st.offsets[f"encoder.layer{cfg.e_layers - 1}.att.W_k.weight"]
+
+    def backward_early(self, flush):
+        """Output layer, decoder, latent block and the TOP encoder layer. With `flush` the weight gradients collected so
+        far get their own wgrad launch, so that the [grad_cut(), n) part of the bucket can be all-reduced while
+        backward_late() runs (data parallel); without it they wait for the single launch at the end."""
         cfg, st, B, T = self.cfg, self.store, self.B, self.T
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
-        sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
+        sq_d = math.sqrt(float(Dd))
         # (the gradient bucket was cleared by forward()'s step_begin launch)
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
@@ -644,14 +662,23 @@ class StepPlan:
                      st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"),
                      st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
                      enc_scale=self.gscale_enc / self.gscale)
-        dy, tgt, nxt = self.d_enc_out, self.be_l[0].dx_a, self.be_l[0].dx_b
-        for i in reversed(range(cfg.e_layers)):
+        top = cfg.e_layers - 1
+        x_in = self.enc[top - 1].x2 if top > 0 else self.x0_e
+        self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top])
+        if flush and cfg.e_layers >= 2:
+            o.gemm_wgrad_batch(self._wgrads)
+            self._wgrads = []
+
+    def backward_late(self):
+        """The encoder layers below the top one, the encoder input, and the (remaining) weight gradients."""
+        cfg, st, B, T = self.cfg, self.store, self.B, self.T
+        De, Se = cfg.e_model, T
+        sq_e = math.sqrt(float(De))
+        dy, tgt, nxt = self.be_l[0].dx_a, self.be_l[0].dx_b, self.be_l[0].dx_a  # the top layer wrote dx_a
+        for i in reversed(range(cfg.e_layers - 1)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
-            if i == cfg.e_layers - 1:
-                self._top_encoder_layer_bwd(i, self.enc[i], x_in, tgt, self.be_l[i])
-            else:
-                self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
-                                3 * i, self.be_l[i])
+            self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
+                            3 * i, self.be_l[i])
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_e = dy
         if cfg.kind == "token":
@@ -661,8 +688,8 @@ class StepPlan:
             self._wgrads.append(o.wgrad_problem(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim,
                                                 K=De, scale=sq_e))
             o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
-        # every Dense weight / bias gradient of the step in ONE launch (15 problems at configs[1]): one resident round
-        # of workgroups with the smallest possible M-split instead of six launches with their own ramps and tails
+        # every (remaining) Dense weight / bias gradient in ONE launch — all 15 problems of the step at configs[1] on a
+        # single GPU: one resident round of workgroups with the smallest possible M-split instead of six launches
         o.gemm_wgrad_batch(self._wgrads)
         self._wgrads = []
 
@@ -698,12 +725,24 @@ class StepPlan:
                 reduce_fn(self.store.g)
             self.optimizer()
 
-    def capture(self, is_train=True, split_optimizer=False):
+    def capture(self, is_train=True, split_optimizer=False, overlap=False):
         """Capture the step into hipGraph(s) on the current stream. Run one eager step of this shape
         first (lazy HIP module loads are not capturable). With split_optimizer the optimizer lives in
-        its own graph so a gradient all-reduce can run between the two (data parallel)."""
+        its own graph so a gradient all-reduce can run between the two (data parallel). With overlap as well (and an
+        encoder of >= 2 layers) the backward pass is cut after the top encoder layer: run(reducer=...) all-reduces the
+        early part of the bucket on the communication stream while the rest of the backward pass executes."""
         self.is_train, self.split = is_train, split_optimizer
-        if split_optimizer or not is_train:
+        self.graph_late = None
+        if is_train and split_optimizer and overlap and self.grad_cut() > 0:
+            def early():
+                self._tick_adam = True
+                self.forward()
+                self.losses(with_grad=True)
+                self.backward_early(flush=True)
+            self.graph = o.Graph().capture(early)
+            self.graph_late = o.Graph().capture(self.backward_late)
+            self.graph_opt = o.Graph().capture(self.optimizer)
+        elif split_optimizer or not is_train:
             self.graph = o.Graph().capture(lambda: self.fwd_bwd_kernels(is_train))
             self.graph_opt = o.Graph().capture(self.optimizer) if is_train else None
         else:
@@ -711,12 +750,27 @@ class StepPlan:
             self.graph_opt = None
         return self
 
-    def run(self, reduce_fn=None):
+    def run(self, reduce_fn=None, reducer=None):
+        """Replay the captured step. reduce_fn(flat): blocking-in-stream-order all-reduce of the whole bucket between the
+        two graphs. reducer (parallel.GradReducer): asynchronous per-range all-reduce, used with capture(overlap=True)."""
         if self.graph is None:
             raise RuntimeError("call capture() first")
         self.graph.launch()
+        if self.graph_late is not None:
+            g, cut = self.store.g, self.grad_cut()
+            pending = [reducer.start(g[cut:])] if reducer is not None else []
+            self.graph_late.launch()  # runs while the early part of the bucket is on the wire
+            if reducer is not None:
+                pending.append(reducer.start(g[:cut]))
+                reducer.finish(pending)
+            elif reduce_fn is not None:
+                reduce_fn(g)
+            self.graph_opt.launch()
+            return
         if self.graph_opt is not None:
-            if reduce_fn is not None:
+            if reducer is not None:
+                reducer.finish([reducer.start(self.store.g)])
+            elif reduce_fn is not None:
                 reduce_fn(self.store.g)
             self.graph_opt.launch()
 

@@ -44,6 +44,24 @@ def make_grad_allreduce(dist):
     return reduce_fn
 
 
+class GradReducer:
+    """Asynchronous SUM all-reduce of ranges of the flat gradient bucket. start() enqueues the collective behind
+    everything already issued on the current stream (nccl: on RCCL's own stream, so kernels launched afterwards on
+    the current stream overlap with it; gloo: a host-side work item), finish() makes the current stream (nccl) or the
+    host (gloo) wait for the given handles. This is the comm/compute overlap of the data-parallel step: the part of
+    the bucket that the top of the backward pass completes travels over xGMI while the rest of backward executes."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def start(self, flat_range):
+        return self.dist.all_reduce(flat_range, op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self, handles):
+        for h in handles:
+            h.wait()
+
+
 def shard_bounds(global_batch, world, rank):
     """contiguous shard [lo, hi) of the global batch for `rank`"""
     assert global_batch % world == 0, "global batch must divide evenly over the ranks"

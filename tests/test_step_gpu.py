@@ -283,6 +283,48 @@ def test_graph_replay_matches_eager(gpu):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-3)
 
 
+def test_overlapped_data_parallel_schedule_matches_single_graph(gpu):
+    """capture(split_optimizer, overlap): forward + early backward | late backward | optimizer, with the gradient
+    bucket handed to the reducer in two ranges (top encoder layer .. decoder first). With a recording stand-in for the
+    collective the three-graph schedule must reproduce the single-graph step."""
+    from musicstyletransfer_amd import engine as E
+    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (32, 32, 2, 16, 32, 2, 2, 32, 1, 2), 4, 16, 37)
+
+    class Recorder:
+        def __init__(self):
+            self.ranges = []
+
+        def start(self, flat):
+            self.ranges.append((flat.data_ptr(), flat.numel()))
+            return None
+
+        def finish(self, handles):
+            assert all(h is None for h in handles)
+
+    res = []
+    for overlap in (False, True):
+        store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+        plan = E.StepPlan(store, 4, 16, lr=1e-3)
+        plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
+        rec = Recorder()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            plan.step_kernels(True)
+            plan.capture(True, split_optimizer=overlap, overlap=overlap)
+            for _ in range(3):
+                plan.run(reducer=rec if overlap else None)
+        torch.cuda.synchronize()
+        res.append((store.w.cpu().numpy().copy(), plan.total.cpu().numpy().copy(), int(store.step_state[0].item())))
+        if overlap:
+            cut, n = plan.grad_cut(), store.g.numel()
+            assert 0 < cut < n and plan.graph_late is not None
+            base = store.g.data_ptr()
+            assert rec.ranges[:2] == [(base + 4 * cut, n - cut), (base, cut)]  # early range first, then the rest
+    assert res[0][2] == res[1][2] == 4
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-4)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-3)
+
+
 def test_dropout_masks_are_applied_and_reproducible(gpu):
     """with dropout on, forward/backward regenerate identical masks from the device-resident seed
     (loss decreases over steps; two plans with the same seed produce the same losses)"""
