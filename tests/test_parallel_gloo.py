@@ -49,7 +49,16 @@ def _worker(rank, world, port, q):
     loss = O.step_losses(P, cfg, shard, torch.from_numpy(eps))[0]
     loss.sum().backward()
     flat = torch.cat([p.grad.reshape(-1) for p in P.values()])
-    parallel.make_grad_allreduce(dist)(flat)  # the one collective of the step
+    # the step's gradient exchange, both forms: one blocking all-reduce of the bucket, and the overlapped schedule's
+    # two asynchronous ranges (early part first, then the rest) — they must agree
+    flat2 = flat.clone()
+    parallel.make_grad_allreduce(dist)(flat)
+    red = parallel.GradReducer(dist)
+    cut = flat2.numel() // 3
+    handles = [red.start(flat2[cut:])]
+    handles.append(red.start(flat2[:cut]))
+    red.finish(handles)
+    assert torch.equal(flat, flat2)
     if rank == 0:
         Pf = O.to_torch_params(params)
         O.step_losses(Pf, cfg, batch, torch.from_numpy(eps_all))[0].sum().backward()
