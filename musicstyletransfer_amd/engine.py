@@ -269,20 +269,7 @@ class StepPlan:
         for name, nbytes in seg:
             self.in_layout[name] = (off, nbytes)
             off = roundup(off + nbytes, 16)
-        self.inbuf = torch.zeros(off, dtype=torch.uint8, device=dev)
-
-        def inview(name, dtype, *shape):
-            a, n = self.in_layout[name]
-            return self.inbuf[a: a + n].view(dtype).view(*shape)
-
-        if cfg.kind == "token":
-            self.tokens = inview("tokens", torch.int32, B, T)
-            self.labels = inview("labels", torch.int32, B, T)
-        else:
-            self.roll = inview("roll", adt, B * T, roundup(cfg.in_dim, 8))
-            self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
-        self.seq_lens = inview("seq_lens", torch.int32, B)
-        self.classes = inview("classes", torch.int32, B)
+        self.bind_inputs(torch.zeros(off, dtype=torch.uint8, device=dev))
         self.eps = torch.zeros(B, Z, **f32)
         self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D, 0], dtype=torch.int64, device=dev)
 
@@ -361,6 +348,29 @@ class StepPlan:
         self._tick_adam = False
 
     # ------------------------------------------------------------------------------ inputs
+    def bind_inputs(self, buf):
+        """Make `buf` (a device uint8 blob with pack_batch()'s layout) the step's input buffer: the typed views the
+        kernels read are re-pointed, nothing is copied. A graph captured afterwards reads THAT buffer — a batcher that
+        fills two or more such buffers in turn (or bench.py's resident batches) needs no device-to-device hop."""
+        cfg, B, T = self.cfg, self.B, self.T
+        need = self.in_layout["classes"][0] + self.in_layout["classes"][1]
+        if not (buf.dtype == torch.uint8 and buf.is_contiguous() and buf.is_cuda and buf.data_ptr() % 16 == 0 and buf.numel() >= need):
+            raise ValueError("bind_inputs: need a contiguous, 16-byte aligned device uint8 blob of pack_batch()'s size")
+        self.inbuf = buf
+
+        def inview(name, dtype, *shape):
+            a, n = self.in_layout[name]
+            return buf[a: a + n].view(dtype).view(*shape)
+
+        if cfg.kind == "token":
+            self.tokens = inview("tokens", torch.int32, B, T)
+            self.labels = inview("labels", torch.int32, B, T)
+        else:
+            self.roll = inview("roll", self.adt, B * T, roundup(cfg.in_dim, 8))
+            self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
+        self.seq_lens = inview("seq_lens", torch.int32, B)
+        self.classes = inview("classes", torch.int32, B)
+
     def load_batch(self, x, seq_lens, classes, labels, eps=None):
         """Copy one batch (host or device tensors / numpy arrays) into the static input buffers."""
         def dev(a, dtype):
