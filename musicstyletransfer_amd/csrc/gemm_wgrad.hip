@@ -185,9 +185,9 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
     }
   };
   // One stage of global loads in flight, staged through registers into the other LDS buffer. (Two stages in flight —
-  // a second register set, 256 VGPRs — measured the same 58 us: with conflict-free reads the kernel is bound by LDS
-  // bandwidth, 8 waves x (32 transposed 512-byte reads + 8 1-KiB writes) per 64-row stage keep the CU's LDS busy
-  // ~100 % of the time; fewer LDS bytes per MFMA needs a larger per-wave tile than 64x64.)
+  // a second register set, 256 VGPRs — measured the same 58 us on the 128x128 tiles: the stage time, ~2.2 us for 0.25 us
+  // of MFMA work per wave, is not a latency that more loads in flight would hide; what did move it was fewer operand
+  // bytes per FLOP — the 256x128 and 256x256 tiles of launch_wgrad.)
   load_tile(m_begin);
   store_tile(0);
   __syncthreads();
