@@ -190,7 +190,13 @@ int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t 
                             const void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
                             const uint8_t* keymask, const float* lse,
                             const void* dout, int64_t ld_dout,
-                            void* dqkv, int64_t ld_dqkv, float* delta, mst_stream_t stream);
+                            void* dqkv, int64_t ld_dqkv, float* delta,
+                            int64_t q_limit /* the caller's promise that rows [q_limit, S) of every sample of dout are ZERO
+                                               (the mirror of the forward's q_limit; <= 0 or >= S: dense). With
+                                               q_limit <= 32 the resident kernel skips the work that multiplies those
+                                               zeros — results are bit-identical to the dense computation; the
+                                               streaming kernels read dout in full, so the rows must really be zero */,
+                            mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K6: y = LayerNorm(x) * gamma + beta over the last axis (eps, biased variance;

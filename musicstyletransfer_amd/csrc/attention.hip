@@ -334,8 +334,9 @@ __device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const flo
   }
 }
 
-// dQ tile: x = P * (dP*scale - delta*scale), then acc += x^T-product with the staged K rows
-template <typename T, int DH, bool EXACT>
+// dQ tile: x = P * (dP*scale - delta*scale), then acc += x^T-product with the staged K rows.
+// LIGHT: the owned queries' dO rows are zero (dP = 0): no V fragments, no dP MFMAs.
+template <typename T, int DH, bool EXACT, bool LIGHT = false>
 __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
                                            const float* sMax, const float* sLogl, const float* sDs, int blk, float scale,
                                            const typename Act<T>::vec8 (&qf)[DH / 16], const typename Act<T>::vec8 (&dof)[DH / 16],
@@ -345,7 +346,7 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     kfr[s] = lds_row_frag<T, DH>(sK, blk * 32, s, lane);
-    vfr[s] = lds_row_frag<T, DH>(sV, blk * 32, s, lane);
+    if (!LIGHT) vfr[s] = lds_row_frag<T, DH>(sV, blk * 32, s, lane);
   }
   typename Act<T>::vec8 ktr[2][DB];
 #pragma unroll
@@ -356,7 +357,7 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     x = Act<T>::mfma32(kfr[s], qf[s], x);
-    dp = Act<T>::mfma32(vfr[s], dof[s], dp);
+    if (!LIGHT) dp = Act<T>::mfma32(vfr[s], dof[s], dp);
   }
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
@@ -369,7 +370,7 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float pr = EXACT ? exact_prob(x[4 * g4 + e], scale, c0[e], c1[e], c2[e]) : fast_exp2(fmaf(x[4 * g4 + e], c0[e], c1[e]));
-      x[4 * g4 + e] = pr * fmaf(dp[4 * g4 + e], scale, -ds[e]);
+      x[4 * g4 + e] = LIGHT ? pr * (0.f - ds[e]) : pr * fmaf(dp[4 * g4 + e], scale, -ds[e]);
     }
   }
 #pragma unroll
@@ -645,16 +646,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 // One 32-query x 32-key tile of the key-owner backward. PASS 0: dV += P^T dO and delta += sum_q P dP;
 // PASS 1: dK += (P (dP s - delta s))^T Q. sQ / sdO are the staged query-side operands (rows >= S are zero, so query
 // rows beyond the sequence contribute nothing and need no guard).
-template <typename T, int DH, int PASS, bool EXACT>
+// LIGHT (PASS 1 only): the tile's dO rows are all zero, so dP = 0 and dL = -P * delta * s — no dO fragments, no dP MFMAs.
+template <typename T, int DH, int PASS, bool EXACT, bool LIGHT = false>
 __device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, float scale, const typename Act<T>::vec8 (&kf)[DH / 16],
                                             const typename Act<T>::vec8 (&vf)[DH / 16], float sk2, float ck2, float madd, float rmax,
                                             float logl, float& delta, float delta_s, f32x16 (&acc)[(DH + 31) / 32], int lane) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  static_assert(!LIGHT || PASS == 1, "a light tile contributes nothing to pass 0");
   typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     qfr[s] = lds_row_frag<T, DH>(sQ, qt * 32, s, lane);
-    dofr[s] = lds_row_frag<T, DH>(sdO, qt * 32, s, lane);
+    if (!LIGHT) dofr[s] = lds_row_frag<T, DH>(sdO, qt * 32, s, lane);
   }
   const T* tr_src = (PASS == 0) ? sdO : sQ;
 #pragma unroll
@@ -665,7 +668,7 @@ __device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, f
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     x = Act<T>::mfma32(qfr[s], kf[s], x);
-    dp = Act<T>::mfma32(dofr[s], vf[s], dp);
+    if (!LIGHT) dp = Act<T>::mfma32(dofr[s], vf[s], dp);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -673,6 +676,8 @@ __device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, f
     if (PASS == 0) {
       delta = fmaf(pr, dp[r], delta);
       x[r] = pr;
+    } else if (LIGHT) {
+      x[r] = pr * (0.f - delta_s);  // = pr * fmaf(0, scale, -delta_s): bit-identical to the full tile on zero dO rows
     } else {
       x[r] = pr * fmaf(dp[r], scale, -delta_s);
     }
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int DH>
+template <typename T, int DH, bool SPARSE>
 __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
@@ -808,9 +813,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
   const T* Vg = base + a.v_off;
   const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH;
+  // Sparse mode (0 < q_limit <= 32: dO is zero from row q_limit on — the top encoder layer, whose output is read at
+  // position 0 only): dP vanishes outside query block 0, so dV and delta need that block alone and every other
+  // tile of dK / dQ is the LIGHT form. Same arithmetic as the dense path on the zero rows, about 45 % of its work.
+  constexpr bool sparse = SPARSE;  // host: 0 < q_limit <= 32 (a separate instantiation keeps the dense kernel's registers)
+  const int64_t do_rows = sparse ? a.q_limit : S;  // rows of dO that are read; the staged tile is zero beyond them
   stage_all<T, DH>(bufA, Qg, a.ld_qkv, S, SP, tid, nthr);
-  stage_all<T, DH>(bufB, dOg, a.ld_dout, S, SP, tid, nthr);
+  stage_all<T, DH>(bufB, dOg, a.ld_dout, do_rows, SP, tid, nthr);
   __syncthreads();
+  const int nq0 = sparse ? 1 : NB;  // query tiles that contribute to pass 0
 
   // ---- phase A: dV, delta, dK for the owned keys (attn_bwd_kv_kernel's two passes over the query tiles)
   int padded = 0;
@@ -839,11 +850,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
       // four straight-line tile loops (pass x exact) instead of branches inside one: the merged form shuffled the
       // probability tile through 15 v_mov per tile to reconcile the two passes' register assignments
       if (pass == 0) {
-        if (exact_w) for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        else for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
       } else {
-        if (exact_w) for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        else for (int qt = 0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        if (exact_w) for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
+        else for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
       }
       if (pass == 0) {
         delta += __shfl_xor(delta, 32, 64);
@@ -880,12 +893,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
-      dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, S, s, lane);
+      dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, do_rows, s, lane);
     }
     f32x16 acc[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
-    if (exact) {
+    if (sparse && ob > 0) {  // this block's dO rows are zero
+      if (exact) for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+      else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+    } else if (exact) {
       for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
     } else {
       for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
@@ -965,14 +981,17 @@ template <typename T, int DH>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_bwd<DH>(a.S);
   if (const int nw = choose_resident(a.S, a.B * a.H, lds)) {
-    static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
-    if (lds > attr_lds) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_res_kernel<T, DH>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool sparse = a.q_limit > 0 && a.q_limit <= 32;
+    static size_t attr_lds[2] = {64 * 1024, 64 * 1024};  // dynamic LDS above 64 KB has to be opted into, per kernel
+    if (lds > attr_lds[sparse]) {
+      const void* fn = sparse ? reinterpret_cast<const void*>(&attn_bwd_res_kernel<T, DH, true>)
+                              : reinterpret_cast<const void*>(&attn_bwd_res_kernel<T, DH, false>);
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("attn_bwd_res_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
-      attr_lds = lds;
+      attr_lds[sparse] = lds;
     }
-    hipLaunchKernelGGL((attn_bwd_res_kernel<T, DH>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
+    if (sparse) hipLaunchKernelGGL((attn_bwd_res_kernel<T, DH, true>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
+    else hipLaunchKernelGGL((attn_bwd_res_kernel<T, DH, false>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
     MST_CHECK_LAUNCH("attn_bwd_res_kernel");
     return MST_OK;
   }
@@ -1013,7 +1032,7 @@ extern "C" int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t 
 extern "C" int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* qkv,
                                        int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
                                        const uint8_t* keymask, const float* lse, const void* dout, int64_t ld_dout,
-                                       void* dqkv, int64_t ld_dqkv, float* delta, mst_stream_t stream) {
+                                       void* dqkv, int64_t ld_dqkv, float* delta, int64_t q_limit, mst_stream_t stream) {
   int rc = attn_check(B, S, H, dh, ld_qkv, k_off, q_off, v_off);
   if (rc) return rc;
   MST_CHECK_ARG(qkv && keymask && lse && dout && dqkv && delta, "mst_attn_keysoftmax_bwd: null pointer");
@@ -1022,6 +1041,7 @@ extern "C" int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t 
   a.B = B; a.S = S; a.H = H; a.qkv = qkv; a.ld_qkv = ld_qkv; a.k_off = k_off; a.q_off = q_off; a.v_off = v_off;
   a.keymask = keymask; a.lse = const_cast<float*>(lse); a.dout = dout; a.ld_dout = ld_dout; a.dqkv = dqkv;
   a.ld_dqkv = ld_dqkv; a.delta = delta;
+  a.q_limit = (q_limit > 0 && q_limit < S) ? q_limit : 0;  // 0: dense dO
   a.scale = 1.f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(dtype, [&](auto tag) -> int {

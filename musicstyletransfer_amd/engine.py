@@ -612,7 +612,7 @@ class StepPlan:
             dproj = dh1_rows
         # d(attention output): rows b*S of a buffer that is zero elsewhere
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
-        o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D)
+        o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
         o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
         self._wgrads += [
             o.wgrad_problem(dff, row0(L.a), st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), M=B, N=D, K=4 * D),

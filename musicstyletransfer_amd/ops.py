@@ -111,9 +111,10 @@ def attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off, q_limit=0
          ptr(lse), ptr(out), ld(out), q_limit, stream())
 
 
-def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off):
+def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off, q_limit=0):
+    """q_limit > 0: rows [q_limit, S) of every sample of dout are zero (see the header)"""
     call("mst_attn_keysoftmax_bwd", dt(qkv), B, S, H, dh, ptr(qkv), ld(qkv), k_off, q_off, v_off, ptr(keymask),
-         ptr(lse), ptr(dout), ld(dout), ptr(dqkv), ld(dqkv), ptr(delta), stream())
+         ptr(lse), ptr(dout), ld(dout), ptr(dqkv), ld(dqkv), ptr(delta), q_limit, stream())
 
 
 # --------------------------------------------------------------------------- LayerNorm

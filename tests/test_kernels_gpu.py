@@ -256,6 +256,32 @@ def test_attention_q_limit_produces_only_the_first_queries(gpu, monkeypatch, pat
     assert (p3[:, 1:] == 5.0).all()
 
 
+@pytest.mark.parametrize("B,S,H,dh,ragged", [(2, 70, 2, 32, False), (8, 256, 2, 32, True), (3, 257, 2, 16, True)])
+def test_attention_bwd_q_limit_is_bit_identical_to_dense(gpu, B, S, H, dh, ragged):
+    """dO that is zero outside query 0 (the top encoder layer): the sparse mode skips work, not arithmetic"""
+    o = ops()
+    D = H * dh
+    qkv = rnd((B * S, 3 * D), gpu, seed=35)
+    lens = torch.tensor([S - ((i * 11) % (S // 3) if ragged else 0) for i in range(B)], dtype=torch.int32, device=gpu)
+    keymask = torch.zeros(B, S, dtype=torch.uint8, device=gpu)
+    o.mask_from_lengths(lens, 0, keymask)
+    lse = torch.zeros(2, B, H, S, dtype=torch.float32, device=gpu)
+    out = torch.zeros(B * S, D, dtype=BF, device=gpu)
+    o.attn_fwd(qkv, keymask, lse, out, B, S, H, dh, 0, D, 2 * D)
+    dout = torch.zeros(B, S, D, dtype=BF, device=gpu)
+    dout[:, 0] = rnd((B, D), gpu, seed=36)
+    dout = dout.view(B * S, D)
+    res = []
+    for q_limit in (0, 1):
+        dqkv = torch.full((B * S, 3 * D), 9.0, dtype=BF, device=gpu)
+        delta = torch.zeros(B, H, S, dtype=torch.float32, device=gpu)
+        o.attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
+        torch.cuda.synchronize()
+        res.append((dqkv.clone(), delta.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][0].float().abs().max().item() > 0
+
+
 @pytest.mark.parametrize("path", ["auto", "stream"])
 def test_attention_padded_key_rows_are_uniform(gpu, monkeypatch, path):
     """a padded key row is NOT excluded, it contributes V[k]/S to every query"""

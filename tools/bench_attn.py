@@ -18,7 +18,9 @@ def case(B, S, H, dh, iters, q_limit=0):
     lse = torch.zeros(2, B, H, S, device=dev); out = torch.zeros(B * S, D, dtype=BF, device=dev)
     dqkv = torch.zeros(B * S, 3 * D, dtype=BF, device=dev); delta = torch.zeros(B, H, S, device=dev)
     fwd = lambda: o.attn_fwd(qkv, km, lse, out, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
-    bwd = lambda: o.attn_bwd(qkv, km, lse, dout, dqkv, delta, B, S, H, dh, 0, D, 2 * D)
+    if q_limit:
+        dout.view(B, S, D)[:, q_limit:] = 0
+    bwd = lambda: o.attn_bwd(qkv, km, lse, dout, dqkv, delta, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
     res = []
     for fn in (fwd, bwd):
         fn(); torch.cuda.synchronize()
