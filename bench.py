@@ -101,7 +101,7 @@ def dominant_kernel_roofline(plan, o, iters=50):
             lambda: o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU),
             2.0 * M * 4 * De * De, 6 * cfg.e_layers,  # same-sized GEMMs per step: ff1/ff2 fwd + 2 dgrads each, per layer
             2.0 * (M * De + 4 * De * De + M * 4 * De) + 4.0 * 4 * De,  # x1 + W + a (16-bit) + fp32 bias
-            "gemm_nt_kernel<128,128,2,2>@%d" % (((M + 127) // 128) * ((4 * De + 127) // 128) * 256)),
+            "gemm_nt_kernel<128,128,2,2,64>@%d" % (((M + 127) // 128) * ((4 * De + 127) // 128) * 256)),
         "wgrad_kernel[enc layer: 4 problems, M=16384]": (
             lambda: o.gemm_wgrad_batch([
                 o.wgrad_problem(plan.be.dh, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=De, K=4 * De),
