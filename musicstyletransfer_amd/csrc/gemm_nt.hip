@@ -87,11 +87,21 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       uint32_t w = (uint32_t)((uint64_t)(mf * a.N + nc) >> 2);
       const uint32_t wstep = (uint32_t)((uint64_t)(RSTEP * a.N) >> 2);
       const float* sp = sF + row0 * LDS_F + ch * 8;
-#pragma unroll 2
-      for (int row = row0; row < WTM; row += RSTEP) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-        float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      constexpr int ITERS = WTM / RSTEP;
+      // every LDS read and every residual / gate load of the thread's chunks is issued before the first chunk is
+      // finished (at two waves per SIMD a chunk-by-chunk loop exposes one LDS + one global round trip per chunk)
+      f32x4 v0[ITERS], v1[ITERS];
+      u32x4 rv[ITERS], gv[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        v0[it] = *reinterpret_cast<const f32x4*>(sp + it * RSTEP * LDS_F);
+        v1[it] = *reinterpret_cast<const f32x4*>(sp + it * RSTEP * LDS_F + 4);
+        if (rp) rv[it] = *reinterpret_cast<const u32x4*>(rp + (int64_t)it * RSTEP * a.ldr);
+        if (gp) gv[it] = *reinterpret_cast<const u32x4*>(gp + (int64_t)it * RSTEP * a.ldg);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        float t[8] = {v0[it][0], v0[it][1], v0[it][2], v0[it][3], v1[it][0], v1[it][1], v1[it][2], v1[it][3]};
         if (a.bias) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] += bias8[e];
@@ -114,16 +124,14 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
           }
         }
         if (rp) {
-          Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(rp);
+          Pack8 p8; p8.u = rv[it];
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
-          rp += (int64_t)RSTEP * a.ldr;
         }
         if (gp) {  // ReLU backward: pass where the forward activation was positive
-          Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(gp);
+          Pack8 p8; p8.u = gv[it];
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] = (bits_to_f32<T>(p8.h[e]) > 0.f) ? t[e] : 0.f;
-          gp += (int64_t)RSTEP * a.ldg;
         }
         u32x4 o;
 #pragma unroll
@@ -132,7 +140,6 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
         *reinterpret_cast<u32x4*>(cp) = o;
         cp += (int64_t)RSTEP * a.ldc;
         w += wstep;
-        sp += RSTEP * LDS_F;
       }
     } else
     if (nc < n_store) {
