@@ -64,15 +64,16 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const T* resid = reinterpret_cast<const T*>(a.resid);
   const T* gate = reinterpret_cast<const T*>(a.gate);
 
+  // every wave stages its accumulators at once (the launch sizes LDS for the whole BM x (BN+4) fp32 tile): one barrier
+  // per workgroup instead of two per wave-row pass
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+  __syncthreads();
   for (int pass = 0; pass < WGM; ++pass) {
-    if (wm == pass) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4*>(sF + (i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
-    }
-    __syncthreads();
+    const float* sFp = sF + pass * WTM * LDS_F;  // this row block of the staged tile
     // Fast path (interior tile, 16-bit output, no row remap / row-indexed adds, < 2^32 output elements): the row
     // loop carries pointers and a 32-bit dropout counter forward by constant strides. At two waves per SIMD the
     // epilogue is VALU-bound (measured per workgroup: 7.7 us of a 13.9 us life in FFN1, most of it 64-bit address
@@ -86,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       const T* gp = gate ? gate + mf * a.ldg + nc : nullptr;
       uint32_t w = (uint32_t)((uint64_t)(mf * a.N + nc) >> 2);
       const uint32_t wstep = (uint32_t)((uint64_t)(RSTEP * a.N) >> 2);
-      const float* sp = sF + row0 * LDS_F + ch * 8;
+      const float* sp = sFp + row0 * LDS_F + ch * 8;
       constexpr int ITERS = WTM / RSTEP;
       // every LDS read and every residual / gate load of the thread's chunks is issued before the first chunk is
       // finished (at two waves per SIMD a chunk-by-chunk loop exposes one LDS + one global round trip per chunk)
@@ -148,8 +149,8 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
         const int64_t m = m0 + pass * WTM + row;
         if (m >= a.M) break;
         const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + ch * 8 + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sFp + row * LDS_F + ch * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sFp + row * LDS_F + ch * 8 + 4);
         float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         // Optional features are wave-uniform branches per 8-column chunk (a branch costs less than 8 neutral
         // operations; per-ELEMENT tests in accumulator layout had made the kernel issue-bound).
@@ -233,7 +234,6 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
         }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -358,14 +358,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
     __syncthreads();
   }
 
-  static_assert((size_t)(BM / WGM) * (BN + 4) * 4 <= (size_t)2 * (BM + BN) * BK * 2, "epilogue staging must fit the K-loop's LDS");
+  // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int BK = 64>
 static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+  const size_t lds_loop = (size_t)2 * (BM + BN) * BK * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
     static bool opted[2] = {false, false};
