@@ -13,7 +13,9 @@ on a side HIP stream while the previous step computes."""
 import numpy as np
 import torch
 
-from .MIDIUtil.Melody import NoteOffEvent, NoteOnEvent, TimeshiftEvent
+from .MIDIUtil.defaults import MAX_TICKS, NUM_TICKS_IN_A_BIN
+from .MIDIUtil.Melody import (Melody, NoteOffEvent, NoteOnEvent, TimeshiftEvent, create_note_off_event, create_note_on_event,
+                              create_timeshift_event)
 from .VarAutoEncoder.data import Batch, _ArrayDataset
 
 N_PITCHES = 128
@@ -43,6 +45,47 @@ def melody_to_pianoroll(melody, slices_per_quarter=None, n_pitches=N_PITCHES):
             b = max(a + 1, int(np.ceil(end / ticks_per_frame)))
             roll[a:b, pitch] = 1
     return roll
+
+
+def pianoroll_to_melody(roll, slices_per_quarter=4, resolution=None, description=""):
+    """Inverse of melody_to_pianoroll: {0,1}^[frames, pitches] -> event melody (note-on / note-off / time-shift ids of
+    defaults.py), ready for MIDIUtil.midi_io.MelodyWriter. A pitch that is 1 in consecutive frames is ONE held note.
+    Time is carried by time-shift events, which exist in bins of NUM_TICKS_IN_A_BIN ticks below MAX_TICKS
+    (Melody.py:117-126), so a frame must be a whole number of bins: with the default resolution (a multiple of
+    30 * slices_per_quarter is chosen when none is given) the round trip melody -> roll -> melody -> roll is exact."""
+    roll = np.asarray(roll)
+    assert roll.ndim == 2
+    m = Melody(slices_per_quarter=slices_per_quarter, description=description)
+    if resolution is None:
+        resolution = NUM_TICKS_IN_A_BIN * slices_per_quarter * 4  # 480 at 4 slices per quarter: 120 ticks = 4 bins a frame
+    m.resolution = resolution
+    tpf = resolution / float(slices_per_quarter)
+    assert tpf >= NUM_TICKS_IN_A_BIN and abs(tpf / NUM_TICKS_IN_A_BIN - round(tpf / NUM_TICKS_IN_A_BIN)) < 1e-9, \
+        "a frame must be a whole number of {}-tick bins (resolution {}, {} slices per quarter)".format(
+            NUM_TICKS_IN_A_BIN, resolution, slices_per_quarter)
+    tpf = int(round(tpf))
+    max_shift = (MAX_TICKS - 1) // NUM_TICKS_IN_A_BIN * NUM_TICKS_IN_A_BIN  # largest representable shift (990)
+    events, pending = [], 0
+
+    def flush():
+        nonlocal pending
+        while pending > 0:
+            step = min(pending, max_shift)
+            events.append(create_timeshift_event(step))
+            pending -= step
+
+    prev = np.zeros(roll.shape[1], bool)
+    for f in range(roll.shape[0] + 1):
+        cur = roll[f] > 0 if f < roll.shape[0] else np.zeros(roll.shape[1], bool)
+        offs, ons = np.nonzero(prev & ~cur)[0], np.nonzero(cur & ~prev)[0]
+        if len(offs) or len(ons):
+            flush()
+            events += [create_note_off_event(int(p)) for p in offs]
+            events += [create_note_on_event(int(p)) for p in ons]
+        pending += tpf
+        prev = cur
+    m.notes = events
+    return m
 
 
 def pianoroll_arrays(melodies, frames_per_sample, slices_per_quarter=4, n_pitches=N_PITCHES):

@@ -127,3 +127,23 @@ def test_checkpoint_and_resume(gpu, tmp_path):
     assert t2.train_state.n_batches == 21, t2.train_state.__dict__
     steps = int(t2.model.store.step_state[0].item())
     assert steps == 21, f"Adam step counter {steps}: optimizer state was not restored"
+
+
+def test_reconstruction_sampler_writes_midi(gpu, tmp_path):
+    """the trainer's sampler hook writes the batch's reconstruction as .mid files (both ends)"""
+    from music_style_transfer.VarAutoEncoder import main
+    from music_style_transfer.MIDIUtil.midi_io import EventBasedMIDIReader
+    for extra, kind in ((["--pianoroll"], "pianoroll"), ([], "token")):
+        flags = [f for f in SCRIPT_FLAGS]
+        flags[flags.index("--sampling-frequency") + 1] = "3"
+        flags[flags.index("--latent-dim") + 1] = "64"
+        out = tmp_path / kind
+        t = main.main(flags + extra + ["--data", MIDI, "--model-output", str(out / "m"), "--out-samples", str(out / "s"),
+                                       "--max-steps", "4"])
+        assert t.model.engine_config.kind == kind
+        found = []
+        for root, _, files in os.walk(str(out)):
+            found += [os.path.join(root, f) for f in files if f.startswith("reconstruction_") and f.endswith(".mid")]
+        assert found, "the sampler hook wrote no reconstruction"
+        melodies = EventBasedMIDIReader().read_file(found[0])  # parses as a standard MIDI file
+        assert isinstance(melodies, list)
