@@ -110,6 +110,33 @@ typedef struct mst_gemm_args {
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Dense + LayerNorm in one launch (transformer.py:155,158,197,200 forward; their autograd backward): the GEMM's tile
+ * spans the whole output row (N = 128 or 256), so the row statistics are available in its epilogue.
+ *   mode 1, forward : C = h = epi(A B^T) as mst_gemm_nt (bias, alpha, dropout / self_resid, resid, C row remap);
+ *                     out = LayerNorm(h; gamma, beta, eps); mean[r], rstd[r] with r = PHYSICAL C row.
+ *                     Equals mst_gemm_nt followed by mst_layernorm_fwd on C.
+ *   mode 2, backward: dy = epi(A B^T) (bias, alpha, resid) is NOT stored; C = dx = LayerNorm backward of dy with
+ *                     x (the forward's pre-norm tensor), mean, rstd all taken at the PHYSICAL C row r (the forward
+ *                     wrote them there), gamma; out = dropout-masked copy of dx (mask_mode 1) at the LOGICAL row m;
+ *                     dgamma / dbeta accumulated into.
+ *                     mask modes and the dropout counter (p / seed / site in the mst_gemm_args dropout fields) are
+ *                     those of mst_layernorm_bwd. Equals mst_gemm_nt followed by mst_layernorm_bwd on its result.
+ * ------------------------------------------------------------------------ */
+typedef struct mst_ln_args {
+  int32_t mode;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  void* out; int64_t ld_out;
+  float* mean; float* rstd;
+  const void* x; int64_t ld_x;
+  float* dgamma; float* dbeta;
+  int32_t mask_mode;
+} mst_ln_args;
+
+int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Weight gradient: dW[N,K] (+)= sum_m A[m,n] * B[m,k]   (A = dY [M,N], B = X [M,K])
  * plus optional bias gradient db[n] += sum_m A[m,n].
  * Autograd counterpart of the Dense call sites above (trainer.py:176).

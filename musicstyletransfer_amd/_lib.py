@@ -40,6 +40,18 @@ class GemmArgs(C.Structure):
     ]
 
 
+class LnArgs(C.Structure):
+    _fields_ = [
+        ("mode", c_i32),
+        ("gamma", vp), ("beta", vp), ("eps", c_f32),
+        ("out", vp), ("ld_out", c_i64),
+        ("mean", vp), ("rstd", vp),
+        ("x", vp), ("ld_x", c_i64),
+        ("dgamma", vp), ("dbeta", vp),
+        ("mask_mode", c_i32),
+    ]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("dtype", c_i32),
@@ -69,6 +81,7 @@ SIGNATURES = {
     "mst_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(c_f32)]),
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "mst_gemm_wgrad_batch": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
     "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,

@@ -237,8 +237,11 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
+// The tile's K loop, shared by the kernels below: locates the workgroup's tile (m0, n0) and leaves the fp32
+// accumulators in `acc`; on return every wave has passed the loop's last barrier, so `smem` is free to reuse.
+template <typename T, int BM, int BN, int WGM, int WGN, int BK>
+__device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
+                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0) {
   constexpr int CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
@@ -247,7 +250,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   static_assert(BM * CHUNKS % NT == 0 && BN * CHUNKS % NT == 0, "tile/threads mismatch");
   typedef typename Act<T>::vec8 vec8;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* sA = reinterpret_cast<u32x4*>(smem);                    // [2][BM*CHUNKS]
   u32x4* sB = sA + 2 * BM * CHUNKS;                              // [2][BN*CHUNKS]
 
@@ -265,8 +267,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
     const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
   }
-  const int64_t m0 = (bid / tiles_n) * BM;
-  const int64_t n0 = (bid % tiles_n) * BN;
+  m0 = (bid / tiles_n) * BM;
+  n0 = (bid % tiles_n) * BN;
 
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
   const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
@@ -315,7 +317,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
     for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
   };
 
-  f32x4 acc[TN][TM];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -357,9 +358,208 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
     if (t + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
+}
 
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+  int64_t m0, n0;
+  gemm_mainloop<T, BM, BN, WGM, WGN, BK>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm fused into the epilogue of a GEMM whose tile spans the whole output row (BN == N).
+//   mode 1 (forward):  h = epi(acc) is written to C as usual (the backward pass needs the pre-norm tensor) and
+//                      y = LayerNorm(h) goes to ln.out, mean / rstd to ln.mean / ln.rstd — what mst_layernorm_fwd would
+//                      compute from C (two-pass statistics on the 16-bit-rounded row, gluon.nn.LayerNorm eps).
+//   mode 2 (backward): dy = epi(acc) is NOT stored; dx = LayerNorm-backward(dy; x, mean, rstd, gamma) goes to C, the
+//                      dropout-masked copy (mask_mode 1) to ln.out, dgamma / dbeta are accumulated — mst_layernorm_bwd
+//                      on the GEMM's result, without the round trip through HBM and without its launch.
+// Supported epilogue features: bias, alpha, dropout / self_resid, residual, C row remap (the others are rejected on the
+// host). One thread finishes 8 columns of a row; the N/8 threads of a row are consecutive lanes, so row sums are
+// xor-shuffles inside a 32- or 16-lane group.
+template <int LANES>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
+__device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
+                                                 f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
+  static_assert(CPR == 32 || CPR == 16, "a row must be a 32- or 16-lane group");
+  static_assert(BM % RSTEP == 0, "rows per thread must be whole");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int frow = lane & 15, fq = lane >> 4;
+  float* sF = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+  __syncthreads();
+
+  const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
+  const float inv_n = 1.f / (float)BN;
+  const float inv_keep = dropout_inv_keep(a.dropout_p);
+  const bool has_drop = a.dropout_p > 0.f;
+  const uint64_t dseed = a.dropout_seed ^ ((has_drop && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
+  const uint32_t dkey = dropout_key(dseed, a.dropout_site), dthr = dropout_thr(a.dropout_p);
+  const T* resid = reinterpret_cast<const T*>(a.resid);
+  float bias8[8], gam8[8], bet8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = a.bias ? a.bias[nc + e] : 0.f;
+    gam8[e] = l.gamma[nc + e];
+    bet8[e] = (MODE == 1) ? l.beta[nc + e] : 0.f;
+  }
+  float dg8[8], db8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg8[e] = 0.f; db8[e] = 0.f; }
+
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = row0 + it * RSTEP;
+    const int64_t m = m0 + row;
+    if (m < a.M) {  // uniform for the lanes of a row
+      const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
+      float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      // ---- the GEMM's own epilogue (same order as gemm_epilogue): bias, alpha, dropout / self_resid, residual
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (t[e] + bias8[e]) * a.alpha;
+      if (MODE == 1 && (has_drop || a.self_resid)) {
+        uint32_t keep8 = 0xFFu;
+        if (has_drop) {
+          const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;
+          keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
+          t[e] = a.self_resid ? t[e] + u : u;
+        }
+      }
+      if (resid) {
+        Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
+      }
+      // the value the unfused pipeline would have stored and re-read: round to the activation type first
+      Pack8 hb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hb.h[e] = f32_to_bits<T>(t[e]); t[e] = bits_to_f32<T>(hb.h[e]); }
+      if (MODE == 1) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + pm * a.ldc + nc) = hb.u;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += t[e];
+        const float mean = row_sum<CPR>(s) * inv_n;
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t[e] -= mean; ss += t[e] * t[e]; }
+        const float rstd = 1.f / sqrtf(row_sum<CPR>(ss) * inv_n + l.eps);
+        Pack8 yb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yb.h[e] = f32_to_bits<T>(t[e] * rstd * gam8[e] + bet8[e]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(l.out) + pm * l.ld_out + nc) = yb.u;
+        if (ch == 0) { l.mean[pm] = mean; l.rstd[pm] = rstd; }
+      } else {
+        const int64_t rid = pm;  // x, the statistics and the forward's dropout counter live at the PHYSICAL row of C
+        const float mean = l.mean[rid], rstd = l.rstd[rid];
+        Pack8 xb; xb.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(l.x) + pm * l.ld_x + nc);
+        float xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[e] = (bits_to_f32<T>(xb.h[e]) - mean) * rstd;
+          g[e] = t[e] * gam8[e];
+          s1 += g[e];
+          s2 += g[e] * xh[e];
+          dg8[e] += t[e] * xh[e];
+          db8[e] += t[e];
+        }
+        s1 = row_sum<CPR>(s1) * inv_n;
+        s2 = row_sum<CPR>(s2) * inv_n;
+        uint32_t keep8 = 0xFFu;
+        if (l.mask_mode != 0 && has_drop) {
+          const uint64_t w = (uint64_t)(rid * BN + nc) >> 2;  // the forward's counter: forward row id, N == BN columns
+          keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
+        }
+        Pack8 ob, mb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float o = rstd * (g[e] - s1 - xh[e] * s2);
+          float om = 0.f;
+          if (l.mask_mode != 0) {
+            const float k = has_drop ? (((keep8 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
+            if (l.mask_mode == 1) om = o * k; else o = o * (1.f + k);
+          }
+          ob.h[e] = f32_to_bits<T>(o);
+          mb.h[e] = f32_to_bits<T>(om);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + pm * a.ldc + nc) = ob.u;
+        if (l.mask_mode == 1) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(l.out) + m * l.ld_out + nc) = mb.u;
+      }
+    }
+  }
+  if (MODE == 2) {
+    // dgamma / dbeta: sum the RSTEP row groups through LDS (the staged tile is dead), one atomic per column per workgroup
+    __syncthreads();
+    float* red = sF;  // [2][RSTEP][BN]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[row0 * BN + nc + e] = dg8[e];
+      red[(RSTEP + row0) * BN + nc + e] = db8[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int which = c / BN, col = c % BN;
+      float s = 0.f;
+      for (int r = 0; r < RSTEP; ++r) s += red[(which * RSTEP + r) * BN + col];
+      atomicAdd((which ? l.dbeta : l.dgamma) + col, s);
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_args a, mst_ln_args l) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+  int64_t m0, n0;
+  gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(a, l, smem, acc, m0);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_gemm_ln(const mst_gemm_args& a, const mst_ln_args& l, hipStream_t s) {
+  const size_t lds_loop = (size_t)2 * (BM + BN) * 64 * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  dim3 grid((unsigned)cdiv(a.M, BM)), block(WGM * WGN * 64);
+  const int mi = l.mode == 2 ? 1 : 0;
+  const void* fn = mi ? reinterpret_cast<const void*>(&gemm_nt_ln_kernel<T, BM, BN, WGM, WGN, 2>)
+                      : reinterpret_cast<const void*>(&gemm_nt_ln_kernel<T, BM, BN, WGM, WGN, 1>);
+  if (lds > 64 * 1024) {
+    static bool opted[2] = {false, false};
+    if (!opted[mi]) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("gemm_nt_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted[mi] = true;
+    }
+  }
+  if (mi) hipLaunchKernelGGL((gemm_nt_ln_kernel<T, BM, BN, WGM, WGN, 2>), grid, block, lds, s, a, l);
+  else hipLaunchKernelGGL((gemm_nt_ln_kernel<T, BM, BN, WGM, WGN, 1>), grid, block, lds, s, a, l);
+  MST_CHECK_LAUNCH("gemm_nt_ln_kernel");
+  return MST_OK;
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int BK = 64>
@@ -389,6 +589,52 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
 }  // namespace mst
 
 using namespace mst;
+
+static int check_gemm_common(const mst_gemm_args& a) {
+  MST_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "mst_gemm_nt: M,N,K must be positive (got %lld,%lld,%lld)",
+                (long long)a.M, (long long)a.N, (long long)a.K);
+  MST_CHECK_ARG(a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0,
+                "mst_gemm_nt: K, lda, ldb must be multiples of 8 (got %lld,%lld,%lld)", (long long)a.K,
+                (long long)a.lda, (long long)a.ldb);
+  MST_CHECK_ARG(a.A && a.B && a.C, "mst_gemm_nt: null operand");
+  MST_CHECK_ARG(a.dropout_p >= 0.f && a.dropout_p < 1.f, "mst_gemm_nt: dropout_p must be in [0,1)");
+  MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.C % 16 == 0),
+                "mst_gemm_nt: operands must be 16-byte aligned");
+  return MST_OK;
+}
+
+extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && ln != nullptr, "mst_gemm_nt_ln: null args");
+  const mst_gemm_args& a = *args;
+  const mst_ln_args& l = *ln;
+  int rc = check_gemm_common(a);
+  if (rc) return rc;
+  MST_CHECK_ARG(a.N == 256 || a.N == 128, "mst_gemm_nt_ln: the row width N must be 128 or 256 (got %lld): use mst_gemm_nt + "
+                "mst_layernorm_* for other widths", (long long)a.N);
+  MST_CHECK_ARG(l.mode == 1 || l.mode == 2, "mst_gemm_nt_ln: mode must be 1 (forward) or 2 (backward)");
+  MST_CHECK_ARG(!a.c_f32 && !a.gate && !a.rowadd && !a.grpadd && a.act == MST_ACT_NONE,
+                "mst_gemm_nt_ln: fp32 output, gate, rowadd, grpadd and activations are not supported in the fused form");
+  MST_CHECK_ARG(a.ldc % 8 == 0 && a.ldc >= a.N, "mst_gemm_nt_ln: ldc must be a multiple of 8 and >= N");
+  MST_CHECK_ARG(!a.resid || (a.ldr % 8 == 0 && a.ldr >= a.N && (uintptr_t)a.resid % 16 == 0), "mst_gemm_nt_ln: bad residual layout");
+  MST_CHECK_ARG(l.gamma && l.mean && l.rstd, "mst_gemm_nt_ln: gamma / mean / rstd are required");
+  if (l.mode == 1) {
+    MST_CHECK_ARG(l.beta && l.out && l.ld_out % 8 == 0 && l.ld_out >= a.N && (uintptr_t)l.out % 16 == 0, "mst_gemm_nt_ln: forward needs beta and out");
+  } else {
+    MST_CHECK_ARG(l.x && l.ld_x % 8 == 0 && (uintptr_t)l.x % 16 == 0 && l.dgamma && l.dbeta,
+                  "mst_gemm_nt_ln: backward needs x, dgamma and dbeta");
+    MST_CHECK_ARG(l.mask_mode >= 0 && l.mask_mode <= 2, "mst_gemm_nt_ln: mask_mode must be 0, 1 or 2");
+    MST_CHECK_ARG(l.mask_mode != 1 || (l.out && l.ld_out % 8 == 0 && l.ld_out >= a.N && (uintptr_t)l.out % 16 == 0),
+                  "mst_gemm_nt_ln: mask_mode 1 needs out");
+    MST_CHECK_ARG(!a.self_resid, "mst_gemm_nt_ln: self_resid belongs to the forward form");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    // 8 waves on a 64-row x full-width tile: measured equal to the 64x64 tiles of the unfused launches
+    if (a.N == 256) return launch_gemm_ln<T, 64, 256, 2, 4>(a, l, s);
+    return launch_gemm_ln<T, 64, 128, 2, 4>(a, l, s);
+  });
+}
 
 extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr, "mst_gemm_nt: null args");

@@ -457,19 +457,20 @@ class StepPlan:
             return self._top_encoder_layer_fwd(i, L, x_in)
         o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
         o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
+        # (Dense + LayerNorm in one launch, ops.gemm_nt_ln_fwd, does not pay in the forward pass: graph-replay timings at
+        # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
+        # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM
+        # as much. The backward forms, where the LayerNorm launch is 16 us, do pay: _layer_bwd.)
         o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
                   resid=x_in, **self._drop(p, site0))
         o.layernorm_fwd(L.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), L.x1, L.mean1, L.rstd1, D=D)
         o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU,
                   **self._drop(p, site0 + 1))
-        if side == "encoder":
-            o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1,
-                      **self._drop(p, site0 + 2))
-            ln = "ln2"
-        else:  # transformer.py:199-200: LN3(ff + dropout(ff))
-            o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), self_resid=True,
-                      **self._drop(p, site0 + 2))
-            ln = "ln3"
+        # encoder: LN2(x1 + dropout(ff)); decoder (transformer.py:199-200): LN3(ff + dropout(ff))
+        ln = "ln2" if side == "encoder" else "ln3"
+        ff2 = dict(K=4 * D, bias=st.p(f"{pre}.ff2.bias"), **self._drop(p, site0 + 2))
+        ff2.update(dict(resid=L.x1) if side == "encoder" else dict(self_resid=True))
+        o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, **ff2)
         o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
         return L.x2
 
@@ -529,44 +530,68 @@ class StepPlan:
         o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
 
     # ------------------------------------------------------------------------------ backward
-    def _layer_bwd(self, side, i, L, x_in, dy, dx_in, keymask, D, H, S, p, site0, t):
-        """dy: gradient w.r.t. the layer output x2; writes the gradient w.r.t. x_in into dx_in."""
+    def _out_ln_bwd(self, side, i, L, D, p, site0, t):
+        """The LayerNorm backward a layer's backward pass STARTS with (LN2 of an encoder layer, LN3 of a decoder layer),
+        as keyword arguments for ops.gemm_nt_ln_bwd: the GEMM that produces the layer's incoming gradient runs it in
+        its epilogue (dX_out = t.dh) when the row width allows, see _layer_bwd(dy_done=...)."""
+        st = self.store
+        pre = f"{side}.layer{i}"
+        ln = "ln2" if side == "encoder" else "ln3"
+        kw = dict(x=L.h2, gamma=st.p(f"{pre}.{ln}.gamma"), mean=L.mean2, rstd=L.rstd2, dgamma=st.grad(f"{pre}.{ln}.gamma"),
+                  dbeta=st.grad(f"{pre}.{ln}.beta"))
+        if side == "encoder":
+            kw.update(dict(mask_mode=1, dx_masked=t.dhm) if p > 0 else dict(mask_mode=0))
+        else:
+            kw.update(mask_mode=2)
+        if p > 0:
+            kw.update(dropout_p=p, dropout_seed_ptr=self.rng_state, dropout_site=site0 + 2)
+        return kw
+
+    def _layer_bwd(self, side, i, L, x_in, dy, dx_in, keymask, D, H, S, p, site0, t, dy_done=False, next_ln=None):
+        """dy: gradient w.r.t. the layer output x2; writes the gradient w.r.t. x_in into dx_in.
+        dy_done: the producer of dy already ran this layer's leading LayerNorm backward (t.dh / t.dhm are filled).
+        next_ln: (_out_ln_bwd(...) of the layer below, its scratch): run THAT layer's leading LayerNorm backward in the
+        epilogue of this layer's last GEMM instead of writing dx_in."""
         st = self.store
         pre = f"{side}.layer{i}"
         dhd = D // H
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
+        fuse = o.can_fuse_ln(D)
         if side == "encoder":
-            ln = "ln2"
-            if p > 0:
-                o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
-                                st.grad(f"{pre}.ln2.beta"), D=D, dx_masked=t.dhm, mask_mode=1, dropout_site=site0 + 2, **dk)
-                dff = t.dhm
-            else:
-                o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
-                                st.grad(f"{pre}.ln2.beta"), D=D)
-                dff = t.dh
+            if not dy_done:
+                if p > 0:
+                    o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
+                                    st.grad(f"{pre}.ln2.beta"), D=D, dx_masked=t.dhm, mask_mode=1, dropout_site=site0 + 2, **dk)
+                else:
+                    o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
+                                    st.grad(f"{pre}.ln2.beta"), D=D)
+            dff = t.dhm if p > 0 else t.dh
             resid_ff = t.dh
         else:
-            ln = "ln3"
-            o.layernorm_bwd(L.h2, st.p(f"{pre}.ln3.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln3.gamma"),
-                            st.grad(f"{pre}.ln3.beta"), D=D, mask_mode=2, dropout_site=site0 + 2, **dk)
+            if not dy_done:
+                o.layernorm_bwd(L.h2, st.p(f"{pre}.ln3.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln3.gamma"),
+                                st.grad(f"{pre}.ln3.beta"), D=D, mask_mode=2, dropout_site=site0 + 2, **dk)
             dff = t.dh
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
         o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
-        o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
-        if p > 0:
-            o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
-                            st.grad(f"{pre}.ln1.beta"), D=D, dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk)
-            dproj = t.dh1m
+        ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
+        if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
+            o.gemm_nt_ln_bwd(t.dpre, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1,
+                             st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), N=D, K=4 * D, resid=resid_ff, **ln1)
         else:
+            o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
             o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
-                            st.grad(f"{pre}.ln1.beta"), D=D)
-            dproj = t.dh1
+                            st.grad(f"{pre}.ln1.beta"), D=D, **ln1)
+        dproj = t.dh1m if p > 0 else t.dh1
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
-        o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
+        if next_ln is not None:  # the layer below starts its backward pass with a LayerNorm backward: run it here
+            kw, t_below = next_ln
+            o.gemm_nt_ln_bwd(t.dqkv, st.t(f"{pre}.att.W_kqv"), t_below.dh, N=D, K=3 * D, resid=t.dh1, **kw)
+        else:
+            o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
         # the layer's four weight gradients: deferred to the ONE wgrad launch at the end of backward() (their operands
         # live in this layer's own scratch `t` and in the forward activations, so nothing is overwritten meanwhile)
         self._wgrads += [
@@ -576,7 +601,7 @@ class StepPlan:
             o.wgrad_problem(t.dqkv, x_in, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * D, K=D),
         ]
 
-    def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t):
+    def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t, next_ln=None):
         """_layer_bwd for the LAST encoder layer, on the B rows (position 0 of each sample) that carry gradient."""
         cfg, st, B, S = self.cfg, self.store, self.B, self.T
         D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, 3 * i
@@ -613,7 +638,11 @@ class StepPlan:
         # d(attention output): rows b*S of a buffer that is zero elsewhere
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
         o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
-        o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
+        if next_ln is not None:  # as in _layer_bwd: the layer below's LayerNorm-2 backward rides on this GEMM
+            kw, t_below = next_ln
+            o.gemm_nt_ln_bwd(t.dqkv, st.t(f"{pre}.att.W_kqv"), t_below.dh, N=D, K=3 * D, resid=self.sp_dh1, **kw)
+        else:
+            o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=self.sp_dh1)
         self._wgrads += [
             o.wgrad_problem(dff, row0(L.a), st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), M=B, N=D, K=4 * D),
             o.wgrad_problem(c.dpre, row0(L.x1), st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), M=B, N=4 * D, K=D),
@@ -646,15 +675,24 @@ class StepPlan:
         # (the gradient bucket was cleared by forward()'s step_begin launch)
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
-        o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
+        fuse_d, fuse_e = o.can_fuse_ln(Dd), o.can_fuse_ln(De)
+        site_d = 3 * cfg.e_layers
+        last = cfg.d_layers - 1
+        if fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
+            o.gemm_nt_ln_bwd(self.dlogits, st.t("decoder.output_layer.weight"), self.bd_l[last].dh, M=B * T, N=Dd, K=ldv,
+                             c_remap=(T, Sd, 1),
+                             **self._out_ln_bwd("decoder", last, self.dec[last], Dd, cfg.d_dropout, site_d + 3 * last, self.bd_l[last]))
+        else:
+            o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
         self._wgrads = [o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
                                         st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1))]
         dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
-        site_d = 3 * cfg.e_layers
         for i in reversed(range(cfg.d_layers)):
             x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d
+            below = (self._out_ln_bwd("decoder", i - 1, self.dec[i - 1], Dd, cfg.d_dropout, site_d + 3 * (i - 1), self.bd_l[i - 1]),
+                     self.bd_l[i - 1]) if (fuse_d and i > 0) else None
             self._layer_bwd("decoder", i, self.dec[i], x_in, dy, tgt, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout,
-                            site_d + 3 * i, self.bd_l[i])
+                            site_d + 3 * i, self.bd_l[i], dy_done=fuse_d, next_ln=below)
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_d = dy  # gradient w.r.t. the decoder input [B, Sd, Dd]
         # ---- decoder input: rows 1..T -> embedding, row 0 -> latent block
@@ -674,7 +712,9 @@ class StepPlan:
                      enc_scale=self.gscale_enc / self.gscale)
         top = cfg.e_layers - 1
         x_in = self.enc[top - 1].x2 if top > 0 else self.x0_e
-        self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top])
+        below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, 3 * (top - 1), self.be_l[top - 1]),
+                 self.be_l[top - 1]) if (fuse_e and top > 0) else None
+        self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top], next_ln=below)
         if flush and cfg.e_layers >= 2:
             o.gemm_wgrad_batch(self._wgrads)
             self._wgrads = []
@@ -685,10 +725,13 @@ class StepPlan:
         De, Se = cfg.e_model, T
         sq_e = math.sqrt(float(De))
         dy, tgt, nxt = self.be_l[0].dx_a, self.be_l[0].dx_b, self.be_l[0].dx_a  # the top layer wrote dx_a
+        fuse_e = o.can_fuse_ln(De)  # then every layer's leading LayerNorm backward already ran in the GEMM above it
         for i in reversed(range(cfg.e_layers - 1)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
+            below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, 3 * (i - 1), self.be_l[i - 1]),
+                     self.be_l[i - 1]) if (fuse_e and i > 0) else None
             self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
-                            3 * i, self.be_l[i])
+                            3 * i, self.be_l[i], dy_done=fuse_e, next_ln=below)
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_e = dy
         if cfg.kind == "token":

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -44,10 +44,9 @@ def ld(t):
 
 
 # --------------------------------------------------------------------------- GEMMs
-def gemm_nt(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_NONE, gate=None, alpha=1.0,
-            rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
-            dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None):
-    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T); see mst_gemm_args in include/mst_hip.h."""
+def _gemm_args(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_NONE, gate=None, alpha=1.0,
+               rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
+               dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None):
     g = GemmArgs()
     g.dtype = dt(A)
     g.c_f32 = 1 if C_out.dtype == torch.float32 else 0
@@ -71,7 +70,43 @@ def gemm_nt(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_
     g.dropout_p, g.dropout_seed, g.dropout_site = dropout_p, dropout_seed, dropout_site
     g.self_resid = 1 if self_resid else 0
     g.dropout_seed_ptr = ptr(dropout_seed_ptr)
-    call("mst_gemm_nt", C.byref(g), stream())
+    return g
+
+
+def gemm_nt(A, B, C_out, **kw):
+    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T); see mst_gemm_args in include/mst_hip.h."""
+    call("mst_gemm_nt", C.byref(_gemm_args(A, B, C_out, **kw)), stream())
+
+
+def can_fuse_ln(D):
+    """row widths the LayerNorm-fused GEMM exists for (mst_gemm_nt_ln)"""
+    return D in (128, 256)
+
+
+def gemm_nt_ln_fwd(A, B, H_out, gamma, beta, Y_out, mean, rstd, eps=1e-5, **kw):
+    """H_out = epilogue(A @ B^T) and Y_out = LayerNorm(H_out) in one launch (mst_gemm_nt_ln, mode 1); the statistics
+    are indexed by H_out's physical row"""
+    g = _gemm_args(A, B, H_out, **kw)
+    l = LnArgs()
+    l.mode, l.gamma, l.beta, l.eps = 1, ptr(gamma), ptr(beta), eps
+    l.out, l.ld_out = ptr(Y_out), ld(Y_out)
+    l.mean, l.rstd = ptr(mean), ptr(rstd)
+    call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
+
+
+def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, **kw):
+    """dX_out = LayerNorm-backward(epilogue(A @ B^T); x, mean, rstd, gamma) in one launch (mst_gemm_nt_ln, mode 2); x, mean,
+    rstd are indexed by dX_out's physical row, dx_masked by the logical row; the dropout fields among **kw are those of
+    the LayerNorm-backward mask"""
+    g = _gemm_args(A, B, dX_out, **kw)
+    l = LnArgs()
+    l.mode, l.gamma = 2, ptr(gamma)
+    l.mean, l.rstd = ptr(mean), ptr(rstd)
+    l.x, l.ld_x = ptr(x), ld(x)
+    l.dgamma, l.dbeta = ptr(dgamma), ptr(dbeta)
+    l.out, l.ld_out = ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0)
+    l.mask_mode = mask_mode
+    call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
 
 
 def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=(0, 0, 0), b_remap=(0, 0, 0)):

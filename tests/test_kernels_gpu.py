@@ -130,6 +130,85 @@ def test_gemm_nt_dropout_matches_mask_kernel(gpu):
     close(C2, t + t * keep.view(M, N).float() / (1 - p), 1e-5, 1e-4, "self_resid")
 
 
+# ------------------------------------------------------------------------------------------ GEMM + LayerNorm
+@pytest.mark.parametrize("M,N,K,remap", [(16384, 256, 256, False), (16448, 128, 512, False), (200, 256, 1024, False),
+                                         (64, 256, 256, True)])
+def test_gemm_ln_forward_equals_gemm_then_layernorm(gpu, M, N, K, remap):
+    """mst_gemm_nt_ln mode 1 == mst_gemm_nt followed by mst_layernorm_fwd, bit for bit on h, to rounding on y"""
+    o = ops()
+    S = 5
+    A = rnd((M, K), gpu, seed=70, scale=0.5)
+    W = rnd((N, K), gpu, seed=71, scale=0.1)
+    bias, gam, bet = rnd((N,), gpu, dtype=torch.float32, seed=72), 1 + 0.1 * rnd((N,), gpu, dtype=torch.float32, seed=73), \
+        rnd((N,), gpu, dtype=torch.float32, seed=74)
+    rows = M * S if remap else M
+    resid = rnd((M, N), gpu, seed=75)
+    seedp = torch.tensor([77, 0, 0, 0], dtype=torch.int64, device=gpu)
+    kw = dict(bias=bias, resid=resid, dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=4,
+              c_remap=(1, S, 0) if remap else (0, 0, 0))
+    h0, h1 = (torch.zeros(rows, N, dtype=BF, device=gpu) for _ in range(2))
+    y0, y1 = (torch.zeros(rows, N, dtype=BF, device=gpu) for _ in range(2))
+    m0, r0, m1, r1 = (torch.zeros(rows, device=gpu) for _ in range(4))
+    o.gemm_nt(A, W, h0, **kw)
+    if remap:
+        v = lambda t: t.view(M, S, -1)[:, 0, :]
+        o.layernorm_fwd(v(h0), gam, bet, v(y0), m0, r0, D=N, M=M, row_id_stride=S)
+    else:
+        o.layernorm_fwd(h0, gam, bet, y0, m0, r0)
+    o.gemm_nt_ln_fwd(A, W, h1, gam, bet, y1, m1, r1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1)
+    close(m1, m0, 1e-5, 1e-5, "mean")
+    close(r1, r0, 1e-5, 1e-5, "rstd")
+    close(y1, y0, 1e-2, 1e-2, "LayerNorm output")
+    assert (y1.float() - y0.float()).abs().max().item() <= 2 ** -6  # at most one bf16 ulp at |y| < 4
+
+
+@pytest.mark.parametrize("M,N,K,mode,remap", [(16384, 256, 1024, 1, False), (16448, 128, 128, 2, False), (300, 256, 768, 0, False),
+                                              (64, 256, 1024, 1, True)])
+def test_gemm_ln_backward_equals_gemm_then_layernorm_bwd(gpu, M, N, K, mode, remap):
+    """mst_gemm_nt_ln mode 2 == mst_gemm_nt followed by mst_layernorm_bwd"""
+    o = ops()
+    S = 3
+    A = rnd((M, K), gpu, seed=80, scale=0.3)
+    W = rnd((N, K), gpu, seed=81, scale=0.1)
+    resid = rnd((M, N), gpu, seed=82)
+    gam = 1 + 0.1 * rnd((N,), gpu, dtype=torch.float32, seed=83)
+    rows = M * S if remap else M
+    xfull = rnd((rows, N), gpu, seed=84)
+    x = xfull.view(M, S, -1)[:, 0, :] if remap else xfull
+    mean = x.float().mean(1)
+    rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    mean_f, rstd_f = torch.zeros(rows, device=gpu), torch.zeros(rows, device=gpu)
+    stride = S if remap else 1
+    mean_f[::stride], rstd_f[::stride] = mean, rstd
+    seedp = torch.tensor([91, 0, 0, 0], dtype=torch.int64, device=gpu)
+    drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2) if mode else {}
+    res = []
+    for fused in (False, True):
+        dxf = torch.zeros(rows, N, dtype=BF, device=gpu)
+        dx = dxf.view(M, S, -1)[:, 0, :] if remap else dxf
+        dxm = torch.zeros(M, N, dtype=BF, device=gpu)
+        dg, db = torch.zeros(N, device=gpu), torch.zeros(N, device=gpu)
+        if fused:
+            o.gemm_nt_ln_bwd(A, W, dxf, xfull, gam, mean_f, rstd_f, dg, db, dx_masked=dxm if mode == 1 else None,
+                             mask_mode=mode, resid=resid, c_remap=(1, S, 0) if remap else (0, 0, 0), **drop)
+        else:
+            dy = torch.zeros(M, N, dtype=BF, device=gpu)
+            o.gemm_nt(A, W, dy, resid=resid)
+            o.layernorm_bwd(x, gam, mean_f, rstd_f, dy, dx, dg, db, D=N, M=M, row_id_stride=stride,
+                            dx_masked=dxm if mode == 1 else None, mask_mode=mode, **drop)
+        torch.cuda.synchronize()
+        res.append((dxf.clone(), dxm.clone(), dg.clone(), db.clone()))
+    scale = res[0][0].float().abs().max().item()
+    close(res[1][0], res[0][0], 1e-2, 1e-2 * scale, "dx")
+    close(res[1][1], res[0][1], 1e-2, 1e-2 * scale, "dx masked")
+    close(res[1][2], res[0][2], 1e-3, 1e-3 * res[0][2].abs().max().item(), "dgamma")
+    close(res[1][3], res[0][3], 1e-3, 1e-3 * res[0][3].abs().max().item(), "dbeta")
+    if remap:  # rows the launch does not own stay untouched
+        assert (res[1][0].view(M, S, -1)[:, 1:] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------ wgrad
 @pytest.mark.parametrize("M,N,K", [(512, 64, 64), (16384, 256, 256), (4097, 128, 1024), (100, 16, 32), (16448, 384, 128)])
 def test_gemm_wgrad(gpu, M, N, K):
