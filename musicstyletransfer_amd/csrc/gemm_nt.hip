@@ -246,8 +246,8 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
   constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 sub-tiles per wave
-  constexpr int A_CH = BM * CHUNKS / NT, B_CH = BN * CHUNKS / NT;
-  static_assert(BM * CHUNKS % NT == 0 && BN * CHUNKS % NT == 0, "tile/threads mismatch");
+  constexpr int A_CH = (BM * CHUNKS + NT - 1) / NT, B_CH = BN * CHUNKS / NT;  // a short A tile may not occupy every thread
+  static_assert((BM * CHUNKS % NT == 0 || BM * CHUNKS < NT) && BN * CHUNKS % NT == 0, "tile/threads mismatch");
   typedef typename Act<T>::vec8 vec8;
 
   u32x4* sA = reinterpret_cast<u32x4*>(smem);                    // [2][BM*CHUNKS]
@@ -281,7 +281,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   for (int i = 0; i < A_CH; ++i) {
     int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
     int64_t m = m0 + row;
-    a_ok[i] = m < a.M;
+    a_ok[i] = m < a.M && c < BM * CHUNKS;
     int64_t pm = remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
     a_ptr[i] = A + pm * a.lda + ch * 8;
     a_ch[i] = ch * 8;
@@ -312,7 +312,8 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) sA[buf * BM * CHUNKS + a_lds[i]] = ra[i];
+    for (int i = 0; i < A_CH; ++i)
+      if (BM * CHUNKS >= NT || tid < BM * CHUNKS) sA[buf * BM * CHUNKS + a_lds[i]] = ra[i];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
   };
@@ -426,6 +427,24 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
 #pragma unroll
   for (int e = 0; e < 8; ++e) { dg8[e] = 0.f; db8[e] = 0.f; }
 
+  // every global load of the thread's rows (residual; backward: x, mean, rstd) is issued before the first row is finished:
+  // in the step these lines are cold, and a row-by-row loop exposed one memory round trip per row at 8 waves per CU
+  u32x4 rv[ITERS], xv[ITERS];
+  float mean_r[ITERS], rstd_r[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int64_t m = m0 + row0 + it * RSTEP;
+    rv[it] = u32x4{0u, 0u, 0u, 0u}; xv[it] = rv[it]; mean_r[it] = 0.f; rstd_r[it] = 0.f;
+    if (m < a.M) {
+      const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+      if (resid) rv[it] = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
+      if (MODE == 2) {
+        xv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(l.x) + pm * l.ld_x + nc);
+        mean_r[it] = l.mean[pm];
+        rstd_r[it] = l.rstd[pm];
+      }
+    }
+  }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int row = row0 + it * RSTEP;
@@ -451,7 +470,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
         }
       }
       if (resid) {
-        Pack8 p8; p8.u = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
+        Pack8 p8; p8.u = rv[it];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
       }
@@ -476,8 +495,8 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
         if (ch == 0) { l.mean[pm] = mean; l.rstd[pm] = rstd; }
       } else {
         const int64_t rid = pm;  // x, the statistics and the forward's dropout counter live at the PHYSICAL row of C
-        const float mean = l.mean[rid], rstd = l.rstd[rid];
-        Pack8 xb; xb.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(l.x) + pm * l.ld_x + nc);
+        const float mean = mean_r[it], rstd = rstd_r[it];
+        Pack8 xb; xb.u = xv[it];
         float xh[8], g[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -630,7 +649,7 @@ extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, 
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    // 8 waves on a 64-row x full-width tile: measured equal to the 64x64 tiles of the unfused launches
+    // 8 waves on a 64-row x full-width tile (32-row tiles, two or three workgroups per CU, measured 8-25 % slower)
     if (a.N == 256) return launch_gemm_ln<T, 64, 256, 2, 4>(a, l, s);
     return launch_gemm_ln<T, 64, 128, 2, 4>(a, l, s);
   });

@@ -557,7 +557,7 @@ class StepPlan:
         dhd = D // H
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
-        fuse = o.can_fuse_ln(D)
+        fuse = o.ln_bwd_fusion_pays(D)
         if side == "encoder":
             if not dy_done:
                 if p > 0:
@@ -675,7 +675,7 @@ class StepPlan:
         # (the gradient bucket was cleared by forward()'s step_begin launch)
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
-        fuse_d, fuse_e = o.can_fuse_ln(Dd), o.can_fuse_ln(De)
+        fuse_d, fuse_e = o.ln_bwd_fusion_pays(Dd), o.ln_bwd_fusion_pays(De)
         site_d = 3 * cfg.e_layers
         last = cfg.d_layers - 1
         if fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
@@ -725,7 +725,7 @@ class StepPlan:
         De, Se = cfg.e_model, T
         sq_e = math.sqrt(float(De))
         dy, tgt, nxt = self.be_l[0].dx_a, self.be_l[0].dx_b, self.be_l[0].dx_a  # the top layer wrote dx_a
-        fuse_e = o.can_fuse_ln(De)  # then every layer's leading LayerNorm backward already ran in the GEMM above it
+        fuse_e = o.ln_bwd_fusion_pays(De)  # then every layer's leading LayerNorm backward already ran in the GEMM above it
         for i in reversed(range(cfg.e_layers - 1)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
             below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, 3 * (i - 1), self.be_l[i - 1]),

@@ -83,6 +83,13 @@ def can_fuse_ln(D):
     return D in (128, 256)
 
 
+def ln_bwd_fusion_pays(D):
+    """Where the engine routes Dense-dgrad + LayerNorm-backward through the fused launch. Measured at configs[1] (step
+    level, ms per step): no fusion 0.953, width 128 only 0.945, widths 128 and 256 0.951 — at width 256 the 64 x 256
+    tile leaves one 8-wave workgroup per CU and the GEMM part loses what the saved LayerNorm launch gains."""
+    return D == 128
+
+
 def gemm_nt_ln_fwd(A, B, H_out, gamma, beta, Y_out, mean, rstd, eps=1e-5, **kw):
     """H_out = epilogue(A @ B^T) and Y_out = LayerNorm(H_out) in one launch (mst_gemm_nt_ln, mode 1); the statistics
     are indexed by H_out's physical row"""
