@@ -162,6 +162,11 @@ int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream);
 /* up to 16 problems (host array) in ONE launch — the engine hands over every weight gradient of the backward pass at
  * once: one resident round of workgroups, the M-split (and with it the fp32-atomic traffic) as small as it gets */
 int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream);
+/* The same with a caller-owned fp32 scratch buffer (16-byte aligned). When the batch is large enough for 256x256 tiles
+ * and the buffer holds tiles * split * 256 KiB, the M-slabs' partial tiles are written there with plain stores and
+ * summed in slab order by a second launch: no fp32 atomics on dW (deterministic gradients, and 62 MB of atomic traffic
+ * less at configs[1]). Otherwise identical to mst_gemm_wgrad_batch. 64 MiB covers configs[1]. */
+int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K1/K2: token path input. out[b, s_off + t, :] = alpha*(table[tok[b,t]] + cls[classes[b]]) + pos[s_off+t]

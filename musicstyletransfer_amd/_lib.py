@@ -84,6 +84,7 @@ SIGNATURES = {
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "mst_gemm_wgrad_batch": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
+    "mst_gemm_wgrad_batch_ws": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, vp]),
     "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,
                                 vp, c_i64, c_i64, c_i64, vp, vp]),
     "mst_embed_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, c_f32,

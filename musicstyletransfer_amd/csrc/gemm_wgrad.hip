@@ -17,7 +17,11 @@ namespace mst {
 constexpr int WG_MAXP = 16;  // problems per launch (the whole backward pass of configs[1] is 15)
 struct WgradBatch {
   int n;
-  int split;                      // M split factor shared by all problems
+  int split;                      // largest M split factor of the batch
+  int split_p[WG_MAXP];           // M split of each problem: min(split, what its row count supports) — a 64-row problem
+                                  // gets ONE slab instead of `split` workgroups of which all but one exit at once
+  int64_t item_prefix[WG_MAXP + 1];  // prefix sums of tiles_p * split_p: work items of problem p are [prefix[p], prefix[p+1])
+  float* partial;                 // optional scratch [items][BN*BKO]: the slabs' tiles go there instead of into dW by atomics
   mst_wgrad_args p[WG_MAXP];
   int64_t tile_prefix[WG_MAXP + 1];  // prefix sums of (tiles_n * tiles_k) per problem
 };
@@ -55,28 +59,28 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WGK, wk = wave % WGK;
 
-  // locate (problem, tile, split)
-  const int64_t total_tiles = b.tile_prefix[b.n];
-  // Workgroup ids are dealt round-robin to the 8 XCDs. Work items are numbered split-major (M-slab, then tile) and
-  // every XCD takes a contiguous eighth of them: the tiles of all problems that read the same rows then mostly share
+  // locate (problem, slab, tile)
+  // Workgroup ids are dealt round-robin to the 8 XCDs. Work items are numbered problem, then M-slab, then tile, and
+  // every XCD takes a contiguous eighth of them: the tiles of a problem that read the same rows then mostly share
   // one XCD's L2, and the operands cross the fabric about once (117 MB for the encoder layer's four problems)
   // instead of once per XCD that owns a tile needing them (312 MB with the tile-major order).
-  const int64_t n_items = total_tiles * b.split;
+  const int64_t n_items = b.item_prefix[b.n];
   const int64_t per_xcd = (n_items + 7) / 8;
   const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (item >= n_items) return;
-  const int64_t tile_lin = item % total_tiles;
-  const int split_id = (int)(item / total_tiles);
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < WG_MAXP; ++i)
-    if (i < b.n && tile_lin >= b.tile_prefix[i]) pi = i;
+    if (i < b.n && item >= b.item_prefix[i]) pi = i;
   const mst_wgrad_args& a = b.p[pi];
-  const int64_t local = tile_lin - b.tile_prefix[pi];
+  const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
+  const int64_t in_p = item - b.item_prefix[pi];
+  const int64_t local = in_p % tiles_p;
+  const int split_id = (int)(in_p / tiles_p), split_here = b.split_p[pi];
   const int64_t tiles_k = (a.K + BKO - 1) / BKO;
   const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * BKO;
 
-  const int64_t m_chunk = ((a.M + b.split - 1) / b.split + BMR - 1) / BMR * BMR;
+  const int64_t m_chunk = ((a.M + split_here - 1) / split_here + BMR - 1) / BMR * BMR;
   const int64_t m_begin = (int64_t)split_id * m_chunk;
   const int64_t m_end = (m_begin + m_chunk < a.M) ? m_begin + m_chunk : a.M;
   if (m_begin >= m_end) return;  // uniform for the whole workgroup
@@ -199,7 +203,36 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
     __syncthreads();
   }
 
-  // D[row = n (4*(lane>>4)+r)][col = k (lane&15)] → atomically accumulate into dW[n][k]
+  // D[row = n (4*(lane>>4)+r)][col = k (lane&15)].
+  if (b.partial) {
+    // Two-pass reduction: this M-slab's tile goes to its own slot of the scratch buffer with plain stores and
+    // wgrad_reduce_kernel sums the slots in a fixed order. fp32 atomics on dW cost ~48 us of the 120 us whole-step
+    // launch (4 N K split = 62 MB at the ~1.3 TB/s the chip adds atomically) and made the gradients depend on
+    // arrival order in the last bits.
+    // The accumulators sit 4 rows x 64 bytes per wave-instruction; stored like that (or added atomically like that)
+    // the 256 KiB tile leaves the CU in 64-byte pieces and the launch spends ~50 us on it. Instead each group of WTN
+    // rows is transposed through LDS (the stage buffers are dead) and leaves as whole 1-KiB rows, 16 bytes per lane.
+    float* slot = b.partial + item * (int64_t)(BN * BKO);
+    constexpr int LDF = BKO + 4;
+    static_assert((size_t)WTN * LDF * 4 <= (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2, "row-group staging must fit the stage buffers");
+    float* sF = reinterpret_cast<float*>(smem);
+    for (int pass = 0; pass < WGN; ++pass) {
+      if (wn == pass) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sF[(j * 16 + 4 * g + r) * LDF + wk * WTK + i * 16 + li] = acc[j][i][r];
+      }
+      __syncthreads();
+      for (int c = tid; c < WTN * (BKO / 4); c += NT) {
+        const int row = c / (BKO / 4), c4 = (c % (BKO / 4)) * 4;
+        *reinterpret_cast<f32x4*>(slot + (pass * WTN + row) * BKO + c4) = *reinterpret_cast<const f32x4*>(sF + row * LDF + c4);
+      }
+      __syncthreads();
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -224,9 +257,39 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   }
 }
 
+// dW[n, k] += scale * sum over the M-slabs (in slab order) of the tiles wgrad_kernel left in the scratch buffer.
+// grid = (tile elements / 1024, tiles); a thread owns 4 consecutive k of one n.
+template <int BN, int BKO>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b) {
+  const int64_t tile_lin = blockIdx.y;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < b.n && tile_lin >= b.tile_prefix[i]) pi = i;
+  const mst_wgrad_args& a = b.p[pi];
+  const int64_t local = tile_lin - b.tile_prefix[pi];
+  const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
+  const int64_t tiles_k = (a.K + BKO - 1) / BKO;
+  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * BKO;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // element of the tile
+  const int nl = e / BKO, kl = e % BKO;
+  const int64_t n = n0 + nl, k = k0 + kl;
+  if (n >= a.N || k >= a.K) return;
+  // slabs that own rows of this problem (wgrad_kernel returns early, writing nothing, for the others)
+  const int sp = b.split_p[pi];
+  const int64_t m_chunk = ((a.M + sp - 1) / sp + BMR - 1) / BMR * BMR;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < sp && (int64_t)s * m_chunk < a.M; ++s)
+    sum += *reinterpret_cast<const f32x4*>(b.partial + (b.item_prefix[pi] + (int64_t)s * tiles_p + local) * (BN * BKO) + e);
+  float* d = a.dW + n * a.ldw + k;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (k + c < a.K) d[c] += sum[c] * a.scale;
+}
+
 template <typename T>
 static int launch_wgrad(const WgradBatch& b, int big, hipStream_t s) {
-  const int64_t total = cdiv(b.tile_prefix[b.n] * b.split, 8) * 8;  // padded to whole XCD rounds (see the kernel)
+  const int64_t total = cdiv(b.item_prefix[b.n], 8) * 8;  // padded to whole XCD rounds (see the kernel)
   if (big == 3) {
     constexpr int BN = 256, BKO = 256;
     size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
@@ -238,6 +301,10 @@ static int launch_wgrad(const WgradBatch& b, int big, hipStream_t s) {
       opted = true;
     }
     hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 4, 2>), dim3((unsigned)total), dim3(512), lds, s, b);
+    if (b.partial) {
+      MST_CHECK_LAUNCH("wgrad_kernel");
+      hipLaunchKernelGGL((wgrad_reduce_kernel<BN, BKO>), dim3(BN * BKO / 1024, (unsigned)b.tile_prefix[b.n]), dim3(256), 0, s, b);
+    }
   } else if (big == 2) {
     constexpr int BN = 256, BKO = 128;
     size_t lds = (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2;
@@ -286,8 +353,10 @@ static int check_wgrad(const mst_wgrad_args& a) {
 
 using namespace mst;
 
-extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream) {
+extern "C" int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
+                                       mst_stream_t stream) {
   MST_CHECK_ARG(list != nullptr && n >= 1 && n <= WG_MAXP, "mst_gemm_wgrad_batch: need 1..%d problems", WG_MAXP);
+  MST_CHECK_ARG(!scratch || ((uintptr_t)scratch % 16 == 0 && scratch_bytes > 0), "mst_gemm_wgrad_batch_ws: bad scratch buffer");
   WgradBatch b;
   b.n = n;
   int64_t out_elems = 0, maxM = 0;
@@ -314,18 +383,42 @@ extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_strea
     b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bk);
   for (int i = n + 1; i <= WG_MAXP; ++i) b.tile_prefix[i] = b.tile_prefix[n];
   const int64_t tiles = b.tile_prefix[n];
-  // one full resident round of workgroups, no more: floor, because the workgroup that does not fit starts a second
-  // round (105 vs 83 us), and every extra split adds 4*N*K bytes of fp32 atomics (~1.3 TB/s chip-wide)
-  int64_t split = (big >= 2 ? 256 : (big ? 512 : 1024)) / tiles;
-  int64_t max_split = cdiv(maxM, 2 * BMR);
-  if (split > max_split) split = max_split;
-  if (split < 1) split = 1;
+  // One full resident round of workgroups, no more (the workgroup that does not fit starts a second round: 105 vs
+  // 83 us). Every problem is split min(S, rows / 128) ways — a 64-row problem (the top encoder layer's position-0 path)
+  // gets one slab, where a batch-wide split left 26 % of the launch's workgroups with nothing to do — and S is the
+  // largest value for which the items still fit.
+  const int64_t slots = big >= 2 ? 256 : (big ? 512 : 1024);
+  int64_t split = 1, n_items = 0;
+  for (int64_t S = cdiv(maxM, 2 * BMR); S >= 1; --S) {
+    int64_t items = 0;
+    for (int i = 0; i < n; ++i) {
+      const int64_t cap = cdiv(list[i].M, 2 * BMR);
+      items += (b.tile_prefix[i + 1] - b.tile_prefix[i]) * (S < cap ? S : cap);
+    }
+    if (items <= slots || S == 1) { split = S; n_items = items; break; }
+  }
   b.split = (int)split;
+  b.item_prefix[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t cap = cdiv(list[i].M, 2 * BMR);
+    b.split_p[i] = (int)(split < cap ? split : cap);
+    b.item_prefix[i + 1] = b.item_prefix[i] + (b.tile_prefix[i + 1] - b.tile_prefix[i]) * b.split_p[i];
+  }
+  for (int i = n; i < WG_MAXP; ++i) b.split_p[i] = 1;
+  for (int i = n + 1; i <= WG_MAXP; ++i) b.item_prefix[i] = b.item_prefix[n];
+  // two-pass reduction through the caller's scratch buffer when it is big enough (256x256 tiles only: that is where
+  // 4 N K split bytes of atomics are tens of microseconds)
+  b.partial = nullptr;
+  if (scratch && big == 3 && n_items * (int64_t)(256 * 256) * 4 <= scratch_bytes) b.partial = scratch;
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(list[0].dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     return launch_wgrad<T>(b, big, s);
   });
+}
+
+extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream) {
+  return mst_gemm_wgrad_batch_ws(list, n, nullptr, 0, stream);
 }
 
 extern "C" int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream) {

@@ -326,6 +326,8 @@ class StepPlan:
         self.bd_l = [bwd_bufs(self.Md, Dd, cfg.d_heads, Sd) for _ in range(cfg.d_layers)]
         self.be, self.bd = self.be_l[0], self.bd_l[0]
         self._wgrads = []
+        # work buffer of the single wgrad launch's two-pass reduction (tiles x split x 256 KiB; 64 MiB covers configs[1])
+        self.wgrad_scratch = torch.empty(16 * 1024 * 1024, **f32)
         self.lat_scratch = torch.zeros(B * (Dd + 2 * Z), **f32)
         # Sparse gradient carriers, never used as ping-pong targets so their untouched rows stay zero:
         #   d_dec_out: d(decoder output) - rows 1..T written by the output-layer dgrad, row 0 always 0 (model.py:253)
@@ -716,7 +718,7 @@ class StepPlan:
                  self.be_l[top - 1]) if (fuse_e and top > 0) else None
         self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top], next_ln=below)
         if flush and cfg.e_layers >= 2:
-            o.gemm_wgrad_batch(self._wgrads)
+            o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch)
             self._wgrads = []
 
     def backward_late(self):
@@ -743,7 +745,7 @@ class StepPlan:
             o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
         # every (remaining) Dense weight / bias gradient in ONE launch — all 15 problems of the step at configs[1] on a
         # single GPU: one resident round of workgroups with the smallest possible M-split instead of six launches
-        o.gemm_wgrad_batch(self._wgrads)
+        o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch)
         self._wgrads = []
 
     def optimizer(self):

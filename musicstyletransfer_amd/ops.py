@@ -135,12 +135,16 @@ def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=
 WGRAD_MAX_PROBLEMS = 16
 
 
-def gemm_wgrad_batch(problems):
-    """dW_i[N,K] += A_i^T @ B_i for a list of problems, 16 per launch."""
+def gemm_wgrad_batch(problems, scratch=None):
+    """dW_i[N,K] += A_i^T @ B_i for a list of problems, 16 per launch. scratch: optional fp32 work buffer for the
+    atomic-free two-pass reduction of big batches (mst_gemm_wgrad_batch_ws)."""
     for i in range(0, len(problems), WGRAD_MAX_PROBLEMS):
         chunk = problems[i:i + WGRAD_MAX_PROBLEMS]
         arr = (WgradArgs * len(chunk))(*chunk)
-        call("mst_gemm_wgrad_batch", arr, len(chunk), stream())
+        if scratch is None:
+            call("mst_gemm_wgrad_batch", arr, len(chunk), stream())
+        else:
+            call("mst_gemm_wgrad_batch_ws", arr, len(chunk), ptr(scratch), scratch.numel() * scratch.element_size(), stream())
 
 
 def gemm_wgrad(A, B, dW, db=None, **kw):

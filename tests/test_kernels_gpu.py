@@ -245,6 +245,40 @@ def test_gemm_wgrad_integer_exact_and_batch(gpu):
         assert torch.equal(db, rb)
 
 
+def roundup8(x):
+    return (x + 7) // 8 * 8
+
+
+def test_gemm_wgrad_two_pass_reduction_is_deterministic_and_equal(gpu):
+    """a batch big enough for 256x256 tiles: with a scratch buffer the M-slabs are summed in slab order by a second
+    launch instead of fp32 atomics — same result to fp32 rounding, and bit-identical run to run"""
+    o = ops()
+    M = 4096
+    shapes = [(256, 1024), (1024, 256), (768, 256), (256, 256), (300, 200), (1024, 256), (256, 1024), (512, 512)]  # 2.1 M outputs
+    probs = []
+    for i, (N, K) in enumerate(shapes):
+        A, B = rnd((M, roundup8(N)), gpu, seed=140 + i), rnd((M, roundup8(K)), gpu, seed=150 + i)
+        A[:, N:] = 0
+        B[:, K:] = 0
+        probs.append((A, B, N, K))
+    scratch = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=gpu)
+
+    def run(ws):
+        outs = [(torch.zeros(N, K, device=gpu), torch.zeros(N, device=gpu)) for _, _, N, K in probs]
+        o.gemm_wgrad_batch([o.wgrad_problem(A, B, dW, db, N=N, K=K, scale=0.5) for (A, B, N, K), (dW, db) in zip(probs, outs)],
+                           scratch=scratch if ws else None)
+        torch.cuda.synchronize()
+        return outs
+
+    atomic, two_a, two_b = run(False), run(True), run(True)
+    for (A, B, N, K), (dWa, dba), (dW1, db1), (dW2, _) in zip(probs, atomic, two_a, two_b):
+        ref = 0.5 * (A[:, :N].float().t() @ B[:, :K].float())
+        close(dW1, ref, 1e-4, 1e-3 * ref.abs().max().item(), "two-pass dW")
+        close(dW1, dWa, 1e-5, 1e-4 * ref.abs().max().item(), "two-pass vs atomic")
+        close(db1, 0.5 * A[:, :N].float().sum(0), 1e-4, 1e-2, "db")
+        assert torch.equal(dW1, dW2), "the two-pass reduction must be run-to-run deterministic"
+
+
 def test_gemm_wgrad_remap(gpu):
     o = ops()
     Bsz, T, N, K = 4, 33, 24, 40
