@@ -102,6 +102,15 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   u32x4 ra[A_CH], rb[B_CH];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // Row remaps (decoder rows 1..T of each sample): the physical row of the thread's first chunk and its offset inside
+  // the group are carried from stage to stage, so the per-chunk mapping is an add and a compare. (Recomputing it with
+  // 64-bit divisions per chunk and stage made the two remapped problems' workgroups finish at 95 us when the median
+  // workgroup of the whole-step launch finished at 70.) Groups shorter than a stage keep the division.
+  const bool div_a = remap_a && a.a_rows_per_group < BMR, div_b = remap_b && a.b_rows_per_group < BMR;
+  int64_t pa0 = remap_a ? remap_row(m_begin + a_r0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : 0;
+  int64_t pb0 = remap_b ? remap_row(m_begin + b_r0, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) : 0;
+  int64_t oa0 = remap_a ? (m_begin + a_r0) % a.a_rows_per_group : 0, ob0 = remap_b ? (m_begin + b_r0) % a.b_rows_per_group : 0;
+
   auto load_tile = [&](int64_t mb) {
     const bool full = mb + BMR <= m_end;  // uniform: only the last stage of a slab can be partial
     if (plain && full) {
@@ -115,14 +124,26 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int64_t m = mb + a_r0 + i * A_RSTEP;
-      const int64_t pm = remap_a ? remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : m;
+      int64_t pm = m;
+      if (div_a) pm = remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
+      else if (remap_a) pm = pa0 + i * A_RSTEP + ((oa0 + i * A_RSTEP >= a.a_rows_per_group) ? a.a_group_stride - a.a_rows_per_group : 0);
       ra[i] = (a_ok && m < m_end) ? *reinterpret_cast<const u32x4*>(A + pm * a.lda + n0 + a_c) : zero4;
+    }
+    if (remap_a && !div_a) {
+      oa0 += BMR; pa0 += BMR;
+      if (oa0 >= a.a_rows_per_group) { oa0 -= a.a_rows_per_group; pa0 += a.a_group_stride - a.a_rows_per_group; }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int64_t m = mb + b_r0 + i * B_RSTEP;
-      const int64_t pm = remap_b ? remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) : m;
+      int64_t pm = m;
+      if (div_b) pm = remap_row(m, a.b_rows_per_group, a.b_group_stride, a.b_group_offset);
+      else if (remap_b) pm = pb0 + i * B_RSTEP + ((ob0 + i * B_RSTEP >= a.b_rows_per_group) ? a.b_group_stride - a.b_rows_per_group : 0);
       rb[i] = (b_ok && m < m_end) ? *reinterpret_cast<const u32x4*>(B + pm * a.ldb + k0 + b_c) : zero4;
+    }
+    if (remap_b && !div_b) {
+      ob0 += BMR; pb0 += BMR;
+      if (ob0 >= a.b_rows_per_group) { ob0 -= a.b_rows_per_group; pb0 += a.b_group_stride - a.b_rows_per_group; }
     }
   };
   T* const wA = sA + a_r0 * LDA_S + a_c;  // this thread's first chunk in buffer 0
