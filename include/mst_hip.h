@@ -118,7 +118,11 @@ int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
  *   mode 2, backward: dy = epi(A B^T) (bias, alpha, resid) is NOT stored; C = dx = LayerNorm backward of dy with
  *                     x (the forward's pre-norm tensor), mean, rstd all taken at the PHYSICAL C row r (the forward
  *                     wrote them there), gamma; out = dropout-masked copy of dx (mask_mode 1) at the LOGICAL row m;
- *                     dgamma / dbeta accumulated into.
+ *                     dgamma / dbeta accumulated into — or, with `partials` set, NOT touched: workgroup w (one per
+ *                     64 output rows; mst_gemm_nt_ln_parts(M) of them) stores its column sums at
+ *                     partials[w * 2N + 0..N) (dgamma) and [N..2N) (dbeta) with plain stores, and the caller adds
+ *                     them up later with mst_partial_sums (256 same-address fp32 atomics per column cost ~5 us of
+ *                     serialisation per launch at configs[1]).
  *                     mask modes and the dropout counter (p / seed / site in the mst_gemm_args dropout fields) are
  *                     those of mst_layernorm_bwd. Equals mst_gemm_nt followed by mst_layernorm_bwd on its result.
  * ------------------------------------------------------------------------ */
@@ -132,9 +136,23 @@ typedef struct mst_ln_args {
   const void* x; int64_t ld_x;
   float* dgamma; float* dbeta;
   int32_t mask_mode;
+  float* partials;        /* mode 2, optional: [mst_gemm_nt_ln_parts(M)][2N] fp32, 16-byte aligned */
 } mst_ln_args;
 
 int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream);
+int64_t mst_gemm_nt_ln_parts(int64_t M);
+
+/* ------------------------------------------------------------------------
+ * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order
+ * (deterministic). The LayerNorm-backward launches leave per-workgroup partial sums of dgamma / dbeta (`partials`
+ * above and in mst_layernorm_bwd); one launch of this adds all of a backward pass's sites into the gradient bucket.
+ * len % 4 == 0, stride % 4 == 0, src and dst 16-byte aligned; up to 24 jobs (host array) per launch.
+ * ------------------------------------------------------------------------ */
+typedef struct mst_partial_sum {
+  const float* src; int64_t n_parts; int64_t stride; int64_t len;
+  float* dst; float scale;
+} mst_partial_sum;
+int mst_partial_sums(const mst_partial_sum* jobs, int n, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Weight gradient: dW[N,K] (+)= sum_m A[m,n] * B[m,k]   (A = dY [M,N], B = X [M,K])
@@ -167,6 +185,11 @@ int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream)
  * summed in slab order by a second launch: no fp32 atomics on dW (deterministic gradients, and 62 MB of atomic traffic
  * less at configs[1]). Otherwise identical to mst_gemm_wgrad_batch. 64 MiB covers configs[1]. */
 int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes, mst_stream_t stream);
+/* The same plus up to 24 column-sum jobs (mst_partial_sum below: the LayerNorm-backward launches' per-workgroup dgamma /
+ * dbeta rows): they are executed by extra workgroups of the reduction pass when there is one, else by one
+ * mst_partial_sums launch after the weight gradients — either way the flush of a backward pass is one call. */
+int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
+                              const mst_partial_sum* sums, int n_sums, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K1/K2: token path input. out[b, s_off + t, :] = alpha*(table[tok[b,t]] + cls[classes[b]]) + pos[s_off+t]
@@ -256,7 +279,11 @@ int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x, int64_t ld
                       const uint64_t* dropout_seed_ptr,
                       int64_t row_id_stride /* row m here is row m*row_id_stride of the forward (mean/rstd index and
                                                dropout counter); 1 for a dense pass */,
+                      float* partials /* optional [mst_layernorm_bwd_parts(M, D)][2D] fp32: per-workgroup column sums
+                                         (dgamma | dbeta) stored instead of atomics on dgamma / dbeta; add them
+                                         with mst_partial_sums */,
                       mst_stream_t stream);
+int64_t mst_layernorm_bwd_parts(int64_t M, int64_t D);
 
 /* ------------------------------------------------------------------------
  * K8/K9/K10 latent block (model.py:97-103,292,229-232; loss.py:8-12), fp32 math:

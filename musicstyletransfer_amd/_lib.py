@@ -49,6 +49,14 @@ class LnArgs(C.Structure):
         ("x", vp), ("ld_x", c_i64),
         ("dgamma", vp), ("dbeta", vp),
         ("mask_mode", c_i32),
+        ("partials", vp),
+    ]
+
+
+class PartialSum(C.Structure):
+    _fields_ = [
+        ("src", vp), ("n_parts", c_i64), ("stride", c_i64), ("len", c_i64),
+        ("dst", vp), ("scale", c_f32),
     ]
 
 
@@ -82,9 +90,13 @@ SIGNATURES = {
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
+    "mst_gemm_nt_ln_parts": (c_i64, [c_i64]),
+    "mst_partial_sums": (C.c_int, [C.POINTER(PartialSum), C.c_int, vp]),
+    "mst_layernorm_bwd_parts": (c_i64, [c_i64, c_i64]),
     "mst_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "mst_gemm_wgrad_batch": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
     "mst_gemm_wgrad_batch_ws": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, vp]),
+    "mst_gemm_wgrad_batch_sums": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, C.POINTER(PartialSum), C.c_int, vp]),
     "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,
                                 vp, c_i64, c_i64, c_i64, vp, vp]),
     "mst_embed_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, c_f32,
@@ -97,7 +109,7 @@ SIGNATURES = {
                                           vp, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp]),
     "mst_layernorm_fwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, c_f32, vp, c_i64, vp, vp, c_i64, vp]),
     "mst_layernorm_bwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_i64, vp, c_i64,
-                                    vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp]),
+                                    vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp, vp]),
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,

@@ -545,7 +545,8 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
       const int which = c / BN, col = c % BN;
       float s = 0.f;
       for (int r = 0; r < RSTEP; ++r) s += red[(which * RSTEP + r) * BN + col];
-      atomicAdd((which ? l.dbeta : l.dgamma) + col, s);
+      if (l.partials) l.partials[(int64_t)blockIdx.x * 2 * BN + c] = s;  // [dgamma | dbeta], summed by partial_sums_kernel
+      else atomicAdd((which ? l.dbeta : l.dgamma) + col, s);
     }
   }
 }
@@ -622,6 +623,8 @@ static int check_gemm_common(const mst_gemm_args& a) {
   return MST_OK;
 }
 
+extern "C" int64_t mst_gemm_nt_ln_parts(int64_t M) { return M > 0 ? cdiv(M, 64) : 0; }  // launch_gemm_ln's 64-row tiles
+
 extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr && ln != nullptr, "mst_gemm_nt_ln: null args");
   const mst_gemm_args& a = *args;
@@ -639,8 +642,9 @@ extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, 
   if (l.mode == 1) {
     MST_CHECK_ARG(l.beta && l.out && l.ld_out % 8 == 0 && l.ld_out >= a.N && (uintptr_t)l.out % 16 == 0, "mst_gemm_nt_ln: forward needs beta and out");
   } else {
-    MST_CHECK_ARG(l.x && l.ld_x % 8 == 0 && (uintptr_t)l.x % 16 == 0 && l.dgamma && l.dbeta,
-                  "mst_gemm_nt_ln: backward needs x, dgamma and dbeta");
+    MST_CHECK_ARG(l.x && l.ld_x % 8 == 0 && (uintptr_t)l.x % 16 == 0 && (l.partials || (l.dgamma && l.dbeta)),
+                  "mst_gemm_nt_ln: backward needs x and dgamma + dbeta (or partials)");
+    MST_CHECK_ARG((uintptr_t)l.partials % 16 == 0, "mst_gemm_nt_ln: partials must be 16-byte aligned");
     MST_CHECK_ARG(l.mask_mode >= 0 && l.mask_mode <= 2, "mst_gemm_nt_ln: mask_mode must be 0, 1 or 2");
     MST_CHECK_ARG(l.mask_mode != 1 || (l.out && l.ld_out % 8 == 0 && l.ld_out >= a.N && (uintptr_t)l.out % 16 == 0),
                   "mst_gemm_nt_ln: mask_mode 1 needs out");

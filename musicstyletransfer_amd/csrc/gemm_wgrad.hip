@@ -11,6 +11,7 @@
 // gradient bucket, which the step zeroes once. Several layers' problems go into ONE launch
 // (mst_wgrad_batch) so the split factor, and with it the atomic traffic, stays small.
 #include "common.hpp"
+#include "partial_sums.hpp"
 
 namespace mst {
 
@@ -281,7 +282,13 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 // dW[n, k] += scale * sum over the M-slabs (in slab order) of the tiles wgrad_kernel left in the scratch buffer.
 // grid = (tile elements / 1024, tiles); a thread owns 4 consecutive k of one n.
 template <int BN, int BKO>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, PartialSumBatch ps) {
+  if (blockIdx.y >= (unsigned)b.tile_prefix[b.n]) {  // rows of workgroups past the tiles: the caller's column-sum jobs
+    __shared__ f32x4 red[16][16];
+    const int wg = (int)((blockIdx.y - (unsigned)b.tile_prefix[b.n]) * gridDim.x + blockIdx.x);
+    if (wg < ps.wg_prefix[ps.n]) partial_sums_wg(ps, wg, red);
+    return;
+  }
   const int64_t tile_lin = blockIdx.y;
   int pi = 0;
 #pragma unroll
@@ -308,8 +315,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b) {
     if (k + c < a.K) d[c] += sum[c] * a.scale;
 }
 
+static_assert(sizeof(WgradBatch) + sizeof(PartialSumBatch) <= 4096, "kernel arguments of the reduction pass");
+
+// *ps_done: the column-sum jobs were taken along by the reduction pass
 template <typename T>
-static int launch_wgrad(const WgradBatch& b, int big, hipStream_t s) {
+static int launch_wgrad(const WgradBatch& b, int big, const PartialSumBatch* ps, bool* ps_done, hipStream_t s) {
   const int64_t total = cdiv(b.item_prefix[b.n], 8) * 8;  // padded to whole XCD rounds (see the kernel)
   if (big == 3) {
     constexpr int BN = 256, BKO = 256;
@@ -324,7 +334,14 @@ static int launch_wgrad(const WgradBatch& b, int big, hipStream_t s) {
     hipLaunchKernelGGL((wgrad_kernel<T, BN, BKO, 4, 2>), dim3((unsigned)total), dim3(512), lds, s, b);
     if (b.partial) {
       MST_CHECK_LAUNCH("wgrad_kernel");
-      hipLaunchKernelGGL((wgrad_reduce_kernel<BN, BKO>), dim3(BN * BKO / 1024, (unsigned)b.tile_prefix[b.n]), dim3(256), 0, s, b);
+      constexpr unsigned GX = BN * BKO / 1024;
+      PartialSumBatch none;
+      none.n = 0;
+      for (int i = 0; i <= PS_MAXJ; ++i) none.wg_prefix[i] = 0;
+      const PartialSumBatch& pb = ps ? *ps : none;
+      const unsigned extra = (unsigned)cdiv(pb.wg_prefix[pb.n], GX);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<BN, BKO>), dim3(GX, (unsigned)b.tile_prefix[b.n] + extra), dim3(256), 0, s, b, pb);
+      if (ps) *ps_done = true;
     }
   } else if (big == 2) {
     constexpr int BN = 256, BKO = 128;
@@ -376,7 +393,18 @@ using namespace mst;
 
 extern "C" int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
                                        mst_stream_t stream) {
+  return mst_gemm_wgrad_batch_sums(list, n, scratch, scratch_bytes, nullptr, 0, stream);
+}
+
+extern "C" int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
+                                         const mst_partial_sum* sums, int n_sums, mst_stream_t stream) {
   MST_CHECK_ARG(list != nullptr && n >= 1 && n <= WG_MAXP, "mst_gemm_wgrad_batch: need 1..%d problems", WG_MAXP);
+  MST_CHECK_ARG(n_sums >= 0 && (n_sums == 0 || sums != nullptr), "mst_gemm_wgrad_batch_sums: bad column-sum job list");
+  PartialSumBatch ps;
+  if (n_sums > 0) {
+    int rc = pack_partial_sums(sums, n_sums, ps);
+    if (rc) return rc;
+  }
   MST_CHECK_ARG(!scratch || ((uintptr_t)scratch % 16 == 0 && scratch_bytes > 0), "mst_gemm_wgrad_batch_ws: bad scratch buffer");
   WgradBatch b;
   b.n = n;
@@ -432,10 +460,13 @@ extern "C" int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float*
   b.partial = nullptr;
   if (scratch && big == 3 && n_items * (int64_t)(256 * 256) * 4 <= scratch_bytes) b.partial = scratch;
   hipStream_t s = (hipStream_t)stream;
-  return dispatch_act(list[0].dtype, [&](auto tag) -> int {
+  bool ps_done = false;
+  int rc = dispatch_act(list[0].dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    return launch_wgrad<T>(b, big, s);
+    return launch_wgrad<T>(b, big, n_sums > 0 ? &ps : nullptr, &ps_done, s);
   });
+  if (rc == MST_OK && n_sums > 0 && !ps_done) rc = mst_partial_sums(sums, n_sums, stream);  // no reduction pass: own launch
+  return rc;
 }
 
 extern "C" int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream) {

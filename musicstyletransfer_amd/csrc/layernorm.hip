@@ -119,7 +119,8 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
                                                             T* __restrict__ dxm, int64_t ld_dxm,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int mask_mode, float p, uint64_t seed_in, uint32_t site,
-                                                            const uint64_t* __restrict__ seed_ptr, int64_t row_id_stride) {
+                                                            const uint64_t* __restrict__ seed_ptr, int64_t row_id_stride,
+                                                            float* __restrict__ partials) {
   // blockDim = 64 * NW waves (NW chosen by the host so that the [2][NW][D] reduction buffer fits 32 KiB):
   // many waves per workgroup hide the row-after-row load latency, few workgroups keep the same-address
   // atomics of the parameter gradients rare
@@ -228,8 +229,13 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     float a = 0.f, b = 0.f;
     for (int w = 0; w < NW; ++w) { a += red0[w * D + d]; b += red1[w * D + d]; }
-    atomicAdd(dgamma + d, a);
-    atomicAdd(dbeta + d, b);
+    if (partials) {  // summed later by partial_sums_kernel: no same-address atomic chains
+      partials[(int64_t)blockIdx.x * 2 * D + d] = a;
+      partials[(int64_t)blockIdx.x * 2 * D + D + d] = b;
+    } else {
+      atomicAdd(dgamma + d, a);
+      atomicAdd(dbeta + d, b);
+    }
   }
 }
 
@@ -244,6 +250,25 @@ static int ln_dispatch_nv(int64_t D, F&& f) {
 }  // namespace mst
 
 using namespace mst;
+
+// Workgroups (and waves per workgroup) of the backward launch. One workgroup per CU at most: every workgroup ends with
+// one column-sum row (an atomic per column on the SAME 2*D addresses, or one row of `partials`).
+static unsigned ln_bwd_grid(int64_t M, int64_t D, int& nw) {
+  nw = (int)(32768 / (8 * D));  // reduction buffer 2 * nw * D floats <= 32 KiB
+  if (nw > 16) nw = 16;
+  if (nw < 1) nw = 1;
+  // ~4 rows per wave when there are enough rows to fill the chip, one row per wave for small M (the top encoder
+  // layer's B rows used to run on ONE workgroup: 11 us)
+  int64_t wgs = cdiv(M, 4 * nw);
+  if (wgs < 64) wgs = cdiv(M, nw) < 64 ? cdiv(M, nw) : 64;
+  return (unsigned)(wgs < 256 ? wgs : 256);
+}
+
+extern "C" int64_t mst_layernorm_bwd_parts(int64_t M, int64_t D) {
+  if (M <= 0 || D <= 0) return 0;
+  int nw;
+  return (int64_t)ln_bwd_grid(M, D, nw);
+}
 
 static int ln_check(int64_t M, int64_t D, int64_t ldx, int64_t ldy) {
   MST_CHECK_ARG(M > 0 && D > 0, "layernorm: M and D must be positive");
@@ -281,24 +306,18 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
                                  const float* mean, const float* rstd, const void* dy, int64_t ldy, void* dx,
                                  int64_t ld_dx, void* dx_masked, int64_t ld_dxm, float* dgamma, float* dbeta,
                                  int mask_mode, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
-                                 const uint64_t* dropout_seed_ptr, int64_t row_id_stride, mst_stream_t stream) {
+                                 const uint64_t* dropout_seed_ptr, int64_t row_id_stride, float* partials,
+                                 mst_stream_t stream) {
   int rc = ln_check(M, D, ldx, ldy);
   if (rc) return rc;
-  MST_CHECK_ARG(x && gamma && mean && rstd && dy && dx && dgamma && dbeta, "mst_layernorm_bwd: null pointer");
+  MST_CHECK_ARG(x && gamma && mean && rstd && dy && dx && (partials || (dgamma && dbeta)), "mst_layernorm_bwd: null pointer");
   MST_CHECK_ARG(ld_dx % 4 == 0 && ld_dx >= D, "mst_layernorm_bwd: bad ld_dx");
   MST_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "mst_layernorm_bwd: mask_mode must be 0,1,2");
   MST_CHECK_ARG(mask_mode != 1 || (dx_masked && ld_dxm % 4 == 0 && ld_dxm >= D), "mst_layernorm_bwd: mask_mode 1 needs dx_masked");
   MST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mst_layernorm_bwd: dropout_p must be in [0,1)");
-  // one workgroup per CU: every workgroup ends with one atomic per column on the SAME 2*D addresses, so the
-  // count of workgroups (not rows) sets the contention
-  int nw = (int)(32768 / (8 * D));  // reduction buffer 2 * nw * D floats <= 32 KiB
-  if (nw > 16) nw = 16;
-  if (nw < 1) nw = 1;
-  // ~4 rows per wave when there are enough rows to fill the chip, one row per wave for small M (the top encoder
-  // layer's B rows used to run on ONE workgroup: 11 us)
-  int64_t wgs = cdiv(M, 4 * nw);
-  if (wgs < 64) wgs = cdiv(M, nw) < 64 ? cdiv(M, nw) : 64;
-  const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+  MST_CHECK_ARG(!partials || (uintptr_t)partials % 16 == 0, "mst_layernorm_bwd: partials must be 16-byte aligned");
+  int nw;
+  const unsigned grid = ln_bwd_grid(M, D, nw);
   const size_t lds = (size_t)2 * nw * D * sizeof(float);
   const int64_t rows_per_wave = cdiv(M, (int64_t)grid * nw);
   return dispatch_act(dtype, [&](auto tag) -> int {
@@ -310,12 +329,12 @@ extern "C" int mst_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* x,
         hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV, RB>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
                            (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
                            dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
-                           row_id_stride > 0 ? row_id_stride : 1);
+                           row_id_stride > 0 ? row_id_stride : 1, partials);
       else
         hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV, 1>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, M, (int)D,
                            (const T*)x, ldx, gamma, mean, rstd, (const T*)dy, ldy, (T*)dx, ld_dx, (T*)dx_masked, ld_dxm,
                            dgamma, dbeta, mask_mode, dropout_p, dropout_seed, dropout_site, dropout_seed_ptr,
-                           row_id_stride > 0 ? row_id_stride : 1);
+                           row_id_stride > 0 ? row_id_stride : 1, partials);
       MST_CHECK_LAUNCH("layernorm_bwd_kernel");
       return MST_OK;
     });

@@ -6,6 +6,7 @@
 //                     VarAutoEncoder/model.py:292); Box-Muller over the counter hash of common.hpp
 #include <math.h>
 #include "common.hpp"
+#include "partial_sums.hpp"
 
 namespace mst {
 
@@ -103,6 +104,11 @@ __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_st
   }
 }
 
+__global__ __launch_bounds__(256) void partial_sums_kernel(PartialSumBatch b) {
+  __shared__ f32x4 red[16][16];
+  partial_sums_wg(b, (int)blockIdx.x, red);
+}
+
 }  // namespace mst
 
 using namespace mst;
@@ -130,6 +136,15 @@ extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double l
                      eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
                      n16_b);
   MST_CHECK_LAUNCH("step_begin_kernel");
+  return MST_OK;
+}
+
+extern "C" int mst_partial_sums(const mst_partial_sum* jobs, int n, mst_stream_t stream) {
+  PartialSumBatch b;
+  int rc = pack_partial_sums(jobs, n, b);
+  if (rc) return rc;
+  hipLaunchKernelGGL(partial_sums_kernel, dim3((unsigned)b.wg_prefix[n]), dim3(256), 0, (hipStream_t)stream, b);
+  MST_CHECK_LAUNCH("partial_sums_kernel");
   return MST_OK;
 }
 

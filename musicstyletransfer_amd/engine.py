@@ -328,6 +328,15 @@ class StepPlan:
         self._wgrads = []
         # work buffer of the single wgrad launch's two-pass reduction (tiles x split x 256 KiB; 64 MiB covers configs[1])
         self.wgrad_scratch = torch.empty(16 * 1024 * 1024, **f32)
+        # LayerNorm parameter gradients: every LayerNorm-backward workgroup leaves one row of column sums here and ONE
+        # launch per flush adds them into the bucket (256 workgroups x one atomic per column on the same 2D addresses
+        # serialised for ~5 us per launch: 30 us of the step at configs[1])
+        self._ln_part, self._psums = {}, []
+        for side, n_l, M, D in (("encoder", cfg.e_layers, self.Me, De), ("decoder", cfg.d_layers, self.Md, Dd)):
+            rows = max(o.layernorm_bwd_parts(M, D), o.gemm_nt_ln_parts(M))
+            for i in range(n_l):
+                for ln in ("ln1", "ln2" if side == "encoder" else "ln3"):
+                    self._ln_part[f"{side}.layer{i}.{ln}"] = torch.zeros(rows, 2 * D, **f32)
         self.lat_scratch = torch.zeros(B * (Dd + 2 * Z), **f32)
         # Sparse gradient carriers, never used as ping-pong targets so their untouched rows stay zero:
         #   d_dec_out: d(decoder output) - rows 1..T written by the output-layer dgrad, row 0 always 0 (model.py:253)
@@ -532,15 +541,36 @@ class StepPlan:
         o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
 
     # ------------------------------------------------------------------------------ backward
-    def _out_ln_bwd(self, side, i, L, D, p, site0, t):
+    LN_PARTIALS_MIN = 32  # fewer workgroups than this: their atomics are cheaper than a row of partials each
+
+    def _ln_partials(self, site, parts):
+        """partials buffer of one LayerNorm-backward launch (None: few workgroups, keep the atomics); registers the
+        deferred column sums into dgamma / dbeta, executed by _flush_grads()"""
+        if parts < self.LN_PARTIALS_MIN:
+            return None
+        st, buf = self.store, self._ln_part[site]
+        dg, db = st.grad(f"{site}.gamma"), st.grad(f"{site}.beta")
+        D = dg.numel()
+        if db.data_ptr() == dg.data_ptr() + 4 * D:  # adjacent in the flat bucket: one job
+            self._psums.append(o.partial_sum_job(buf, parts, dg, length=2 * D))
+        else:
+            self._psums += [o.partial_sum_job(buf, parts, dg, length=D), o.partial_sum_job(buf, parts, db, col_off=D, length=D)]
+        return buf
+
+    def _flush_grads(self):
+        """the weight gradients collected so far in one wgrad launch; the LayerNorm column sums ride on its reduction pass"""
+        o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch, sums=self._psums)
+        self._wgrads, self._psums = [], []
+
+    def _out_ln_bwd(self, side, i, L, D, p, site0, t, M):
         """The LayerNorm backward a layer's backward pass STARTS with (LN2 of an encoder layer, LN3 of a decoder layer),
-        as keyword arguments for ops.gemm_nt_ln_bwd: the GEMM that produces the layer's incoming gradient runs it in
-        its epilogue (dX_out = t.dh) when the row width allows, see _layer_bwd(dy_done=...)."""
+        as keyword arguments for ops.gemm_nt_ln_bwd: the GEMM (of M rows) that produces the layer's incoming gradient runs
+        it in its epilogue (dX_out = t.dh) when the row width allows, see _layer_bwd(dy_done=...)."""
         st = self.store
         pre = f"{side}.layer{i}"
         ln = "ln2" if side == "encoder" else "ln3"
         kw = dict(x=L.h2, gamma=st.p(f"{pre}.{ln}.gamma"), mean=L.mean2, rstd=L.rstd2, dgamma=st.grad(f"{pre}.{ln}.gamma"),
-                  dbeta=st.grad(f"{pre}.{ln}.beta"))
+                  dbeta=st.grad(f"{pre}.{ln}.beta"), partials=self._ln_partials(f"{pre}.{ln}", o.gemm_nt_ln_parts(M)))
         if side == "encoder":
             kw.update(dict(mask_mode=1, dx_masked=t.dhm) if p > 0 else dict(mask_mode=0))
         else:
@@ -560,20 +590,24 @@ class StepPlan:
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
         fuse = o.ln_bwd_fusion_pays(D)
+        M = L.h1.shape[0]
         if side == "encoder":
             if not dy_done:
+                part = self._ln_partials(f"{pre}.ln2", o.layernorm_bwd_parts(M, D))
                 if p > 0:
                     o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
-                                    st.grad(f"{pre}.ln2.beta"), D=D, dx_masked=t.dhm, mask_mode=1, dropout_site=site0 + 2, **dk)
+                                    st.grad(f"{pre}.ln2.beta"), D=D, dx_masked=t.dhm, mask_mode=1, dropout_site=site0 + 2,
+                                    partials=part, **dk)
                 else:
                     o.layernorm_bwd(L.h2, st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln2.gamma"),
-                                    st.grad(f"{pre}.ln2.beta"), D=D)
+                                    st.grad(f"{pre}.ln2.beta"), D=D, partials=part)
             dff = t.dhm if p > 0 else t.dh
             resid_ff = t.dh
         else:
             if not dy_done:
                 o.layernorm_bwd(L.h2, st.p(f"{pre}.ln3.gamma"), L.mean2, L.rstd2, dy, t.dh, st.grad(f"{pre}.ln3.gamma"),
-                                st.grad(f"{pre}.ln3.beta"), D=D, mask_mode=2, dropout_site=site0 + 2, **dk)
+                                st.grad(f"{pre}.ln3.beta"), D=D, mask_mode=2, dropout_site=site0 + 2,
+                                partials=self._ln_partials(f"{pre}.ln3", o.layernorm_bwd_parts(M, D)), **dk)
             dff = t.dh
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
@@ -581,11 +615,13 @@ class StepPlan:
         ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
         if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
             o.gemm_nt_ln_bwd(t.dpre, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1,
-                             st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), N=D, K=4 * D, resid=resid_ff, **ln1)
+                             st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), N=D, K=4 * D, resid=resid_ff,
+                             partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), **ln1)
         else:
             o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
             o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
-                            st.grad(f"{pre}.ln1.beta"), D=D, **ln1)
+                            st.grad(f"{pre}.ln1.beta"), D=D, partials=self._ln_partials(f"{pre}.ln1", o.layernorm_bwd_parts(M, D)),
+                            **ln1)
         dproj = t.dh1m if p > 0 else t.dh1
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
@@ -675,6 +711,7 @@ class StepPlan:
         Se, Sd = T, T + 1
         sq_d = math.sqrt(float(Dd))
         # (the gradient bucket was cleared by forward()'s step_begin launch)
+        self._wgrads, self._psums = [], []
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         fuse_d, fuse_e = o.ln_bwd_fusion_pays(Dd), o.ln_bwd_fusion_pays(De)
@@ -683,7 +720,7 @@ class StepPlan:
         if fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
             o.gemm_nt_ln_bwd(self.dlogits, st.t("decoder.output_layer.weight"), self.bd_l[last].dh, M=B * T, N=Dd, K=ldv,
                              c_remap=(T, Sd, 1),
-                             **self._out_ln_bwd("decoder", last, self.dec[last], Dd, cfg.d_dropout, site_d + 3 * last, self.bd_l[last]))
+                             **self._out_ln_bwd("decoder", last, self.dec[last], Dd, cfg.d_dropout, site_d + 3 * last, self.bd_l[last], B * T))
         else:
             o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
         self._wgrads = [o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
@@ -691,7 +728,7 @@ class StepPlan:
         dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
         for i in reversed(range(cfg.d_layers)):
             x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d
-            below = (self._out_ln_bwd("decoder", i - 1, self.dec[i - 1], Dd, cfg.d_dropout, site_d + 3 * (i - 1), self.bd_l[i - 1]),
+            below = (self._out_ln_bwd("decoder", i - 1, self.dec[i - 1], Dd, cfg.d_dropout, site_d + 3 * (i - 1), self.bd_l[i - 1], self.Md),
                      self.bd_l[i - 1]) if (fuse_d and i > 0) else None
             self._layer_bwd("decoder", i, self.dec[i], x_in, dy, tgt, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout,
                             site_d + 3 * i, self.bd_l[i], dy_done=fuse_d, next_ln=below)
@@ -714,12 +751,11 @@ class StepPlan:
                      enc_scale=self.gscale_enc / self.gscale)
         top = cfg.e_layers - 1
         x_in = self.enc[top - 1].x2 if top > 0 else self.x0_e
-        below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, 3 * (top - 1), self.be_l[top - 1]),
+        below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, 3 * (top - 1), self.be_l[top - 1], self.Me),
                  self.be_l[top - 1]) if (fuse_e and top > 0) else None
         self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top], next_ln=below)
         if flush and cfg.e_layers >= 2:
-            o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch)
-            self._wgrads = []
+            self._flush_grads()
 
     def backward_late(self):
         """The encoder layers below the top one, the encoder input, and the (remaining) weight gradients."""
@@ -730,7 +766,7 @@ class StepPlan:
         fuse_e = o.ln_bwd_fusion_pays(De)  # then every layer's leading LayerNorm backward already ran in the GEMM above it
         for i in reversed(range(cfg.e_layers - 1)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
-            below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, 3 * (i - 1), self.be_l[i - 1]),
+            below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, 3 * (i - 1), self.be_l[i - 1], self.Me),
                      self.be_l[i - 1]) if (fuse_e and i > 0) else None
             self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
                             3 * i, self.be_l[i], dy_done=fuse_e, next_ln=below)
@@ -745,8 +781,7 @@ class StepPlan:
             o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
         # every (remaining) Dense weight / bias gradient in ONE launch — all 15 problems of the step at configs[1] on a
         # single GPU: one resident round of workgroups with the smallest possible M-split instead of six launches
-        o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch)
-        self._wgrads = []
+        self._flush_grads()
 
     def optimizer(self):
         st = self.store

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import LnArgs, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, PartialSum, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -101,10 +101,11 @@ def gemm_nt_ln_fwd(A, B, H_out, gamma, beta, Y_out, mean, rstd, eps=1e-5, **kw):
     call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
 
 
-def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, **kw):
+def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):
     """dX_out = LayerNorm-backward(epilogue(A @ B^T); x, mean, rstd, gamma) in one launch (mst_gemm_nt_ln, mode 2); x, mean,
     rstd are indexed by dX_out's physical row, dx_masked by the logical row; the dropout fields among **kw are those of
-    the LayerNorm-backward mask"""
+    the LayerNorm-backward mask. partials: [gemm_nt_ln_parts(M), 2N] fp32 -> per-workgroup column sums are stored there
+    instead of being added to dgamma / dbeta (finish with partial_sums)"""
     g = _gemm_args(A, B, dX_out, **kw)
     l = LnArgs()
     l.mode, l.gamma = 2, ptr(gamma)
@@ -113,7 +114,39 @@ def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=
     l.dgamma, l.dbeta = ptr(dgamma), ptr(dbeta)
     l.out, l.ld_out = ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0)
     l.mask_mode = mask_mode
+    l.partials = ptr(partials)
+    if partials is not None:
+        assert partials.shape[0] >= gemm_nt_ln_parts(g.M) and partials.shape[1] == 2 * g.N and partials.is_contiguous()
     call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
+
+
+def gemm_nt_ln_parts(M):
+    return int(_lib.load().mst_gemm_nt_ln_parts(M))
+
+
+def layernorm_bwd_parts(M, D):
+    return int(_lib.load().mst_layernorm_bwd_parts(M, D))
+
+
+PARTIAL_SUM_MAX_JOBS = 24
+
+
+def partial_sum_job(src, n_parts, dst, scale=1.0, col_off=0, length=None):
+    """dst[0:length] += scale * sum_p src[p, col_off:col_off+length] (src: [>= n_parts, stride] fp32, contiguous rows)"""
+    j = PartialSum()
+    length = dst.numel() if length is None else length
+    assert src.dtype == dst.dtype and src.element_size() == 4 and src.shape[0] >= n_parts
+    j.src = src.data_ptr() + 4 * col_off
+    j.n_parts, j.stride, j.len = n_parts, src.stride(0), length
+    j.dst, j.scale = ptr(dst), scale
+    return j
+
+
+def partial_sums(jobs):
+    """mst_partial_sums: every job's parts added in index order, 24 jobs per launch"""
+    for i in range(0, len(jobs), PARTIAL_SUM_MAX_JOBS):
+        chunk = jobs[i:i + PARTIAL_SUM_MAX_JOBS]
+        call("mst_partial_sums", (PartialSum * len(chunk))(*chunk), len(chunk), stream())
 
 
 def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=(0, 0, 0), b_remap=(0, 0, 0)):
@@ -135,16 +168,25 @@ def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=
 WGRAD_MAX_PROBLEMS = 16
 
 
-def gemm_wgrad_batch(problems, scratch=None):
+def gemm_wgrad_batch(problems, scratch=None, sums=None):
     """dW_i[N,K] += A_i^T @ B_i for a list of problems, 16 per launch. scratch: optional fp32 work buffer for the
-    atomic-free two-pass reduction of big batches (mst_gemm_wgrad_batch_ws)."""
+    atomic-free two-pass reduction of big batches (mst_gemm_wgrad_batch_ws). sums: column-sum jobs (partial_sum_job)
+    to execute along with the weight gradients (mst_gemm_wgrad_batch_sums)."""
+    sums = list(sums or [])
     for i in range(0, len(problems), WGRAD_MAX_PROBLEMS):
         chunk = problems[i:i + WGRAD_MAX_PROBLEMS]
         arr = (WgradArgs * len(chunk))(*chunk)
-        if scratch is None:
+        if sums and i + WGRAD_MAX_PROBLEMS >= len(problems):  # the last launch takes (the first 24 of) the sums along
+            take, sums = sums[:PARTIAL_SUM_MAX_JOBS], sums[PARTIAL_SUM_MAX_JOBS:]
+            call("mst_gemm_wgrad_batch_sums", arr, len(chunk), ptr(scratch),
+                 (scratch.numel() * scratch.element_size() if scratch is not None else 0),
+                 (PartialSum * len(take))(*take), len(take), stream())
+        elif scratch is None:
             call("mst_gemm_wgrad_batch", arr, len(chunk), stream())
         else:
             call("mst_gemm_wgrad_batch_ws", arr, len(chunk), ptr(scratch), scratch.numel() * scratch.element_size(), stream())
+    if sums:
+        partial_sums(sums)
 
 
 def gemm_wgrad(A, B, dW, db=None, **kw):
@@ -172,12 +214,15 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5, M=None, row_i
 
 
 def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, D=None, dx_masked=None, mask_mode=0, dropout_p=0.0,
-                  dropout_seed=0, dropout_site=0, dropout_seed_ptr=None, M=None, row_id_stride=1):
+                  dropout_seed=0, dropout_site=0, dropout_seed_ptr=None, M=None, row_id_stride=1, partials=None):
+    """partials: [layernorm_bwd_parts(M, D), 2D] fp32 -> per-workgroup column sums instead of atomics on dgamma / dbeta"""
     M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
+    if partials is not None:
+        assert partials.shape[0] >= layernorm_bwd_parts(M, D) and partials.shape[1] == 2 * D and partials.is_contiguous()
     call("mst_layernorm_bwd", dt(x), M, D, ptr(x), ld(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ld(dy), ptr(dx),
          ld(dx), ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0), ptr(dgamma), ptr(dbeta), mask_mode,
-         dropout_p, dropout_seed, dropout_site, ptr(dropout_seed_ptr), row_id_stride, stream())
+         dropout_p, dropout_seed, dropout_site, ptr(dropout_seed_ptr), row_id_stride, ptr(partials), stream())
 
 
 # --------------------------------------------------------------------------- embedding / masks

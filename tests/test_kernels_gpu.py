@@ -185,14 +185,19 @@ def test_gemm_ln_backward_equals_gemm_then_layernorm_bwd(gpu, M, N, K, mode, rem
     seedp = torch.tensor([91, 0, 0, 0], dtype=torch.int64, device=gpu)
     drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2) if mode else {}
     res = []
-    for fused in (False, True):
+    for fused in (False, True, "partials"):
         dxf = torch.zeros(rows, N, dtype=BF, device=gpu)
         dx = dxf.view(M, S, -1)[:, 0, :] if remap else dxf
         dxm = torch.zeros(M, N, dtype=BF, device=gpu)
         dg, db = torch.zeros(N, device=gpu), torch.zeros(N, device=gpu)
         if fused:
+            parts = o.gemm_nt_ln_parts(M)
+            part = torch.full((parts, 2 * N), float("nan"), device=gpu) if fused == "partials" else None
             o.gemm_nt_ln_bwd(A, W, dxf, xfull, gam, mean_f, rstd_f, dg, db, dx_masked=dxm if mode == 1 else None,
-                             mask_mode=mode, resid=resid, c_remap=(1, S, 0) if remap else (0, 0, 0), **drop)
+                             mask_mode=mode, resid=resid, c_remap=(1, S, 0) if remap else (0, 0, 0), partials=part, **drop)
+            if part is not None:  # per-workgroup column sums, added by the deferred launch
+                assert (dg == 0).all() and (db == 0).all()
+                o.partial_sums([o.partial_sum_job(part, parts, dg, length=N), o.partial_sum_job(part, parts, db, col_off=N, length=N)])
         else:
             dy = torch.zeros(M, N, dtype=BF, device=gpu)
             o.gemm_nt(A, W, dy, resid=resid)
@@ -205,6 +210,9 @@ def test_gemm_ln_backward_equals_gemm_then_layernorm_bwd(gpu, M, N, K, mode, rem
     close(res[1][1], res[0][1], 1e-2, 1e-2 * scale, "dx masked")
     close(res[1][2], res[0][2], 1e-3, 1e-3 * res[0][2].abs().max().item(), "dgamma")
     close(res[1][3], res[0][3], 1e-3, 1e-3 * res[0][3].abs().max().item(), "dbeta")
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1])
+    close(res[2][2], res[0][2], 1e-3, 1e-3 * res[0][2].abs().max().item(), "dgamma from partials")
+    close(res[2][3], res[0][3], 1e-3, 1e-3 * res[0][3].abs().max().item(), "dbeta from partials")
     if remap:  # rows the launch does not own stay untouched
         assert (res[1][0].view(M, S, -1)[:, 1:] == 0).all()
 
@@ -263,11 +271,20 @@ def test_gemm_wgrad_two_pass_reduction_is_deterministic_and_equal(gpu):
         probs.append((A, B, N, K))
     scratch = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=gpu)
 
+    # column-sum jobs that ride along (on the reduction pass with the scratch buffer, in their own launch without)
+    g = torch.Generator().manual_seed(3)
+    part = torch.randint(-8, 9, (300, 512), generator=g).float().to(gpu)
+    sum_specs = [(257, 0, 512), (300, 256, 128), (1, 4, 60)] * 9  # 27 jobs: more than one launch's worth
+    colsums = []
+
     def run(ws):
         outs = [(torch.zeros(N, K, device=gpu), torch.zeros(N, device=gpu)) for _, _, N, K in probs]
+        dsts = [torch.ones(length, device=gpu) for _, _, length in sum_specs]
         o.gemm_wgrad_batch([o.wgrad_problem(A, B, dW, db, N=N, K=K, scale=0.5) for (A, B, N, K), (dW, db) in zip(probs, outs)],
-                           scratch=scratch if ws else None)
+                           scratch=scratch if ws else None,
+                           sums=[o.partial_sum_job(part, n, d, col_off=off, length=length) for (n, off, length), d in zip(sum_specs, dsts)])
         torch.cuda.synchronize()
+        colsums.append(dsts)
         return outs
 
     atomic, two_a, two_b = run(False), run(True), run(True)
@@ -277,6 +294,9 @@ def test_gemm_wgrad_two_pass_reduction_is_deterministic_and_equal(gpu):
         close(dW1, dWa, 1e-5, 1e-4 * ref.abs().max().item(), "two-pass vs atomic")
         close(db1, 0.5 * A[:, :N].float().sum(0), 1e-4, 1e-2, "db")
         assert torch.equal(dW1, dW2), "the two-pass reduction must be run-to-run deterministic"
+    for dsts in colsums:
+        for (n, off, length), d in zip(sum_specs, dsts):
+            assert torch.equal(d, 1.0 + part[:n, off:off + length].sum(0))
 
 
 def test_gemm_wgrad_remap(gpu):
@@ -441,6 +461,21 @@ def test_layernorm_fwd_bwd(gpu, M, D):
     close(dx, xr.grad, 1e-2, 1e-2, "ln dx")
     close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dgamma")
     close(db, br.grad, 1e-3, 1e-3 * math.sqrt(M), "ln dbeta")
+    # per-workgroup partial sums + the deferred reduction instead of atomics: same dx, same sums, and bit-reproducible
+    parts = o.layernorm_bwd_parts(M, D)
+    outs = []
+    for _ in range(2):
+        part = torch.full((parts, 2 * D), float("nan"), device=gpu)
+        dxp = torch.zeros(M, D, dtype=BF, device=gpu)
+        dgb = torch.full((2 * D,), 1.0, device=gpu)  # accumulated INTO
+        o.layernorm_bwd(x, gamma, mean, rstd, dy, dxp, None, None, partials=part)
+        o.partial_sums([o.partial_sum_job(part, parts, dgb, scale=0.5)])
+        torch.cuda.synchronize()
+        outs.append(dgb.clone())
+        assert torch.equal(dxp, dx)
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0][:D], 1.0 + 0.5 * gr.grad, 1e-3, 1e-3 * math.sqrt(M), "dgamma from partials")
+    close(outs[0][D:], 1.0 + 0.5 * br.grad, 1e-3, 1e-3 * math.sqrt(M), "dbeta from partials")
     # strided row subset (every 4th row), statistics indexed by the dense row id
     if M % 4 == 0:
         Ms = M // 4
@@ -458,6 +493,24 @@ def test_layernorm_fwd_bwd(gpu, M, D):
         assert torch.equal(mean2[::4], mean[::4]) and (mean2.view(Ms, 4)[:, 1:] == 0).all()
         assert torch.equal(dx2, dx[::4])
         close(db2, dy.float()[::4].sum(0), 1e-3, 1e-3 * math.sqrt(M), "strided dbeta")
+
+
+def test_partial_sums_integer_exact(gpu):
+    """mst_partial_sums: many jobs of different shapes in one launch; integer-valued data make every order exact"""
+    o = ops()
+    g = torch.Generator().manual_seed(7)
+    jobs, want, dsts = [], [], []
+    for n_parts, stride, length, off, scale in [(1, 8, 8, 0, 1.0), (257, 512, 256, 256, 1.0), (40, 132, 68, 64, 2.0),
+                                                (3, 1024, 1024, 0, -1.0), (300, 64, 60, 4, 1.0)] * 7:  # 35 jobs: two launches
+        src = torch.randint(-8, 9, (n_parts + 2, stride), generator=g).float().to(gpu)
+        dst = torch.randint(-8, 9, (length,), generator=g).float().to(gpu)
+        want.append(dst + scale * src[:n_parts, off:off + length].sum(0))
+        jobs.append(o.partial_sum_job(src, n_parts, dst, scale=scale, col_off=off, length=length))
+        dsts.append((src, dst))
+    o.partial_sums(jobs)
+    torch.cuda.synchronize()
+    for (src, dst), w in zip(dsts, want):
+        assert torch.equal(dst, w)
 
 
 def test_layernorm_bwd_dropout_modes(gpu):
