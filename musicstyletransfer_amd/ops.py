@@ -86,7 +86,8 @@ def can_fuse_ln(D):
 def ln_bwd_fusion_pays(D):
     """Where the engine routes Dense-dgrad + LayerNorm-backward through the fused launch. Measured at configs[1] (step
     level, ms per step): no fusion 0.953, width 128 only 0.945, widths 128 and 256 0.951 — at width 256 the 64 x 256
-    tile leaves one 8-wave workgroup per CU and the GEMM part loses what the saved LayerNorm launch gains."""
+    tile leaves one 8-wave workgroup per CU and the GEMM part loses what the saved LayerNorm launch gains (still so
+    once the parameter gradients left the atomics: 0.917 without, 0.922 with the width-256 fusion)."""
     return D == 128
 
 
