@@ -19,6 +19,7 @@ namespace mst {
 
 constexpr int LAT_THREADS = 1024;  // 16 waves: these kernels are B workgroups of dependent dot products (latency-bound)
 constexpr int OPW = 8;             // outputs a wave works on at once
+constexpr int PRE_C = 4;           // 64-lane chunks of a contraction whose weights the forward keeps in registers (De <= 256)
 
 // out[j] = sum_d x[d] * W[j, d] for j < n_out: wave w takes outputs [w*U, w*U+U), then strides by n_waves*U;
 // `emit(j, value)` runs on lane 0
@@ -62,16 +63,59 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
   constexpr int NW = LAT_THREADS / 64;
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Every load whose ADDRESS does not depend on a result is issued before the first barrier: in the step all of these
+  // lines are cold (the weights were rewritten by the optimizer), and the three phases used to pay five dependent
+  // memory round trips (20 us for a few hundred kFLOP). Fast path: one pass of OPW outputs per wave in both products.
+  const bool pre1 = 2 * Z <= NW * OPW && De <= 64 * PRE_C, pre2 = Dd <= NW * OPW && Z <= 64;
+  const int c = classes[b];
+  float w1[OPW][PRE_C], w2[OPW], b1 = 0.f, bh2 = 0.f, cls2 = 0.f, pos2 = 0.f, eps_r = 0.f;
+  const int j1 = wave * OPW;  // this wave's outputs in both products
+  if (pre1) {
+#pragma unroll
+    for (int u = 0; u < OPW; ++u)
+#pragma unroll
+      for (int k = 0; k < PRE_C; ++k) {
+        const int d = lane + k * 64;
+        w1[u][k] = (j1 + u < 2 * Z && d < De) ? Wl[(int64_t)(j1 + u) * De + d] : 0.f;
+      }
+    if (lane < OPW && j1 + lane < 2 * Z) b1 = bl[j1 + lane];
+  }
+  if (pre2) {
+#pragma unroll
+    for (int u = 0; u < OPW; ++u) w2[u] = (j1 + u < Dd && lane < Z) ? Wh[(int64_t)(j1 + u) * Z + lane] : 0.f;
+    if (lane < OPW && j1 + lane < Dd) {
+      bh2 = bh[j1 + lane];
+      cls2 = cls_d[(int64_t)c * ld_cls + j1 + lane];
+      pos2 = pos_d[j1 + lane];
+    }
+  }
+  if (tid < Z) eps_r = eps[b * Z + tid];
   for (int d = tid; d < De; d += LAT_THREADS) h0[d] = to_f32(enc_out[b * enc_stride + d]);
   __syncthreads();
   // one wave per output, lanes across the contraction (coalesced weight rows); OPW outputs at a time so that their
   // weight loads are all in flight together (one output at a time was eight dependent L2 round trips per wave)
-  wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
+  if (pre1) {
+    float acc[OPW];
+#pragma unroll
+    for (int u = 0; u < OPW; ++u) {
+      acc[u] = 0.f;
+#pragma unroll
+      for (int k = 0; k < PRE_C; ++k)
+        if (lane + k * 64 < De) acc[u] = fmaf(h0[lane + k * 64], w1[u][k], acc[u]);  // same order as wave_dots
+    }
+#pragma unroll
+    for (int u = 0; u < OPW; ++u) {
+      const float v = wave_sum(acc[u]);
+      if (lane == u && j1 + u < 2 * Z) lat[j1 + u] = v + b1;
+    }
+  } else {
+    wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
+  }
   __syncthreads();
   float klacc = 0.f;
   for (int i = tid; i < Z; i += LAT_THREADS) {
     const float m = lat[i], s = lat[Z + i];
-    const float zz = m + eps[b * Z + i] * s;
+    const float zz = m + (i == tid ? eps_r : eps[b * Z + i]) * s;
     mu[b * Z + i] = m;
     sigma[b * Z + i] = s;
     z[b * Z + i] = zz;
@@ -87,11 +131,19 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
     for (int w = 0; w < NW; ++w) t += klred[w];
     kl[b] = t;
   }
-  const int c = classes[b];
-  wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, [&](int j, float acc) {
-    const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
-    dec_in[b * dec_stride + j] = from_f32<T>(v);
-  });
+  if (pre2) {
+    const float zv = lane < Z ? zs[lane] : 0.f;
+#pragma unroll
+    for (int u = 0; u < OPW; ++u) {
+      const float v = wave_sum(zv * w2[u]);  // (fmaf(zv, w, 0) of wave_dots)
+      if (lane == u && j1 + u < Dd) dec_in[b * dec_stride + j1 + u] = from_f32<T>(alpha_d * (v + bh2 + cls2) + pos2);
+    }
+  } else {
+    wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, [&](int j, float acc) {
+      const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
+      dec_in[b * dec_stride + j] = from_f32<T>(v);
+    });
+  }
 }
 
 // per-sample backward vectors: t = alpha_d * g0, dz, dlat = [dmu | dsigma], dh0.
@@ -115,6 +167,29 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   float* part = dl + 2 * Z;  // [LAT_THREADS] partial sums
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
+  // Fast path (one round per product, few rows per thread): the weight elements a thread will contract, and mu / sigma
+  // / eps, are loaded before the first barrier — their addresses depend on nothing computed here, and in the step they
+  // are cold lines (three dependent round trips otherwise).
+  constexpr int PRE_H = 8, PRE_L = 32;
+  const int zc = Z < LAT_THREADS ? Z : LAT_THREADS, np_h = LAT_THREADS / zc > 0 ? LAT_THREADS / zc : 1;
+  const int dc = De < LAT_THREADS ? De : LAT_THREADS, np_l = LAT_THREADS / dc > 0 ? LAT_THREADS / dc : 1;
+  const bool pre = Z <= LAT_THREADS && De <= LAT_THREADS && (Dd + np_h - 1) / np_h <= PRE_H && (2 * Z + np_l - 1) / np_l <= PRE_L;
+  float wh[PRE_H], wl[PRE_L], m_r = 0.f, s_r = 0.f, e_r = 0.f;
+  if (pre) {
+    const int i = tid % zc, pt = tid / zc;
+#pragma unroll
+    for (int k = 0; k < PRE_H; ++k) {
+      const int j = pt + k * np_h;
+      wh[k] = (pt < np_h && j < Dd) ? Wh[(int64_t)j * Z + i] : 0.f;
+    }
+    const int d = tid % dc, pl = tid / dc;
+#pragma unroll
+    for (int k = 0; k < PRE_L; ++k) {
+      const int j = pl + k * np_l;
+      wl[k] = (pl < np_l && j < 2 * Z) ? Wl[(int64_t)j * De + d] : 0.f;
+    }
+    if (tid < Z) { m_r = mu[b * Z + tid]; s_r = sigma[b * Z + tid]; e_r = eps[b * Z + tid]; }
+  }
   for (int j = tid; j < Dd; j += LAT_THREADS) {
     const float v = alpha_d * to_f32(d_dec_in[b * dec_stride + j]);
     t[j] = v;
@@ -123,24 +198,28 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   __syncthreads();
   // dz[i] = sum_j t[j] * Wh[j,i]: thread (i, part) sums every np-th j
   {
-    const int np = LAT_THREADS / Z > 0 ? LAT_THREADS / Z : 1;  // parts per output (16 at Z = 64)
+    const int np = np_h;  // parts per output (16 at Z = 64)
     for (int i0 = 0; i0 < Z; i0 += LAT_THREADS) {             // one round unless Z > 1024
-      const int i = i0 + tid % (Z < LAT_THREADS ? Z : LAT_THREADS), pt = tid / (Z < LAT_THREADS ? Z : LAT_THREADS);
+      const int i = i0 + tid % zc, pt = tid / zc;
       float acc = 0.f;
-      if (i < Z && pt < np)
+      if (pre) {
+#pragma unroll
+        for (int k = 0; k < PRE_H; ++k)
+          if (pt + k * np < Dd) acc = fmaf(t[pt + k * np], wh[k], acc);
+      } else if (i < Z && pt < np) {
         for (int j = pt; j < Dd; j += np) acc = fmaf(t[j], Wh[(int64_t)j * Z + i], acc);
+      }
       part[tid] = acc;
       __syncthreads();
       if (tid < Z - i0 && tid < LAT_THREADS) {
-        const int zc = Z < LAT_THREADS ? Z : LAT_THREADS;
         float a = 0.f;
         for (int p2 = 0; p2 < np && p2 * zc + tid < LAT_THREADS; ++p2) a += part[p2 * zc + tid];
         const int ii = i0 + tid;
-        const float m = mu[b * Z + ii], s2 = sigma[b * Z + ii];
+        const float m = pre ? m_r : mu[b * Z + ii], s2 = pre ? s_r : sigma[b * Z + ii], ee = pre ? e_r : eps[b * Z + ii];
         // gscale: loss scale of everything upstream of here (the encoder); enc_scale = gscale / (loss scale the
         // incoming decoder-side gradient carries). Both are 1 unless fp16 loss scaling is on.
         const float dm = kl_weight * gscale * m + enc_scale * a;
-        const float ds = kl_weight * gscale * (s2 - 1.f / s2) + enc_scale * eps[b * Z + ii] * a;
+        const float ds = kl_weight * gscale * (s2 - 1.f / s2) + enc_scale * ee * a;
         dl[ii] = dm;
         dl[Z + ii] = ds;
         dlat[b * 2 * Z + ii] = dm;
@@ -151,13 +230,17 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   }
   // dh0[d] = sum_j dlat[j] * Wl[j,d], same split
   {
-    const int dc = De < LAT_THREADS ? De : LAT_THREADS;
-    const int np = LAT_THREADS / dc > 0 ? LAT_THREADS / dc : 1;  // 4 at De = 256
+    const int np = np_l;  // 4 at De = 256
     for (int d0 = 0; d0 < De; d0 += LAT_THREADS) {
       const int d = d0 + tid % dc, pt = tid / dc;
       float acc = 0.f;
-      if (d < De && pt < np)
+      if (pre) {
+#pragma unroll
+        for (int k = 0; k < PRE_L; ++k)
+          if (pt + k * np < 2 * Z) acc = fmaf(dl[pt + k * np], wl[k], acc);
+      } else if (d < De && pt < np) {
         for (int j = pt; j < 2 * Z; j += np) acc = fmaf(dl[j], Wl[(int64_t)j * De + d], acc);
+      }
       part[tid] = acc;
       __syncthreads();
       if (tid < dc && d0 + tid < De) {
@@ -170,33 +253,46 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   }
 }
 
-// parameter gradients: out[j, i] += sum_b L[b, j] * R[b, i]; obias[j] += sum_b L[b, j]. One output per thread, the
-// batch loop unrolled 8-fold on independent accumulators (the loop is load-latency bound).
+// parameter gradients: out[j, i] += sum_b L[b, j] * R[b, i]; obias[j] += sum_b L[b, j]. A 256-thread workgroup owns 64
+// outputs; its four waves take a quarter of the batch each (8 rows in flight per thread: the strided rows of R are cold
+// lines and the loop is one memory round trip per group — one thread per output walking the whole batch was 11 us) and
+// the quarters are added in order through LDS (deterministic).
 template <typename RT>
-__device__ __forceinline__ void batch_outer(int64_t idx, int64_t B, int J, int I, const float* __restrict__ L,
+__device__ __forceinline__ void batch_outer(int64_t blk, int tid, int64_t B, int J, int I, const float* __restrict__ L,
                                             const RT* __restrict__ R, int64_t r_stride, float* __restrict__ out,
-                                            float* __restrict__ obias) {
+                                            float* __restrict__ obias, float (*red)[64]) {
+  const int o = tid & 63, part = tid >> 6;
+  const int64_t idx = blk * 64 + o;
+  const int64_t per = (B + 3) / 4, b0 = part * per, b1 = b0 + per < B ? b0 + per : B;
+  float acc = 0.f, accb = 0.f;
   if (idx < (int64_t)J * I) {
     const int j = (int)(idx / I), i = (int)(idx % I);
     float a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = 0.f;
-    int64_t b = 0;
-    for (; b + 8 <= B; b += 8) {
+    int64_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) a[u] = fmaf(L[(b + u) * J + j], to_f32(R[(b + u) * r_stride + i]), a[u]);
     }
-    for (; b < B; ++b) a[0] = fmaf(L[b * J + j], to_f32(R[b * r_stride + i]), a[0]);
-    out[idx] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (; b < b1; ++b) a[0] = fmaf(L[b * J + j], to_f32(R[b * r_stride + i]), a[0]);
+    acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   if (obias && idx < J) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t b = 0;
-    for (; b + 4 <= B; b += 4) {
+    int64_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
       a0 += L[(b + 0) * J + idx]; a1 += L[(b + 1) * J + idx]; a2 += L[(b + 2) * J + idx]; a3 += L[(b + 3) * J + idx];
     }
-    for (; b < B; ++b) a0 += L[b * J + idx];
-    obias[idx] += (a0 + a1) + (a2 + a3);
+    for (; b < b1; ++b) a0 += L[b * J + idx];
+    accb = (a0 + a1) + (a2 + a3);
+  }
+  red[part][o] = acc;
+  red[4 + part][o] = accb;
+  __syncthreads();
+  if (part == 0) {
+    if (idx < (int64_t)J * I) out[idx] += (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (obias && idx < J) obias[idx] += (red[4][o] + red[5][o]) + (red[6][o] + red[7][o]);
   }
 }
 
@@ -211,11 +307,12 @@ __global__ __launch_bounds__(256) void latent_param_grads_kernel(int64_t B, int 
                                                                  float* __restrict__ dbl, float* __restrict__ dWh,
                                                                  float* __restrict__ dbh, float* __restrict__ dcls, int64_t ld_cls,
                                                                  int n_wl, int n_wh) {
+  __shared__ float red[8][64];
   const int blk = blockIdx.x;
   if (blk < n_wl) {
-    batch_outer<T>((int64_t)blk * 256 + threadIdx.x, B, 2 * Z, De, dlat, enc_out, enc_stride, dWl, dbl);
+    batch_outer<T>(blk, threadIdx.x, B, 2 * Z, De, dlat, enc_out, enc_stride, dWl, dbl, red);
   } else if (blk < n_wl + n_wh) {
-    batch_outer<float>((int64_t)(blk - n_wl) * 256 + threadIdx.x, B, Dd, Z, tvec, z, Z, dWh, dbh);
+    batch_outer<float>(blk - n_wl, threadIdx.x, B, Dd, Z, tvec, z, Z, dWh, dbh, red);
   } else {
     const int64_t idx = (int64_t)(blk - n_wl - n_wh) * 256 + threadIdx.x;
     if (idx < B * Dd) atomicAdd(dcls + (int64_t)classes[idx / Dd] * ld_cls + idx % Dd, tvec[idx]);
@@ -262,7 +359,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   float* dlat = scratch + B * Dd;   // [B, 2Z]
   MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd: latent size above %d", LAT_THREADS);
   const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
-  const int n_wl = (int)cdiv(2 * Z * De, 256), n_wh = (int)cdiv(Dd * Z, 256), n_cls = (int)cdiv(B * Dd, 256);
+  const int n_wl = (int)cdiv(2 * Z * De, 64), n_wh = (int)cdiv(Dd * Z, 64), n_cls = (int)cdiv(B * Dd, 256);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
