@@ -21,7 +21,11 @@ namespace mst {
 // dependent K tiles, each one exposed memory round trip).
 
 // Shared epilogue of the GEMM kernels (called after a workgroup barrier: `smem` is free to reuse).
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32>
+// ROWOPS: the row-indexed adds (rowadd / grpadd: the two embedding GEMMs of a step) are compiled in. They are a template
+// switch, not a run-time one, because the launch-floor-bound GEMMs of the step (M = 64: four workgroups, every
+// instruction line a cold fetch) measurably pay for code they jump over: +0.4 ... +2.6 us per launch with the row-op code
+// present in the one kernel, against -10 us on the embedding GEMM that uses it.
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS>
 __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0) {
   constexpr int NT = WGM * WGN * 64;
@@ -53,9 +57,22 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
                     (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
                     (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
   const bool has_drop = a.dropout_p > 0.f;
-  const bool has_rowops = a.rowadd || a.grpadd;
-  const bool fast = !C_F32 && !edge && !has_rowops && a.c_rows_per_group <= 0 && (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
+  const bool has_rowops = ROWOPS && (a.rowadd || a.grpadd);
+  // row-indexed adds (positional table row m % period, class row grp_index[m / period]) ride on the fast path when a
+  // tile cannot straddle a period: the class row is then one per tile and the positional rows advance with the tile rows
+  const bool rowops_fast = !has_rowops || (a.rowadd_period % BM == 0 &&
+                                           (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
+                                           (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0)));
+  const bool fast = !C_F32 && !edge && rowops_fast && a.c_rows_per_group <= 0 && (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
                     nc + 8 <= n_store;
+  float ga8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ga8[e] = 0.f;
+  if (ROWOPS && fast && a.grpadd) {
+    const float* gp8 = a.grpadd + (int64_t)a.grp_index[m0 / a.rowadd_period] * a.ldga + nc;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp8), g1 = *reinterpret_cast<const f32x4*>(gp8 + 4);
+    ga8[0] = g0[0]; ga8[1] = g0[1]; ga8[2] = g0[2]; ga8[3] = g0[3]; ga8[4] = g1[0]; ga8[5] = g1[1]; ga8[6] = g1[2]; ga8[7] = g1[3];
+  }
   const bool relu = a.act == MST_ACT_RELU;
   const float alpha = a.alpha;
   float bias8[8];
@@ -91,18 +108,27 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       constexpr int ITERS = WTM / RSTEP;
       // every LDS read and every residual / gate load of the thread's chunks is issued before the first chunk is
       // finished (at two waves per SIMD a chunk-by-chunk loop exposes one LDS + one global round trip per chunk)
-      f32x4 v0[ITERS], v1[ITERS];
+      f32x4 v0[ITERS], v1[ITERS], ra0[ITERS], ra1[ITERS];
       u32x4 rv[ITERS], gv[ITERS];
+      const float* rap = (ROWOPS && a.rowadd) ? a.rowadd + (m0 % a.rowadd_period + pass * WTM + row0) * a.ldra + nc : nullptr;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         v0[it] = *reinterpret_cast<const f32x4*>(sp + it * RSTEP * LDS_F);
         v1[it] = *reinterpret_cast<const f32x4*>(sp + it * RSTEP * LDS_F + 4);
         if (rp) rv[it] = *reinterpret_cast<const u32x4*>(rp + (int64_t)it * RSTEP * a.ldr);
         if (gp) gv[it] = *reinterpret_cast<const u32x4*>(gp + (int64_t)it * RSTEP * a.ldg);
+        if (rap) {
+          ra0[it] = *reinterpret_cast<const f32x4*>(rap + (int64_t)it * RSTEP * a.ldra);
+          ra1[it] = *reinterpret_cast<const f32x4*>(rap + (int64_t)it * RSTEP * a.ldra + 4);
+        }
       }
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         float t[8] = {v0[it][0], v0[it][1], v0[it][2], v0[it][3], v1[it][0], v1[it][1], v1[it][2], v1[it][3]};
+        if (ROWOPS && a.grpadd) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] += ga8[e];
+        }
         if (a.bias) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] += bias8[e];
@@ -123,6 +149,11 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
             const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
             t[e] = a.self_resid ? t[e] + u : u;
           }
+        }
+        if (rap) {
+          const float r8[8] = {ra0[it][0], ra0[it][1], ra0[it][2], ra0[it][3], ra1[it][0], ra1[it][1], ra1[it][2], ra1[it][3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] += r8[e];
         }
         if (rp) {
           Pack8 p8; p8.u = rv[it];
@@ -361,14 +392,14 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK>
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
   gemm_mainloop<T, BM, BN, WGM, WGN, BK>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
-  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32>(a, smem, acc, m0, n0);
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS>(a, smem, acc, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -588,20 +619,20 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const size_t lds_loop = (size_t)2 * (BM + BN) * BK * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
+  const bool rowops = a.rowadd || a.grpadd;
+  const int variant = (a.c_f32 ? 1 : 0) + (rowops ? 2 : 0);
+  typedef void (*kern_t)(mst_gemm_args);
+  const kern_t fns[4] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[2] = {false, false};
-    if (!opted[a.c_f32 ? 1 : 0]) {
-      const void* fn = a.c_f32 ? reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK>)
-                               : reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK>);
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool opted[4] = {false, false, false, false};
+    if (!opted[variant]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
-      opted[a.c_f32 ? 1 : 0] = true;
+      opted[variant] = true;
     }
   }
-  if (a.c_f32)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK>), grid, block, lds, s, a);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK>), grid, block, lds, s, a);
+  hipLaunchKernelGGL(fns[variant], grid, block, lds, s, a);
   MST_CHECK_LAUNCH("gemm_nt_kernel");
   return MST_OK;
 }
@@ -685,7 +716,11 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // every GEMM of the step (time = 4.7 us fixed + 1.7 us per 8.4 MB of output + 4.2 us per 2.1 GFLOP: with K <= 1024
     // a tile's main loop is 2-16 stages of one exposed L2 round trip each, at 12 TB/s of L2->LDS traffic for the
     // K = 1024 shapes). 128x128 is used where it still leaves >= 1.5 workgroups per CU.
-    if (big_tiles >= 384 && a.N >= 128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
+    // Two 128x128 workgroups fit a CU (LDS), 512 on the chip: a launch of 516 (the decoder's M = 64 x 257 rows: 129 row
+    // tiles x 4) runs a second resident round for four workgroups — 21 us against 13 us with 64x64 tiles.
+    const int64_t last_round = big_tiles % 512;
+    const bool stub_round = big_tiles > 512 && last_round > 0 && last_round < 128;
+    if (big_tiles >= 384 && a.N >= 128 && !stub_round) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     if (a.M <= 64 && a.K >= 512 && a.K % 256 == 0) return launch_gemm<T, 64, 64, 2, 2, 256>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });

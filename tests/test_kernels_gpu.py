@@ -70,9 +70,10 @@ def test_gemm_nt_integer_exact_asymmetric(gpu):
     assert torch.equal(C, ref)
 
 
-def test_gemm_nt_epilogue(gpu):
+@pytest.mark.parametrize("S,N,K", [(50, 72, 64), (128, 256, 128), (256, 128, 64)])  # ragged / tile-aligned periods (fast epilogue)
+def test_gemm_nt_epilogue(gpu, S, N, K):
     o = ops()
-    Bsz, S, N, K = 6, 50, 72, 64
+    Bsz = 6
     M = Bsz * S
     A = rnd((M, K), gpu, seed=3)
     W = rnd((N, K), gpu, seed=4, scale=0.2)
