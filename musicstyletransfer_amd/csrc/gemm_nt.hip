@@ -25,7 +25,9 @@ namespace mst {
 // switch, not a run-time one, because the launch-floor-bound GEMMs of the step (M = 64: four workgroups, every
 // instruction line a cold fetch) measurably pay for code they jump over: +0.4 ... +2.6 us per launch with the row-op code
 // present in the one kernel, against -10 us on the embedding GEMM that uses it.
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS>
+// PATH, likewise: 1 = every tile of the launch is interior and eligible for the fast row loop below (the host checks:
+// gemm_fast_eligible), 2 = the guarded general loop only. Two small kernels instead of one with both bodies.
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS, int PATH>
 __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0) {
   constexpr int NT = WGM * WGN * 64;
@@ -53,18 +55,14 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const int ch = tid % CPR;
   const int nc = (int)n0 + ch * 8;             // first column of this thread's chunk (N < 2^31)
   const int N32 = (int)a.N;
-  const bool edge = (m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
-                    (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
-                    (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0)));
+  const bool edge = PATH != 1 && ((m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
+                                  (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
+                                  (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0))));
   const bool has_drop = a.dropout_p > 0.f;
   const bool has_rowops = ROWOPS && (a.rowadd || a.grpadd);
   // row-indexed adds (positional table row m % period, class row grp_index[m / period]) ride on the fast path when a
   // tile cannot straddle a period: the class row is then one per tile and the positional rows advance with the tile rows
-  const bool rowops_fast = !has_rowops || (a.rowadd_period % BM == 0 &&
-                                           (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
-                                           (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0)));
-  const bool fast = !C_F32 && !edge && rowops_fast && a.c_rows_per_group <= 0 && (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
-                    nc + 8 <= n_store;
+  const bool fast = PATH == 1;
   float ga8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) ga8[e] = 0.f;
@@ -95,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
     // loop carries pointers and a 32-bit dropout counter forward by constant strides. At two waves per SIMD the
     // epilogue is VALU-bound (measured per workgroup: 7.7 us of a 13.9 us life in FFN1, most of it 64-bit address
     // and counter arithmetic per 8-column chunk).
-    if (fast) {
+    if constexpr (PATH == 1) {
       constexpr int RSTEP = NT / CPR;
       const int row0 = tid / CPR;
       const int64_t mf = m0 + pass * WTM + row0;
@@ -392,14 +390,14 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS>
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS, int PATH>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
   gemm_mainloop<T, BM, BN, WGM, WGN, BK>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
-  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS>(a, smem, acc, m0, n0);
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH>(a, smem, acc, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -620,12 +618,22 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
   const bool rowops = a.rowadd || a.grpadd;
-  const int variant = (a.c_f32 ? 1 : 0) + (rowops ? 2 : 0);
+  // every tile interior and every optional operand 16-byte friendly: the launch takes the kernel that holds only the
+  // fast row loop (conditions of the former per-tile test, now decided once per launch)
+  const bool fast = !a.c_f32 && a.M % BM == 0 && a.N % BN == 0 && a.ldc % 8 == 0 && a.c_rows_per_group <= 0 &&
+                    (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
+                    (!a.resid || (a.ldr % 8 == 0 && (uintptr_t)a.resid % 16 == 0)) &&
+                    (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0)) &&
+                    (!rowops || (a.rowadd_period % BM == 0 && (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
+                                 (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
+  const int variant = (a.c_f32 ? 2 : (fast ? 0 : 1)) + (rowops ? 3 : 0);
   typedef void (*kern_t)(mst_gemm_args);
-  const kern_t fns[4] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true>};
+  const kern_t fns[6] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[4] = {false, false, false, false};
+    static bool opted[6] = {false, false, false, false, false, false};
     if (!opted[variant]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
@@ -720,7 +728,10 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // tiles x 4) runs a second resident round for four workgroups — 21 us against 13 us with 64x64 tiles.
     const int64_t last_round = big_tiles % 512;
     const bool stub_round = big_tiles > 512 && last_round > 0 && last_round < 128;
-    if (big_tiles >= 384 && a.N >= 128 && !stub_round) return launch_gemm<T, 128, 128, 2, 2>(a, s);
+    // (a launch whose rows are whole 64-row tiles but not whole 128-row tiles — the decoder's 64 x 257 — keeps the
+    // fast-epilogue kernel with 64x64 tiles)
+    const bool ragged128 = a.M % 128 != 0 && a.M % 64 == 0 && a.N % 128 == 0 && !a.c_f32 && a.c_rows_per_group <= 0;
+    if (big_tiles >= 384 && a.N >= 128 && !stub_round && !ragged128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     if (a.M <= 64 && a.K >= 512 && a.K % 256 == 0) return launch_gemm<T, 64, 64, 2, 2, 256>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
