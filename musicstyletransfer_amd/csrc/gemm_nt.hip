@@ -97,10 +97,12 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       constexpr int RSTEP = NT / CPR;
       const int row0 = tid / CPR;
       const int64_t mf = m0 + pass * WTM + row0;
-      T* cp = reinterpret_cast<T*>(a.C) + mf * a.ldc + nc;
+      // a C row remap whose groups are whole tiles moves the tile as a block: physical row = remap(m0) + (m - m0)
+      const int64_t pmf = remap_row(m0, a.c_rows_per_group, a.c_group_stride, a.c_group_offset) + pass * WTM + row0;
+      T* cp = reinterpret_cast<T*>(a.C) + pmf * a.ldc + nc;
       const T* rp = resid ? resid + mf * a.ldr + nc : nullptr;
       const T* gp = gate ? gate + mf * a.ldg + nc : nullptr;
-      uint32_t w = (uint32_t)((uint64_t)(mf * a.N + nc) >> 2);
+      uint32_t w = (uint32_t)((uint64_t)(pmf * a.N + nc) >> 2);  // counter = PHYSICAL output row
       const uint32_t wstep = (uint32_t)((uint64_t)(RSTEP * a.N) >> 2);
       const float* sp = sFp + row0 * LDS_F + ch * 8;
       constexpr int ITERS = WTM / RSTEP;
@@ -620,8 +622,10 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const bool rowops = a.rowadd || a.grpadd;
   // every tile interior and every optional operand 16-byte friendly: the launch takes the kernel that holds only the
   // fast row loop (conditions of the former per-tile test, now decided once per launch)
-  const bool fast = !a.c_f32 && a.M % BM == 0 && a.N % BN == 0 && a.ldc % 8 == 0 && a.c_rows_per_group <= 0 &&
-                    (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
+  const int64_t phys_rows = a.c_rows_per_group > 0 ? (a.M / a.c_rows_per_group + 1) * a.c_group_stride + a.c_group_offset : a.M;
+  const bool fast = !a.c_f32 && a.M % BM == 0 && a.N % BN == 0 && a.ldc % 8 == 0 &&
+                    (a.c_rows_per_group <= 0 || a.c_rows_per_group % BM == 0) &&
+                    (uint64_t)phys_rows * (uint64_t)a.N < (1ull << 32) &&
                     (!a.resid || (a.ldr % 8 == 0 && (uintptr_t)a.resid % 16 == 0)) &&
                     (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0)) &&
                     (!rowops || (a.rowadd_period % BM == 0 && (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
@@ -730,7 +734,7 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     const bool stub_round = big_tiles > 512 && last_round > 0 && last_round < 128;
     // (a launch whose rows are whole 64-row tiles but not whole 128-row tiles — the decoder's 64 x 257 — keeps the
     // fast-epilogue kernel with 64x64 tiles)
-    const bool ragged128 = a.M % 128 != 0 && a.M % 64 == 0 && a.N % 128 == 0 && !a.c_f32 && a.c_rows_per_group <= 0;
+    const bool ragged128 = a.M % 128 != 0 && a.M % 64 == 0 && a.N % 128 == 0 && !a.c_f32;
     if (big_tiles >= 384 && a.N >= 128 && !stub_round && !ragged128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     if (a.M <= 64 && a.K >= 512 && a.K % 256 == 0) return launch_gemm<T, 64, 64, 2, 2, 256>(a, s);
     return launch_gemm<T, 64, 64, 2, 2>(a, s);

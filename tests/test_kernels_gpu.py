@@ -109,6 +109,27 @@ def test_gemm_nt_row_remaps_and_f32_out(gpu):
     assert (got[:, 0, :] == 0).all()
 
 
+@pytest.mark.parametrize("T", [128, 64, 100])  # groups of whole 64-row tiles take the fast epilogue, T = 100 the general one
+def test_gemm_nt_c_remap_keeps_the_physical_row_dropout_counter(gpu, T):
+    """16-bit output with a C row remap, a residual and dropout: the mask of output row (b, 1 + t) is the one of physical
+    row b*(T+1) + 1 + t, whichever epilogue kernel the launch takes"""
+    o = ops()
+    Bsz, N, K = 3, 128, 64
+    p, seed, site = 0.25, 4242, 2
+    A, W = rnd((Bsz * T, K), gpu, seed=14), rnd((N, K), gpu, seed=15, scale=0.2)
+    resid = rnd((Bsz * T, N), gpu, seed=16)
+    Cbuf = torch.zeros(Bsz * (T + 1), N, dtype=BF, device=gpu)
+    o.gemm_nt(A, W, Cbuf, M=Bsz * T, c_remap=(T, T + 1, 1), resid=resid, dropout_p=p, dropout_seed=seed, dropout_site=site)
+    keep = torch.zeros(Bsz * (T + 1) * N, dtype=torch.uint8, device=gpu)
+    o.dropout_mask(keep.numel(), p, seed, site, keep)
+    torch.cuda.synchronize()
+    k3 = keep.view(Bsz, T + 1, N)[:, 1:, :].float()
+    ref = (A.float() @ W.float().t()).view(Bsz, T, N) * k3 / (1 - p) + resid.float().view(Bsz, T, N)
+    got = Cbuf.view(Bsz, T + 1, N)
+    close(got[:, 1:, :], ref, 1e-2, 2e-2, "remapped dropout")
+    assert (got[:, 0, :] == 0).all()
+
+
 def test_gemm_nt_dropout_matches_mask_kernel(gpu):
     o = ops()
     M, N, K = 300, 64, 64
