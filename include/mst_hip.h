@@ -369,12 +369,18 @@ int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_we
  *   1-thread kernel issued ahead of the update in the same stream, so a captured graph replays
  *   with the right bias correction.
  * Also refreshes the 16-bit shadow copy w16 (act dtype, same offsets).
+ * metrics (optional): the end-of-step bookkeeping of mst_loss_combine (total[b] = recon[b] + kl_weight * kl[b] and the
+ * running metric sums; trainer.py:107-120,172,181-186) done by the first workgroup of this launch instead of a launch of
+ * its own.
  * ------------------------------------------------------------------------ */
+typedef struct mst_step_metrics {
+  int64_t B; const float* recon; const float* kl; float kl_weight; float* total; float* metric;
+} mst_step_metrics;
 int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
                   void* w16, double lr, double beta1, double beta2, float eps, float wd,
                   float rescale, float clip, int32_t* step_state /* device int32[2]: {t, bits(lr_t)} */,
                   int advance_step /* 0: reuse the lr_t of the previous launch (second range of one step) */,
-                  mst_stream_t stream);
+                  const mst_step_metrics* metrics, mst_stream_t stream);
 
 /* 16-bit shadow + transposed shadow refresh for a list of matrices.
  * desc: int64 [n_mat, 4] on device = {src_offset, dst_offset, rows, cols}; dst is [cols, ld_t] with

@@ -53,6 +53,10 @@ class LnArgs(C.Structure):
     ]
 
 
+class StepMetrics(C.Structure):
+    _fields_ = [("B", c_i64), ("recon", vp), ("kl", vp), ("kl_weight", c_f32), ("total", vp), ("metric", vp)]
+
+
 class PartialSum(C.Structure):
     _fields_ = [
         ("src", vp), ("n_parts", c_i64), ("stride", c_i64), ("len", c_i64),
@@ -121,7 +125,7 @@ SIGNATURES = {
                                   vp, c_i64, c_f32, C.c_int, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
-                                vp, C.c_int, vp]),
+                                vp, C.c_int, C.POINTER(StepMetrics), vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
     "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),
     "mst_dropout_mask": (C.c_int, [c_i64, c_f32, c_u64, c_u32, vp, vp]),

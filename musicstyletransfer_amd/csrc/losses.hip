@@ -12,6 +12,7 @@
 // logit gradient in the same pass, per-sample sums reduced in-wave then with one atomic per wave.
 #include <math.h>
 #include "common.hpp"
+#include "loss_combine.hpp"
 
 namespace mst {
 
@@ -196,22 +197,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(int64_t B, const floa
                                                            const float* __restrict__ kl, float kl_weight,
                                                            float* __restrict__ total, float* __restrict__ metric) {
   __shared__ float red[2][4];
-  float skl = 0.f, stot = 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += 256) {
-    const float t = recon[b] + kl_weight * kl[b];
-    if (total) total[b] = t;
-    skl += kl[b];
-    stot += t;
-  }
-  skl = wave_sum(skl);
-  stot = wave_sum(stot);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = skl; red[1][threadIdx.x >> 6] = stot; }
-  __syncthreads();
-  if (threadIdx.x == 0 && metric) {
-    metric[0] += red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    metric[1] += red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    metric[2] += (float)B;
-  }
+  loss_combine_wg(B, recon, kl, kl_weight, total, metric, red);
 }
 
 }  // namespace mst

@@ -11,6 +11,7 @@
 // so a captured graph replays with the right bias correction.
 #include <math.h>
 #include "common.hpp"
+#include "loss_combine.hpp"
 
 namespace mst {
 
@@ -28,7 +29,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __rest
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         T* __restrict__ w16, const int32_t* __restrict__ state,
                                                         float beta1, float beta2, float eps, float wd, float rescale,
-                                                        float clip) {
+                                                        float clip, mst_step_metrics mt) {
+  __shared__ float red[2][4];
+  if (blockIdx.x == 0 && mt.recon) loss_combine_wg(mt.B, mt.recon, mt.kl, mt.kl_weight, mt.total, mt.metric, red);  // (uniform branch)
   const float lr_t = reinterpret_cast<const float*>(state)[1];
   const int64_t nvec = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
@@ -125,8 +128,13 @@ static unsigned grid_for(int64_t n, int per_thread) {
 
 extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr,
                              double beta1, double beta2, float eps, float wd, float rescale, float clip,
-                             int32_t* step_state, int advance_step, mst_stream_t stream) {
+                             int32_t* step_state, int advance_step, const mst_step_metrics* metrics, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
+  mst_step_metrics mt = {0, nullptr, nullptr, 0.f, nullptr, nullptr};
+  if (metrics) {
+    MST_CHECK_ARG(metrics->B > 0 && metrics->recon && metrics->kl, "mst_adam_flat: metrics need B, recon and kl");
+    mt = *metrics;
+  }
   MST_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                 "mst_adam_flat: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -137,7 +145,7 @@ extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, 
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,
-                       (float)beta1, (float)beta2, eps, wd, rescale, clip);
+                       (float)beta1, (float)beta2, eps, wd, rescale, clip, mt);
     MST_CHECK_LAUNCH("adam_flat_kernel");
     return MST_OK;
   });

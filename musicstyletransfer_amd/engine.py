@@ -528,7 +528,8 @@ class StepPlan:
         o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, M=B * T, K=Dd, bias=st.p("decoder.output_layer.bias"),
                   a_remap=(T, Sd, 1))
 
-    def losses(self, with_grad=True):
+    def losses(self, with_grad=True, combine=True):
+        """combine=False: the total loss / running metric sums are left to optimizer() (they ride on the Adam launch)"""
         cfg, B, T = self.cfg, self.B, self.T
         dl = self.dlogits if with_grad else None
         if cfg.kind == "token":
@@ -538,7 +539,8 @@ class StepPlan:
             o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
                           downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale,
                           pre_zeroed=True)
-        o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
+        if combine:
+            o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
 
     # ------------------------------------------------------------------------------ backward
     LN_PARTIALS_MIN = 32  # fewer workgroups than this: their atomics are cheaper than a row of partials each
@@ -786,9 +788,11 @@ class StepPlan:
     def optimizer(self):
         st = self.store
         clip = self.clip if self.clip is not None else -1.0
+        # end-of-step bookkeeping (total loss, running metric sums) on the first Adam launch: losses(combine=False)
+        mt = dict(recon=self.recon, kl=self.kl, kl_weight=self.kl_weight, total=self.total, metric=self.metric_acc)
         if self.gscale == self.gscale_enc:
             o.adam_flat(st.w, st.g, st.m, st.v, st.w16, st.step_state, lr=self.lr,
-                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, **self.opt)
+                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, metrics=mt, **self.opt)
         else:
             # encoder.* tensors come first in the flat buffers; everything from decoder.latent2hid on is decoder-side.
             # NOTE the latent_proj gradients are produced by latent_bwd at the encoder-side scale.
@@ -796,14 +800,15 @@ class StepPlan:
             rng = [(0, cut, self.gscale_enc, False), (cut, st.n, self.gscale, False)]
             for a, b, gs, adv in rng:
                 o.adam_flat(st.w[a:b], st.g[a:b], st.m[a:b], st.v[a:b], st.w16[a:b], st.step_state, lr=self.lr,
-                            rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv, **self.opt)
+                            rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv, metrics=mt if a == 0 else None,
+                            **self.opt)
         o.transpose_shadows(st.w, st.wt16, st.t_desc, st.t_prefix, len(st.t_specs), st.t_tiles)
 
     # ------------------------------------------------------------------------------ step
     def fwd_bwd_kernels(self, is_train=True):
         self._tick_adam = is_train  # the step counter / lr_t are advanced by forward()'s step_begin launch
         self.forward()
-        self.losses(with_grad=is_train)
+        self.losses(with_grad=is_train, combine=not is_train)
         if is_train:
             self.backward()
 
@@ -827,7 +832,7 @@ class StepPlan:
             def early():
                 self._tick_adam = True
                 self.forward()
-                self.losses(with_grad=True)
+                self.losses(with_grad=True, combine=False)
                 self.backward_early(flush=True)
             self.graph = o.Graph().capture(early)
             self.graph_late = o.Graph().capture(self.backward_late)

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import LnArgs, PartialSum, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, PartialSum, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -303,9 +303,15 @@ def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None):
 
 # --------------------------------------------------------------------------- optimizer / shadows
 def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0,
-              advance_step=True):
+              advance_step=True, metrics=None):
+    """metrics: dict(recon, kl, kl_weight, total, metric) -> loss_combine's bookkeeping runs in this launch"""
+    mt = None
+    if metrics is not None:
+        mt = StepMetrics()
+        mt.B, mt.recon, mt.kl = metrics["recon"].numel(), ptr(metrics["recon"]), ptr(metrics["kl"])
+        mt.kl_weight, mt.total, mt.metric = metrics["kl_weight"], ptr(metrics.get("total")), ptr(metrics.get("metric"))
     call("mst_adam_flat", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd,
-         rescale, clip, ptr(step_state), 1 if advance_step else 0, stream())
+         rescale, clip, ptr(step_state), 1 if advance_step else 0, C.byref(mt) if mt is not None else None, stream())
 
 
 def transpose_shadows(w, wt16, desc, tile_prefix, n_mat, total_tiles):

@@ -805,11 +805,20 @@ def test_adam_flat_mxnet_rule(gpu):
     w16 = torch.zeros(n, dtype=BF, device=gpu)
     state = torch.zeros(2, dtype=torch.int32, device=gpu)
     wr, mr, vr = w0.clone(), m.clone(), v.clone()
+    # the end-of-step bookkeeping that may ride on the launch: the same numbers as mst_loss_combine
+    B = 37
+    recon, kl = rnd((B,), gpu, dtype=torch.float32, seed=98).abs(), rnd((B,), gpu, dtype=torch.float32, seed=99).abs()
+    total, metric = torch.zeros(B, device=gpu), torch.zeros(3, device=gpu)
+    total_ref, metric_ref = torch.zeros(B, device=gpu), torch.zeros(3, device=gpu)
     for t in range(1, 4):
         g = rnd((n,), gpu, dtype=torch.float32, seed=100 + t, scale=50.0)
-        o.adam_flat(w, g, m, v, w16, state, lr=3e-4, rescale=1 / 32, clip=1.0)
+        o.adam_flat(w, g, m, v, w16, state, lr=3e-4, rescale=1 / 32, clip=1.0,
+                    metrics=dict(recon=recon, kl=kl, kl_weight=0.5, total=total, metric=metric) if t != 2 else None)
+        if t != 2:
+            o.loss_combine(recon, kl, 0.5, total_ref, metric_ref)
         wr, mr, vr = mxnet_adam_reference(wr, g, mr, vr, t, 3e-4, 0.9, 0.999, 1e-8, 0.0, 1 / 32, 1.0)
     torch.cuda.synchronize()
+    assert torch.equal(total, total_ref) and torch.equal(metric, metric_ref) and metric[2].item() == 2 * B
     assert state[0].item() == 3
     close(w, wr, 1e-6, 1e-7, "adam w")
     close(m, mr, 1e-5, 1e-7, "adam m")
