@@ -27,7 +27,8 @@ namespace mst {
 // present in the one kernel, against -10 us on the embedding GEMM that uses it.
 // PATH, likewise: 1 = every tile of the launch is interior and eligible for the fast row loop below (the host checks:
 // gemm_fast_eligible), 2 = the guarded general loop only. Two small kernels instead of one with both bodies.
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS, int PATH>
+// DROP, likewise: dropout / self_resid compiled in (half of the step's GEMM launches are gradient GEMMs without it).
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS, int PATH, bool DROP>
 __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0) {
   constexpr int NT = WGM * WGN * 64;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const bool edge = PATH != 1 && ((m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
                                   (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
                                   (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0))));
-  const bool has_drop = a.dropout_p > 0.f;
+  const bool has_drop = DROP && a.dropout_p > 0.f;
   const bool has_rowops = ROWOPS && (a.rowadd || a.grpadd);
   // row-indexed adds (positional table row m % period, class row grp_index[m / period]) ride on the fast path when a
   // tile cannot straddle a period: the class row is then one per tile and the positional rows advance with the tile rows
@@ -141,7 +142,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
         }
-        if (has_drop || a.self_resid) {
+        if (DROP && (has_drop || a.self_resid)) {
           uint32_t keep8 = 0xFFu;
           if (has_drop) keep8 = dropout_keep4k32(dkey, w, dthr) | (dropout_keep4k32(dkey, w + 1, dthr) << 4);
 #pragma unroll
@@ -203,7 +204,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
         }
-        if (has_drop || a.self_resid) {
+        if (DROP && (has_drop || a.self_resid)) {
           uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
           if (has_drop) {
             const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
@@ -392,14 +393,14 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS, int PATH>
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS, int PATH, bool DROP>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
   gemm_mainloop<T, BM, BN, WGM, WGN, BK>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
-  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH>(a, smem, acc, m0, n0);
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -630,14 +631,16 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
                     (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0)) &&
                     (!rowops || (a.rowadd_period % BM == 0 && (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
                                  (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
-  const int variant = (a.c_f32 ? 2 : (fast ? 0 : 1)) + (rowops ? 3 : 0);
+  const bool drop = a.dropout_p > 0.f || a.self_resid;
+  // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
+  const int variant = (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
   typedef void (*kern_t)(mst_gemm_args);
-  const kern_t fns[6] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2>};
+  const kern_t fns[8] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2, true>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, true>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2, true>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[6] = {false, false, false, false, false, false};
+    static bool opted[8] = {false, false, false, false, false, false, false, false};
     if (!opted[variant]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
