@@ -21,7 +21,8 @@ namespace mst {
 // dependent K tiles, each one exposed memory round trip).
 
 // Shared epilogue of the GEMM kernels (called after a workgroup barrier: `smem` is free to reuse).
-// ROWOPS: the row-indexed adds (rowadd / grpadd: the two embedding GEMMs of a step) are compiled in. They are a template
+// ROWOPS: the row-indexed adds (rowadd / grpadd: the two embedding GEMMs of a step) AND the A / C row remaps (their 64-bit
+// divisions) are compiled in. They are a template
 // switch, not a run-time one, because the launch-floor-bound GEMMs of the step (M = 64: four workgroups, every
 // instruction line a cold fetch) measurably pay for code they jump over: +0.4 ... +2.6 us per launch with the row-op code
 // present in the one kernel, against -10 us on the embedding GEMM that uses it.
@@ -99,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       const int row0 = tid / CPR;
       const int64_t mf = m0 + pass * WTM + row0;
       // a C row remap whose groups are whole tiles moves the tile as a block: physical row = remap(m0) + (m - m0)
-      const int64_t pmf = remap_row(m0, a.c_rows_per_group, a.c_group_stride, a.c_group_offset) + pass * WTM + row0;
+      const int64_t pmf = (ROWOPS ? remap_row(m0, a.c_rows_per_group, a.c_group_stride, a.c_group_offset) : m0) + pass * WTM + row0;
       T* cp = reinterpret_cast<T*>(a.C) + pmf * a.ldc + nc;
       const T* rp = resid ? resid + mf * a.ldr + nc : nullptr;
       const T* gp = gate ? gate + mf * a.ldg + nc : nullptr;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
       for (int row = tid / CPR; row < WTM; row += NT / CPR) {
         const int64_t m = m0 + pass * WTM + row;
         if (m >= a.M) break;
-        const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+        const int64_t pm = ROWOPS ? remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset) : m;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sFp + row * LDS_F + ch * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sFp + row * LDS_F + ch * 8 + 4);
         float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -271,7 +272,8 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 
 // The tile's K loop, shared by the kernels below: locates the workgroup's tile (m0, n0) and leaves the fp32
 // accumulators in `acc`; on return every wave has passed the loop's last barrier, so `smem` is free to reuse.
-template <typename T, int BM, int BN, int WGM, int WGN, int BK>
+// AREMAP: the A row remap is compiled in (a 64-bit division per staged chunk of the prologue).
+template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true>
 __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0) {
   constexpr int CHUNKS = BK / 8;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
     int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
     int64_t m = m0 + row;
     a_ok[i] = m < a.M && c < BM * CHUNKS;
-    int64_t pm = remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
+    int64_t pm = AREMAP ? remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : (a_ok[i] ? m : 0);
     a_ptr[i] = A + pm * a.lda + ch * 8;
     a_ch[i] = ch * 8;
     a_lds[i] = row * CHUNKS + (ch ^ (row & 7));
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
-  gemm_mainloop<T, BM, BN, WGM, WGN, BK>(a, smem, acc, m0, n0);
+  gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0);
 }
@@ -620,7 +622,8 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const size_t lds_loop = (size_t)2 * (BM + BN) * BK * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
-  const bool rowops = a.rowadd || a.grpadd;
+  // ("row ops" in the kernel choice: row-indexed adds or a row remap of A or C)
+  const bool rowops = a.rowadd || a.grpadd || a.a_rows_per_group > 0 || a.c_rows_per_group > 0;
   // every tile interior and every optional operand 16-byte friendly: the launch takes the kernel that holds only the
   // fast row loop (conditions of the former per-tile test, now decided once per launch)
   const int64_t phys_rows = a.c_rows_per_group > 0 ? (a.M / a.c_rows_per_group + 1) * a.c_group_stride + a.c_group_offset : a.M;
