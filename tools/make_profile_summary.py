@@ -28,6 +28,8 @@ def short(name):
     if m:
         base = re.match(r"_ZN3mst\d+([a-z_0-9]+?_kernel)", name)
         tmpl = re.findall(r"Li(\d+)E", name)
+        if "gemm_nt_kernel" in name:
+            tmpl = tmpl[:5]  # BM, BN, WGM, WGN, BK (the epilogue switches that follow do not change the traffic key)
         return (base.group(1) if base else m.group(1)) + ("<" + ",".join(tmpl) + ">" if tmpl else "")
     return re.sub(r"\(.*", "", name.replace("mst::", ""))[:70]
 
