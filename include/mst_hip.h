@@ -142,6 +142,13 @@ typedef struct mst_ln_args {
 int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream);
 int64_t mst_gemm_nt_ln_parts(int64_t M);
 
+/* The whole feed-forward block of a Transformer layer in one launch (transformer.py:38-40 with :152-158 or :194-200):
+ *     mst_gemm_nt(ff1)              a  = dropout(relu(x W1^T + b1))       — written (the backward pass needs it), never re-read
+ *     mst_gemm_nt_ln(ff2, ln) mode 1 h2 = epi(a W2^T + b2), y = LayerNorm(h2), mean, rstd
+ * with identical results (same MFMA order per output element, same epilogues). ff2->A must be ff1->C; the model width
+ * (ff1 K = ff2 N) is 128 or 256 and divides the hidden width; no remaps, gates or row-indexed adds. */
+int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order
  * (deterministic). The LayerNorm-backward launches leave per-workgroup partial sums of dgamma / dbeta (`partials`

@@ -12,6 +12,7 @@
 // ds_read_b128), double-buffered with one barrier per 64-deep K tile; the global loads of tile
 // t+1 are issued before the MFMAs of tile t and written to LDS after them.
 #include <math.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace mst {
@@ -594,6 +595,220 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
   gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(a, l, smem, acc, m0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The whole feed-forward block of a Transformer layer in ONE launch (mst_ffn_ln_fwd):
+//     a  = dropout(relu(x W1^T + b1))                 (transformer.py:38-40 / 152-153)
+//     h2 = epi(a W2^T + b2) with the layer's residual form, y = LayerNorm(h2)      (transformer.py:157-158 / 199-200)
+// = mst_gemm_nt(ff1) followed by mst_gemm_nt_ln(ff2, mode 1), bit for bit: the same MFMA sequence per output element (K
+// in the same order), the same epilogues. A workgroup owns 64 rows for both GEMMs. The hidden activation is produced
+// in chunks of BN (= the model width) columns: one chunk is a 64 x BN tile of the first GEMM (K = BN), finished in
+// registers (bias, ReLU, dropout, rounding), parked in LDS as 16-bit — from where it is the A operand of the second GEMM's
+// K-slice for that chunk, and is copied out to `a` for the backward pass with full-line stores. So the hidden tensor
+// (33 MB at configs[1]) is written once and never read back, the 64 x BN accumulators of the second GEMM stay in
+// registers across the F / BN chunks, and three launches (FFN1, FFN2, LayerNorm) become one. Weights stream through a
+// double-buffered LDS stage exactly as in gemm_mainloop (both GEMMs of a chunk are stages of ONE pipelined stream);
+// every workgroup reads both matrices once (1 MB at configs[1]: ~8 us at the ~127 GB/s a CU pulls from L2).
+template <typename T, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_fwd_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln) {
+  constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int B_CH = BN * CHUNKS / NT;       // 16-byte pieces of a weight stage per thread
+  constexpr int LDA = BN + 8;                  // row stride (elements) of the two activation tiles: conflict-free b128 reads
+  constexpr int KST = BN / BK;                 // K stages of one GEMM of a chunk (K = BN for both)
+  static_assert(BN * CHUNKS % NT == 0 && (BM * BN / 8) % NT == 0, "tile/threads mismatch");
+  typedef typename Act<T>::vec8 vec8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [weight stages 2 x BN x 64][hidden chunk 64 x LDA][x tile 64 x LDA]; the LayerNorm epilogue's fp32 staging tile reuses
+  // the first two regions (both dead by then)
+  u32x4* sB = reinterpret_cast<u32x4*>(smem);
+  T* sH = reinterpret_cast<T*>(smem + (size_t)2 * BN * BK * 2);
+  T* sX = sH + BM * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t F = g1.N;
+  const int n_chunks = (int)(F / BN);
+  const T* __restrict__ W1 = reinterpret_cast<const T*>(g1.B);
+  const T* __restrict__ W2 = reinterpret_cast<const T*>(g2.B);
+
+  // ---- the x tile (rows past M read as zero)
+  {
+    const T* X = reinterpret_cast<const T*>(g1.A);
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / NT; ++i) {
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m0 + row < g1.M) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
+      *reinterpret_cast<u32x4*>(sX + row * LDA + ch * 8) = v;
+    }
+  }
+  // ---- weight stream: stage s of chunk c is GEMM 1 (s < KST: W1 rows c*BN.., columns s*64..) or GEMM 2 (W2 rows 0..BN-1,
+  // columns c*BN + (s-KST)*64..). Per-thread element offsets are constants; the uniform base moves.
+  uint32_t off1[B_CH], off2[B_CH];
+  int b_lds[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
+    off1[i] = (uint32_t)row * (uint32_t)g1.ldb + (uint32_t)ch * 8u;
+    off2[i] = (uint32_t)row * (uint32_t)g2.ldb + (uint32_t)ch * 8u;
+    b_lds[i] = row * CHUNKS + (ch ^ (row & 7));
+  }
+  // The stream runs AHEAD stages in front of the MFMAs, in a register ring: with one 8-wave workgroup per CU (BN = 256:
+  // 133 KB of LDS) nothing else hides a weight load's ~1.5 us, and a single stage of lookahead (gemm_mainloop's scheme,
+  // which relies on 2-5 co-resident workgroups) made every stage as long as that latency: 52 us for the launch.
+  constexpr int SPC = 2 * KST;                 // stages per chunk (a multiple of the ring: slots are compile-time)
+  constexpr int RING = BN >= 256 ? 4 : 2, AHEAD = RING - 1;
+  static_assert(SPC % RING == 0, "ring slots must repeat per chunk");
+  u32x4 ring[RING][B_CH];
+  auto load_stage = [&](int c, int s, u32x4 (&rb)[B_CH]) {  // (c, s) uniform
+    if (s < KST) {
+      const T* base = W1 + (int64_t)c * BN * g1.ldb + s * BK;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off1[i]);
+    } else {
+      const T* base = W2 + (int64_t)c * BN + (s - KST) * BK;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off2[i]);
+    }
+  };
+  auto store_stage = [&](int buf, const u32x4 (&rb)[B_CH]) {
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
+  };
+  // one 64-deep K stage: acc += A[64, 64] (LDS tile `sA`, columns k0..) x stage `buf`
+  auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf) {
+    const u32x4* cB = sB + buf * BN * CHUNKS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      vec8 xf[TM], wf[TN];
+      const int kc = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        xf[i] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sA + (wm * WTM + i * 16 + frow) * LDA + k0 + kc * 8));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 16 + frow;
+        wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf[j], xf[i], acc[j][i]);
+    }
+  };
+
+  f32x4 acc1[TN][TM], acc2[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc2[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float p1 = g1.dropout_p;
+  const bool drop1 = p1 > 0.f;
+  const uint64_t seed1 = g1.dropout_seed ^ ((drop1 && g1.dropout_seed_ptr) ? g1.dropout_seed_ptr[0] : 0ull);
+  const uint32_t dkey1 = dropout_key(seed1, g1.dropout_site), dthr1 = dropout_thr(p1);
+  const float inv_keep1 = dropout_inv_keep(p1);
+  const bool relu1 = g1.act == MST_ACT_RELU;
+  T* Aout = reinterpret_cast<T*>(g1.C);
+
+  // prologue: stages 0 .. AHEAD-1 requested, stage 0 in LDS
+  {
+    auto pro = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j < AHEAD && (j < SPC || n_chunks > 1)) load_stage(j / SPC, j % SPC, ring[j % RING]);
+    };
+    pro(std::integral_constant<int, 0>()); pro(std::integral_constant<int, 1>()); pro(std::integral_constant<int, 2>());
+  }
+  store_stage(0, ring[0]);
+  __syncthreads();  // (also publishes the x tile)
+  for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc1[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;      // stage within the chunk: ring slot s % RING, LDS buffer s % 2
+      if constexpr (s < SPC) {
+        {  // request stage s + AHEAD of the stream (it may belong to the next chunk)
+          constexpr int t = s + AHEAD;
+          const int tc = t < SPC ? c : c + 1;
+          if (tc < n_chunks) load_stage(tc, t % SPC, ring[t % RING]);
+        }
+        if constexpr (s < KST) mma_stage(acc1, sX, s * BK, s & 1);
+        else mma_stage(acc2, sH, (s - KST) * BK, s & 1);
+        if constexpr (s == KST - 1) {
+          // ---- chunk epilogue of GEMM 1, in registers: bias, ReLU, dropout, rounding (the order of gemm_epilogue) -> sH.
+          // (The previous chunk's GEMM-2 stages, which read sH, ended with a barrier.)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = wn * WTN + j * 16 + fq * 4;   // column within the chunk
+            const int64_t col = (int64_t)c * BN + n;     // hidden unit
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (g1.bias) b4 = *reinterpret_cast<const f32x4*>(g1.bias + col);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int row = wm * WTM + i * 16 + frow;
+              uint32_t keep = 0xFu;
+              if (drop1) keep = dropout_keep4k(dkey1, (uint64_t)((m0 + row) * F + col) >> 2, dthr1);
+              uint16_t hb[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float t = (acc1[j][i][e] + b4[e]) * g1.alpha;
+                if (relu1) t = fmaxf(t, 0.f);
+                if (drop1) t = ((keep >> e) & 1u) ? t * inv_keep1 : 0.f;
+                hb[e] = f32_to_bits<T>(t);
+              }
+              *reinterpret_cast<u32x2*>(sH + row * LDA + n) =
+                  u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
+            }
+          }
+        }
+        // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
+        if (s + 1 < SPC || c + 1 < n_chunks) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+        __syncthreads();
+        if constexpr (s == KST - 1) {
+          // the finished chunk goes out to `a` (the backward pass needs it) as whole 16-byte pieces of rows, while the
+          // second GEMM's stages run
+          constexpr int CPR = BN / 8;
+#pragma unroll
+          for (int i = 0; i < BM * CPR / NT; ++i) {
+            const int cc = tid + i * NT, row = cc / CPR, ch = cc % CPR;
+            if (m0 + row < g1.M)
+              *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)c * BN + ch * 8) = *reinterpret_cast<const u32x4*>(sH + row * LDA + ch * 8);
+          }
+        }
+      }
+    };
+    static_assert(SPC <= 8, "the stage list below covers eight stages per chunk");
+    stage(std::integral_constant<int, 0>()); stage(std::integral_constant<int, 1>());
+    stage(std::integral_constant<int, 2>()); stage(std::integral_constant<int, 3>());
+    stage(std::integral_constant<int, 4>()); stage(std::integral_constant<int, 5>());
+    stage(std::integral_constant<int, 6>()); stage(std::integral_constant<int, 7>());
+  }
+  // ---- the second GEMM's epilogue + LayerNorm: exactly mst_gemm_nt_ln's (staging tile over the dead weight / hidden regions)
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(g2, ln, smem, acc2, m0);
+}
+
+template <typename T, int BN>
+static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, hipStream_t s) {
+  constexpr int BM = 64;
+  const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  const void* fn = reinterpret_cast<const void*>(&ffn_ln_fwd_kernel<T, BN, 2, 4>);
+  if (lds > 64 * 1024) {
+    static bool opted = false;
+    if (!opted) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("ffn_ln_fwd_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted = true;
+    }
+  }
+  hipLaunchKernelGGL((ffn_ln_fwd_kernel<T, BN, 2, 4>), dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln);
+  MST_CHECK_LAUNCH("ffn_ln_fwd_kernel");
+  return MST_OK;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_gemm_ln(const mst_gemm_args& a, const mst_ln_args& l, hipStream_t s) {
   const size_t lds_loop = (size_t)2 * (BM + BN) * 64 * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
@@ -673,6 +888,38 @@ static int check_gemm_common(const mst_gemm_args& a) {
 }
 
 extern "C" int64_t mst_gemm_nt_ln_parts(int64_t M) { return M > 0 ? cdiv(M, 64) : 0; }  // launch_gemm_ln's 64-row tiles
+
+extern "C" int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream) {
+  MST_CHECK_ARG(ff1 != nullptr && ff2 != nullptr && ln != nullptr, "mst_ffn_ln_fwd: null args");
+  const mst_gemm_args& a = *ff1;
+  const mst_gemm_args& b = *ff2;
+  const mst_ln_args& l = *ln;
+  int rc = check_gemm_common(a);
+  if (rc) return rc;
+  rc = check_gemm_common(b);
+  if (rc) return rc;
+  MST_CHECK_ARG(a.dtype == b.dtype && a.M == b.M, "mst_ffn_ln_fwd: the two GEMMs must share dtype and M");
+  MST_CHECK_ARG((b.N == 256 || b.N == 128) && a.K == b.N, "mst_ffn_ln_fwd: the model width (ff1 K = ff2 N) must be 128 or 256 (got %lld, %lld)",
+                (long long)a.K, (long long)b.N);
+  MST_CHECK_ARG(a.N == b.K && a.N % b.N == 0, "mst_ffn_ln_fwd: the hidden width (ff1 N = ff2 K) must be a multiple of the model width");
+  MST_CHECK_ARG(b.A == a.C && b.lda == a.ldc, "mst_ffn_ln_fwd: ff2's A operand must be ff1's output (it is consumed on chip)");
+  MST_CHECK_ARG(!a.c_f32 && !b.c_f32 && !a.gate && !b.gate && !a.rowadd && !b.rowadd && !a.grpadd && !b.grpadd && !a.resid && !a.self_resid &&
+                b.act == MST_ACT_NONE && a.a_rows_per_group <= 0 && a.c_rows_per_group <= 0 && b.a_rows_per_group <= 0 && b.c_rows_per_group <= 0,
+                "mst_ffn_ln_fwd: fp32 outputs, gates, row-indexed adds, row remaps, a residual on ff1 and an activation on ff2 are not supported");
+  MST_CHECK_ARG(a.lda % 8 == 0 && a.ldc % 8 == 0 && a.ldc >= a.N && b.ldc % 8 == 0 && b.ldc >= b.N, "mst_ffn_ln_fwd: leading dimensions must be multiples of 8");
+  MST_CHECK_ARG((uint64_t)a.N * (uint64_t)a.ldb < (1ull << 32) && (uint64_t)b.N * (uint64_t)b.ldb < (1ull << 32), "mst_ffn_ln_fwd: weight matrices too large");
+  MST_CHECK_ARG(!b.resid || (b.ldr % 8 == 0 && b.ldr >= b.N && (uintptr_t)b.resid % 16 == 0), "mst_ffn_ln_fwd: bad residual layout");
+  MST_CHECK_ARG(!a.bias || (uintptr_t)a.bias % 16 == 0, "mst_ffn_ln_fwd: ff1 bias must be 16-byte aligned");
+  MST_CHECK_ARG(a.dropout_p == 0.f || a.N % 4 == 0, "mst_ffn_ln_fwd: dropout needs widths that are multiples of 4");
+  MST_CHECK_ARG(l.mode == 1 && l.gamma && l.beta && l.mean && l.rstd && l.out && l.ld_out % 8 == 0 && l.ld_out >= b.N && (uintptr_t)l.out % 16 == 0,
+                "mst_ffn_ln_fwd: the LayerNorm arguments are those of mst_gemm_nt_ln's forward form");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, s);
+    return launch_ffn_ln<T, 128>(a, b, l, s);
+  });
+}
 
 extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr && ln != nullptr, "mst_gemm_nt_ln: null args");

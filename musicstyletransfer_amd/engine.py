@@ -475,12 +475,16 @@ class StepPlan:
         o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
                   resid=x_in, **self._drop(p, site0))
         o.layernorm_fwd(L.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), L.x1, L.mean1, L.rstd1, D=D)
-        o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU,
-                  **self._drop(p, site0 + 1))
+        ff1 = dict(K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **self._drop(p, site0 + 1))
         # encoder: LN2(x1 + dropout(ff)); decoder (transformer.py:199-200): LN3(ff + dropout(ff))
         ln = "ln2" if side == "encoder" else "ln3"
         ff2 = dict(K=4 * D, bias=st.p(f"{pre}.ff2.bias"), **self._drop(p, site0 + 2))
         ff2.update(dict(resid=L.x1) if side == "encoder" else dict(self_resid=True))
+        if o.ffn_fusion_pays(D, 4 * D):  # the whole feed-forward block + LayerNorm in one launch (same results, bit for bit in a / h2)
+            o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.{ln}.gamma"),
+                         st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, ff1=ff1, ff2=ff2)
+            return L.x2
+        o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, **ff1)
         o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, **ff2)
         o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
         return L.x2

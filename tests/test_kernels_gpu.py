@@ -239,6 +239,42 @@ def test_gemm_ln_backward_equals_gemm_then_layernorm_bwd(gpu, M, N, K, mode, rem
         assert (res[1][0].view(M, S, -1)[:, 1:] == 0).all()
 
 
+@pytest.mark.parametrize("M,D,F,p,self_resid", [(16384, 256, 1024, 0.2, False), (16448, 128, 512, 0.2, True), (200, 256, 512, 0.0, False),
+                                                  (77, 128, 128, 0.1, False)])
+def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
+    """mst_ffn_ln_fwd == gemm_nt(ff1) + gemm_nt(ff2) + layernorm_fwd: the hidden activation and the pre-norm tensor bit for
+    bit (same MFMA order, same epilogues), the LayerNorm output within an ulp (statistics summed in another order)"""
+    o = ops()
+    x = rnd((M, D), gpu, seed=400)
+    W1, W2 = rnd((F, D), gpu, seed=401, scale=0.06), rnd((D, F), gpu, seed=402, scale=0.03)
+    b1, b2 = rnd((F,), gpu, dtype=torch.float32, seed=403, scale=0.1), rnd((D,), gpu, dtype=torch.float32, seed=404, scale=0.1)
+    gam, bet = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=405), rnd((D,), gpu, dtype=torch.float32, seed=406, scale=0.1)
+    seedp = torch.tensor([55, 0, 0, 0], dtype=torch.int64, device=gpu)
+    d1 = dict(dropout_p=p, dropout_seed_ptr=seedp, dropout_site=4) if p > 0 else {}
+    d2 = dict(dropout_p=p, dropout_seed_ptr=seedp, dropout_site=5) if p > 0 else {}
+    ff1 = dict(K=D, bias=b1, act=o.ACT_RELU, **d1)
+    ff2 = dict(K=F, bias=b2, **d2)
+    ff2.update(dict(self_resid=True) if self_resid else dict(resid=x))
+
+    def bufs():
+        return (torch.zeros(M, F, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu),
+                torch.zeros(M, device=gpu), torch.zeros(M, device=gpu))
+
+    a0, h0, y0, m0, r0 = bufs()
+    o.gemm_nt(x, W1, a0, **ff1)
+    o.gemm_nt(a0, W2, h0, **ff2)
+    o.layernorm_fwd(h0, gam, bet, y0, m0, r0, D=D)
+    a1, h1, y1, m1, r1 = bufs()
+    o.ffn_ln_fwd(x, W1, a1, W2, h1, gam, bet, y1, m1, r1, ff1=ff1, ff2=ff2)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a0), "hidden activation"
+    assert torch.equal(h1, h0), "pre-norm tensor"
+    close(m1, m0, 1e-5, 1e-5, "mean")
+    close(r1, r0, 1e-5, 1e-5, "rstd")
+    assert (y1.float() - y0.float()).abs().max().item() <= 2 ** -6  # at most one bf16 ulp at |y| < 4
+    assert ((y1 != y0).float().mean().item()) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------ wgrad
 @pytest.mark.parametrize("M,N,K", [(512, 64, 64), (16384, 256, 256), (4097, 128, 1024), (100, 16, 32), (16448, 384, 128)])
 def test_gemm_wgrad(gpu, M, N, K):
