@@ -148,6 +148,12 @@ int64_t mst_gemm_nt_ln_parts(int64_t M);
  * with identical results (same MFMA order per output element, same epilogues). ff2->A must be ff1->C; the model width
  * (ff1 K = ff2 N) is 128 or 256 and divides the hidden width; no remaps, gates or row-indexed adds. */
 int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream);
+/* The block's backward pass, same kernel skeleton (autograd of the above):
+ *     mst_gemm_nt(ff2_dgrad)               d(pre) = ((dff W2) * alpha) gated by a > 0     — written (the weight-gradient launch reads it)
+ *     mst_gemm_nt_ln(ff1_dgrad, ln) mode 2 dx = LayerNorm-backward(d(pre) W1 + resid), masked copy, dgamma / dbeta (or partials:
+ *                                          mst_gemm_nt_ln_parts(M) rows)
+ * ff2_dgrad->gate is the forward's hidden activation; ff1_dgrad->A must be ff2_dgrad->C. */
+int mst_ffn_ln_bwd(const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad, const mst_ln_args* ln, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order

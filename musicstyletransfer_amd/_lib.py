@@ -94,6 +94,7 @@ SIGNATURES = {
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
+    "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln_parts": (c_i64, [c_i64]),
     "mst_partial_sums": (C.c_int, [C.POINTER(PartialSum), C.c_int, vp]),

@@ -426,7 +426,10 @@ __device__ __forceinline__ float row_sum(float v) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
-                                                 f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0) {
+                                                 f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0,
+                                                 const T* lds_resid = nullptr, int lds_resid_ld = 0) {
+  // lds_resid: the workgroup's BM residual rows already sit in LDS (row stride lds_resid_ld elements, outside the staging
+  // tile): they are read from there instead of from a.resid
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -472,7 +475,8 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
     rv[it] = u32x4{0u, 0u, 0u, 0u}; xv[it] = rv[it]; mean_r[it] = 0.f; rstd_r[it] = 0.f;
     if (m < a.M) {
       const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
-      if (resid) rv[it] = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
+      if (lds_resid) rv[it] = *reinterpret_cast<const u32x4*>(lds_resid + (row0 + it * RSTEP) * lds_resid_ld + nc);
+      else if (resid) rv[it] = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
       if (MODE == 2) {
         xv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(l.x) + pm * l.ld_x + nc);
         mean_r[it] = l.mean[pm];
@@ -504,7 +508,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
           t[e] = a.self_resid ? t[e] + u : u;
         }
       }
-      if (resid) {
+      if (resid || lds_resid) {
         Pack8 p8; p8.u = rv[it];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] += bits_to_f32<T>(p8.h[e]);
@@ -608,8 +612,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 // registers across the F / BN chunks, and three launches (FFN1, FFN2, LayerNorm) become one. Weights stream through a
 // double-buffered LDS stage exactly as in gemm_mainloop (both GEMMs of a chunk are stages of ONE pipelined stream);
 // every workgroup reads both matrices once (1 MB at configs[1]: ~8 us at the ~127 GB/s a CU pulls from L2).
-template <typename T, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_fwd_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln) {
+// MODE 2 is the block's backward pass with the same skeleton (mst_ffn_ln_bwd): the first GEMM is the FFN2 dgrad
+// (d(pre-activation) = (dff W2) * alpha, then the ReLU gate a > 0), the second the FFN1 dgrad with the LayerNorm backward in
+// its epilogue (mst_gemm_nt_ln mode 2). The gate is applied in a row-layout pass over the parked chunk (coalesced 16-byte
+// reads of `a`), which is also the pass that stores the chunk for the weight-gradient launch.
+template <typename T, int BN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln) {
   constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
@@ -727,6 +735,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_fwd_kernel(mst_gemm_arg
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i) acc1[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // backward: this chunk's gate rows (the forward's hidden activation), requested now, used after the first GEMM
+    constexpr int OUT_CH = BM * (BN / 8) / NT;
+    u32x4 gv[OUT_CH];
+    if constexpr (MODE == 2) {
+      const T* G = reinterpret_cast<const T*>(g1.gate);
+#pragma unroll
+      for (int i = 0; i < OUT_CH; ++i) {
+        const int cc = tid + i * NT, row = cc / (BN / 8), ch = cc % (BN / 8);
+        gv[i] = u32x4{0u, 0u, 0u, 0u};
+        if (m0 + row < g1.M) gv[i] = *reinterpret_cast<const u32x4*>(G + (m0 + row) * g1.ldg + (int64_t)c * BN + ch * 8);
+      }
+    }
     auto stage = [&](auto sc) {
       constexpr int s = decltype(sc)::value;      // stage within the chunk: ring slot s % RING, LDS buffer s % 2
       if constexpr (s < SPC) {
@@ -774,9 +794,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_fwd_kernel(mst_gemm_arg
 #pragma unroll
           for (int i = 0; i < BM * CPR / NT; ++i) {
             const int cc = tid + i * NT, row = cc / CPR, ch = cc % CPR;
-            if (m0 + row < g1.M)
-              *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)c * BN + ch * 8) = *reinterpret_cast<const u32x4*>(sH + row * LDA + ch * 8);
+            u32x4 v = *reinterpret_cast<const u32x4*>(sH + row * LDA + ch * 8);
+            if constexpr (MODE == 2) {  // ReLU backward: pass where the forward activation was positive (gemm_epilogue's gate)
+              Pack8 pv, pg;
+              pv.u = v; pg.u = gv[i];
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (!(bits_to_f32<T>(pg.h[e]) > 0.f)) pv.h[e] = 0;
+              v = pv.u;
+              *reinterpret_cast<u32x4*>(sH + row * LDA + ch * 8) = v;
+            }
+            if (m0 + row < g1.M) *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)c * BN + ch * 8) = v;
           }
+          if constexpr (MODE == 2) __syncthreads();  // the gated chunk is what the second GEMM reads
         }
       }
     };
@@ -787,7 +817,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_fwd_kernel(mst_gemm_arg
     stage(std::integral_constant<int, 6>()); stage(std::integral_constant<int, 7>());
   }
   // ---- the second GEMM's epilogue + LayerNorm: exactly mst_gemm_nt_ln's (staging tile over the dead weight / hidden regions)
-  gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(g2, ln, smem, acc2, m0);
+  // (a residual that IS the block's input — the encoder's x1 + dropout(ff) — is taken from the x tile in LDS)
+  const bool resid_is_x = g2.resid == g1.A && g2.ldr == g1.lda;
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA);
 }
 
 template <typename T, int BN>
@@ -795,17 +827,19 @@ static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const
   constexpr int BM = 64;
   const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  const void* fn = reinterpret_cast<const void*>(&ffn_ln_fwd_kernel<T, BN, 2, 4>);
+  const int mi = ln.mode == 2 ? 1 : 0;
+  typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args);
+  const kern_t fns[2] = {&ffn_ln_kernel<T, BN, 2, 4, 1>, &ffn_ln_kernel<T, BN, 2, 4, 2>};
   if (lds > 64 * 1024) {
-    static bool opted = false;
-    if (!opted) {
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { set_error("ffn_ln_fwd_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
-      opted = true;
+    static bool opted[2] = {false, false};
+    if (!opted[mi]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted[mi] = true;
     }
   }
-  hipLaunchKernelGGL((ffn_ln_fwd_kernel<T, BN, 2, 4>), dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln);
-  MST_CHECK_LAUNCH("ffn_ln_fwd_kernel");
+  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln);
+  MST_CHECK_LAUNCH("ffn_ln_kernel");
   return MST_OK;
 }
 
@@ -889,36 +923,56 @@ static int check_gemm_common(const mst_gemm_args& a) {
 
 extern "C" int64_t mst_gemm_nt_ln_parts(int64_t M) { return M > 0 ? cdiv(M, 64) : 0; }  // launch_gemm_ln's 64-row tiles
 
-extern "C" int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream) {
-  MST_CHECK_ARG(ff1 != nullptr && ff2 != nullptr && ln != nullptr, "mst_ffn_ln_fwd: null args");
-  const mst_gemm_args& a = *ff1;
-  const mst_gemm_args& b = *ff2;
+static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_gemm_args* second, const mst_ln_args* ln, int mode,
+                       mst_stream_t stream) {
+  MST_CHECK_ARG(first != nullptr && second != nullptr && ln != nullptr, "%s: null args", who);
+  const mst_gemm_args& a = *first;
+  const mst_gemm_args& b = *second;
   const mst_ln_args& l = *ln;
   int rc = check_gemm_common(a);
   if (rc) return rc;
   rc = check_gemm_common(b);
   if (rc) return rc;
-  MST_CHECK_ARG(a.dtype == b.dtype && a.M == b.M, "mst_ffn_ln_fwd: the two GEMMs must share dtype and M");
-  MST_CHECK_ARG((b.N == 256 || b.N == 128) && a.K == b.N, "mst_ffn_ln_fwd: the model width (ff1 K = ff2 N) must be 128 or 256 (got %lld, %lld)",
+  MST_CHECK_ARG(a.dtype == b.dtype && a.M == b.M, "%s: the two GEMMs must share dtype and M", who);
+  MST_CHECK_ARG((b.N == 256 || b.N == 128) && a.K == b.N, "%s: the model width (first K = second N) must be 128 or 256 (got %lld, %lld)", who,
                 (long long)a.K, (long long)b.N);
-  MST_CHECK_ARG(a.N == b.K && a.N % b.N == 0, "mst_ffn_ln_fwd: the hidden width (ff1 N = ff2 K) must be a multiple of the model width");
-  MST_CHECK_ARG(b.A == a.C && b.lda == a.ldc, "mst_ffn_ln_fwd: ff2's A operand must be ff1's output (it is consumed on chip)");
-  MST_CHECK_ARG(!a.c_f32 && !b.c_f32 && !a.gate && !b.gate && !a.rowadd && !b.rowadd && !a.grpadd && !b.grpadd && !a.resid && !a.self_resid &&
+  MST_CHECK_ARG(a.N == b.K && a.N % b.N == 0, "%s: the hidden width (first N = second K) must be a multiple of the model width", who);
+  MST_CHECK_ARG(b.A == a.C && b.lda == a.ldc, "%s: the second GEMM's A operand must be the first one's output (it is consumed on chip)", who);
+  MST_CHECK_ARG(!a.c_f32 && !b.c_f32 && !b.gate && !a.rowadd && !b.rowadd && !a.grpadd && !b.grpadd && !a.resid && !a.self_resid &&
                 b.act == MST_ACT_NONE && a.a_rows_per_group <= 0 && a.c_rows_per_group <= 0 && b.a_rows_per_group <= 0 && b.c_rows_per_group <= 0,
-                "mst_ffn_ln_fwd: fp32 outputs, gates, row-indexed adds, row remaps, a residual on ff1 and an activation on ff2 are not supported");
-  MST_CHECK_ARG(a.lda % 8 == 0 && a.ldc % 8 == 0 && a.ldc >= a.N && b.ldc % 8 == 0 && b.ldc >= b.N, "mst_ffn_ln_fwd: leading dimensions must be multiples of 8");
-  MST_CHECK_ARG((uint64_t)a.N * (uint64_t)a.ldb < (1ull << 32) && (uint64_t)b.N * (uint64_t)b.ldb < (1ull << 32), "mst_ffn_ln_fwd: weight matrices too large");
-  MST_CHECK_ARG(!b.resid || (b.ldr % 8 == 0 && b.ldr >= b.N && (uintptr_t)b.resid % 16 == 0), "mst_ffn_ln_fwd: bad residual layout");
-  MST_CHECK_ARG(!a.bias || (uintptr_t)a.bias % 16 == 0, "mst_ffn_ln_fwd: ff1 bias must be 16-byte aligned");
-  MST_CHECK_ARG(a.dropout_p == 0.f || a.N % 4 == 0, "mst_ffn_ln_fwd: dropout needs widths that are multiples of 4");
-  MST_CHECK_ARG(l.mode == 1 && l.gamma && l.beta && l.mean && l.rstd && l.out && l.ld_out % 8 == 0 && l.ld_out >= b.N && (uintptr_t)l.out % 16 == 0,
-                "mst_ffn_ln_fwd: the LayerNorm arguments are those of mst_gemm_nt_ln's forward form");
+                "%s: fp32 outputs, row-indexed adds, row remaps, a gate or activation on the second GEMM and a residual on the first are not supported", who);
+  MST_CHECK_ARG(a.lda % 8 == 0 && a.ldc % 8 == 0 && a.ldc >= a.N && b.ldc % 8 == 0 && b.ldc >= b.N, "%s: leading dimensions must be multiples of 8", who);
+  MST_CHECK_ARG((uint64_t)a.N * (uint64_t)a.ldb < (1ull << 32) && (uint64_t)b.N * (uint64_t)b.ldb < (1ull << 32), "%s: weight matrices too large", who);
+  MST_CHECK_ARG(!b.resid || (b.ldr % 8 == 0 && b.ldr >= b.N && (uintptr_t)b.resid % 16 == 0), "%s: bad residual layout", who);
+  MST_CHECK_ARG(!a.bias || (uintptr_t)a.bias % 16 == 0, "%s: the first GEMM's bias must be 16-byte aligned", who);
+  MST_CHECK_ARG(a.dropout_p == 0.f || a.N % 4 == 0, "%s: dropout needs widths that are multiples of 4", who);
+  MST_CHECK_ARG(l.mode == mode && l.gamma && l.mean && l.rstd, "%s: LayerNorm arguments of the wrong form", who);
+  if (mode == 1) {
+    MST_CHECK_ARG(!a.gate, "%s: a gate belongs to the backward form", who);
+    MST_CHECK_ARG(l.beta && l.out && l.ld_out % 8 == 0 && l.ld_out >= b.N && (uintptr_t)l.out % 16 == 0,
+                  "%s: the LayerNorm arguments are those of mst_gemm_nt_ln's forward form", who);
+  } else {
+    MST_CHECK_ARG(a.gate && a.ldg % 8 == 0 && a.ldg >= a.N && (uintptr_t)a.gate % 16 == 0, "%s: the first GEMM needs the forward activation as its gate", who);
+    MST_CHECK_ARG(a.act == MST_ACT_NONE && a.dropout_p == 0.f && !b.self_resid, "%s: activation / dropout / self_resid belong to the forward form", who);
+    MST_CHECK_ARG(l.x && l.ld_x % 8 == 0 && (uintptr_t)l.x % 16 == 0 && (l.partials || (l.dgamma && l.dbeta)) && (uintptr_t)l.partials % 16 == 0,
+                  "%s: backward needs x and dgamma + dbeta (or partials)", who);
+    MST_CHECK_ARG(l.mask_mode >= 0 && l.mask_mode <= 2 &&
+                  (l.mask_mode != 1 || (l.out && l.ld_out % 8 == 0 && l.ld_out >= b.N && (uintptr_t)l.out % 16 == 0)),
+                  "%s: mask_mode must be 0, 1 (with out) or 2", who);
+  }
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, s);
     return launch_ffn_ln<T, 128>(a, b, l, s);
   });
+}
+
+extern "C" int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream) {
+  return ffn_ln_impl("mst_ffn_ln_fwd", ff1, ff2, ln, 1, stream);
+}
+extern "C" int mst_ffn_ln_bwd(const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad, const mst_ln_args* ln, mst_stream_t stream) {
+  return ffn_ln_impl("mst_ffn_ln_bwd", ff2_dgrad, ff1_dgrad, ln, 2, stream);
 }
 
 extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {

@@ -617,17 +617,22 @@ class StepPlan:
             dff = t.dh
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
-        o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
         ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
-        if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
-            o.gemm_nt_ln_bwd(t.dpre, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1,
-                             st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), N=D, K=4 * D, resid=resid_ff,
-                             partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), **ln1)
+        if o.ffn_fusion_pays(D, 4 * D):  # both dgrads of the block + LayerNorm-1 backward in one launch (mst_ffn_ln_bwd)
+            o.ffn_ln_bwd(dff, st.t(f"{pre}.ff2.weight"), t.dpre, L.a, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"),
+                         L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), alpha=inv_keep, resid=resid_ff,
+                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), **ln1)
         else:
-            o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
-            o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
-                            st.grad(f"{pre}.ln1.beta"), D=D, partials=self._ln_partials(f"{pre}.ln1", o.layernorm_bwd_parts(M, D)),
-                            **ln1)
+            o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
+            if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
+                o.gemm_nt_ln_bwd(t.dpre, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1,
+                                 st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), N=D, K=4 * D, resid=resid_ff,
+                                 partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), **ln1)
+            else:
+                o.gemm_nt(t.dpre, st.t(f"{pre}.ff1.weight"), t.dx1, N=D, K=4 * D, resid=resid_ff)
+                o.layernorm_bwd(L.h1, st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, t.dx1, t.dh1, st.grad(f"{pre}.ln1.gamma"),
+                                st.grad(f"{pre}.ln1.beta"), D=D, partials=self._ln_partials(f"{pre}.ln1", o.layernorm_bwd_parts(M, D)),
+                                **ln1)
         dproj = t.dh1m if p > 0 else t.dh1
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)

@@ -125,6 +125,26 @@ def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5
     call("mst_ffn_ln_fwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
 
 
+def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgamma, dbeta, alpha=1.0, dx_masked=None, mask_mode=0,
+               partials=None, **kw):
+    """dpre_out = ((dff @ W2t^T) * alpha) gated by gate > 0; dx_out = LayerNorm-backward(dpre_out @ W1t^T + resid; x, mean, rstd,
+    gamma) in one launch (mst_ffn_ln_bwd). W2t / W1t: the transposed 16-bit weights ([F, D] and [D, F]); **kw: resid and the
+    dropout fields of the LayerNorm-backward mask, as for gemm_nt_ln_bwd"""
+    g1 = _gemm_args(dff, W2t, dpre_out, gate=gate, alpha=alpha)
+    g2 = _gemm_args(dpre_out, W1t, dx_out, **kw)
+    l = LnArgs()
+    l.mode, l.gamma = 2, ptr(gamma)
+    l.mean, l.rstd = ptr(mean), ptr(rstd)
+    l.x, l.ld_x = ptr(x), ld(x)
+    l.dgamma, l.dbeta = ptr(dgamma), ptr(dbeta)
+    l.out, l.ld_out = ptr(dx_masked), (ld(dx_masked) if dx_masked is not None else 0)
+    l.mask_mode = mask_mode
+    l.partials = ptr(partials)
+    if partials is not None:
+        assert partials.shape[0] >= gemm_nt_ln_parts(g1.M) and partials.shape[1] == 2 * g2.N and partials.is_contiguous()
+    call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+
+
 def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):
     """dX_out = LayerNorm-backward(epilogue(A @ B^T); x, mean, rstd, gamma) in one launch (mst_gemm_nt_ln, mode 2); x, mean,
     rstd are indexed by dX_out's physical row, dx_masked by the logical row; the dropout fields among **kw are those of

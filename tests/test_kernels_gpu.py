@@ -275,6 +275,48 @@ def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
     assert ((y1 != y0).float().mean().item()) < 1e-2
 
 
+@pytest.mark.parametrize("M,D,F,mode,with_resid", [(16384, 256, 1024, 1, True), (16448, 128, 512, 2, False), (200, 256, 512, 0, True),
+                                                     (77, 128, 128, 1, True)])
+def test_ffn_ln_bwd_equals_the_separate_launches(gpu, M, D, F, mode, with_resid):
+    """mst_ffn_ln_bwd == gemm_nt(gate) + gemm_nt(resid) + layernorm_bwd: the gated d(pre-activation) bit for bit, dx and the
+    parameter gradients to the tolerance of the LayerNorm-fused GEMM"""
+    o = ops()
+    dff = rnd((M, D), gpu, seed=500, scale=0.5)
+    gate = rnd((M, F), gpu, seed=501)
+    W2t, W1t = rnd((F, D), gpu, seed=502, scale=0.05), rnd((D, F), gpu, seed=503, scale=0.05)
+    resid = rnd((M, D), gpu, seed=504) if with_resid else None
+    x = rnd((M, D), gpu, seed=505)
+    gam = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=506)
+    mean = x.float().mean(1)
+    rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    seedp = torch.tensor([91, 0, 0, 0], dtype=torch.int64, device=gpu)
+    drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2) if mode else {}
+    rk = dict(resid=resid) if with_resid else {}
+    # separate launches
+    dpre0, dy0 = torch.zeros(M, F, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+    dx0, dxm0 = torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+    dg0, db0 = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+    o.gemm_nt(dff, W2t, dpre0, gate=gate, alpha=1.25)
+    o.gemm_nt(dpre0, W1t, dy0, **rk)
+    o.layernorm_bwd(x, gam, mean, rstd, dy0, dx0, dg0, db0, D=D, dx_masked=dxm0 if mode == 1 else None, mask_mode=mode, **drop)
+    # one launch, parameter gradients through the partial rows
+    dpre1 = torch.zeros_like(dpre0)
+    dx1, dxm1 = torch.zeros_like(dx0), torch.zeros_like(dxm0)
+    dg1, db1 = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+    parts = o.gemm_nt_ln_parts(M)
+    part = torch.full((parts, 2 * D), float("nan"), device=gpu)
+    o.ffn_ln_bwd(dff, W2t, dpre1, gate, W1t, dx1, x, gam, mean, rstd, dg1, db1, alpha=1.25, dx_masked=dxm1 if mode == 1 else None,
+                 mask_mode=mode, partials=part, **rk, **drop)
+    o.partial_sums([o.partial_sum_job(part, parts, dg1, length=D), o.partial_sum_job(part, parts, db1, col_off=D, length=D)])
+    torch.cuda.synchronize()
+    assert torch.equal(dpre1, dpre0), "gated d(pre-activation)"
+    scale = dx0.float().abs().max().item()
+    close(dx1, dx0, 1e-2, 1e-2 * scale, "dx")
+    close(dxm1, dxm0, 1e-2, 1e-2 * scale, "dx masked")
+    close(dg1, dg0, 1e-3, 1e-3 * dg0.abs().max().item(), "dgamma")
+    close(db1, db0, 1e-3, 1e-3 * db0.abs().max().item(), "dbeta")
+
+
 # ------------------------------------------------------------------------------------------ wgrad
 @pytest.mark.parametrize("M,N,K", [(512, 64, 64), (16384, 256, 256), (4097, 128, 1024), (100, 16, 32), (16448, 384, 128)])
 def test_gemm_wgrad(gpu, M, N, K):

@@ -46,4 +46,24 @@ for M, D, F, self_resid in [(16384, 256, 1024, False), (16448, 128, 512, True)]:
     def fused():
         o.ffn_ln_fwd(x, W1, a, W2, h, gam, bet, y, mean, rstd, ff1=ff1, ff2=ff2)
 
-    print(f"M {M} D {D} F {F}: three launches {timeit(three):.1f} us   fused {timeit(fused):.1f} us")
+    print(f"M {M} D {D} F {F}: forward, three launches {timeit(three):.1f} us   fused {timeit(fused):.1f} us")
+    # backward: FFN2 dgrad (gate) + FFN1 dgrad (+resid) + LayerNorm backward
+    dff, W2t, W1t = r(M, D, sc=0.5).to(BF), r(F, D, sc=0.05).to(BF), r(D, F, sc=0.05).to(BF)
+    dpre, dy, dx, dxm = torch.zeros(M, F, dtype=BF, device=dev), torch.zeros(M, D, dtype=BF, device=dev), torch.zeros(M, D, dtype=BF, device=dev), torch.zeros(M, D, dtype=BF, device=dev)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    part = torch.zeros(o.gemm_nt_ln_parts(M), 2 * D, device=dev)
+    part2 = torch.zeros(max(o.layernorm_bwd_parts(M, D), 1), 2 * D, device=dev)
+    mk = dict(mask_mode=1, dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2)
+
+    def bwd_sep():
+        o.gemm_nt(dff, W2t, dpre, gate=a, alpha=1.25)
+        if D == 128:
+            o.gemm_nt_ln_bwd(dpre, W1t, dx, h, gam, mean, rstd, dg, db, dx_masked=dxm, resid=x, partials=part, **mk)
+        else:
+            o.gemm_nt(dpre, W1t, dy, resid=x)
+            o.layernorm_bwd(h, gam, mean, rstd, dy, dx, dg, db, D=D, dx_masked=dxm, partials=part2, **mk)
+
+    def bwd_fused():
+        o.ffn_ln_bwd(dff, W2t, dpre, a, W1t, dx, h, gam, mean, rstd, dg, db, alpha=1.25, dx_masked=dxm, resid=x, partials=part, **mk)
+
+    print(f"M {M} D {D} F {F}: backward, separate launches {timeit(bwd_sep):.1f} us   fused {timeit(bwd_fused):.1f} us")
