@@ -154,6 +154,23 @@ int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst
  *                                          mst_gemm_nt_ln_parts(M) rows)
  * ff2_dgrad->gate is the forward's hidden activation; ff1_dgrad->A must be ff2_dgrad->C. */
 int mst_ffn_ln_bwd(const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad, const mst_ln_args* ln, mst_stream_t stream);
+/* The same with the layer's LEADING LayerNorm backward (the one whose output gradient the block receives: LayerNorm-2 of an
+ * encoder layer, transformer.py:158) computed in the kernel's prologue instead of by an mst_layernorm_bwd launch in front:
+ * dx = LayerNorm-backward(dy; x, mean, rstd, gamma) on the workgroup's 64 rows, dx and (mask_mode 1) its dropout-masked copy
+ * stored for the residual branch / the weight gradients, the masked copy (or dx) handed to the first GEMM on chip —
+ * ff2_dgrad->A must be that buffer. dgamma / dbeta as in mst_gemm_nt_ln (partials: mst_gemm_nt_ln_parts(M) rows). */
+typedef struct mst_ln_bwd_in {
+  const void* dy; int64_t ld_dy;
+  const void* x;  int64_t ld_x;
+  const float* gamma; const float* mean; const float* rstd;
+  void* dx; int64_t ld_dx;
+  void* dx_masked; int64_t ld_dxm;
+  float* dgamma; float* dbeta; float* partials;
+  int32_t mask_mode;     /* 0 or 1 */
+  float dropout_p; uint64_t dropout_seed; const uint64_t* dropout_seed_ptr; uint32_t dropout_site;
+} mst_ln_bwd_in;
+int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
+                        const mst_ln_args* ln, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order

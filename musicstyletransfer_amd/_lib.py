@@ -53,6 +53,19 @@ class LnArgs(C.Structure):
     ]
 
 
+class LnBwdIn(C.Structure):
+    _fields_ = [
+        ("dy", vp), ("ld_dy", c_i64),
+        ("x", vp), ("ld_x", c_i64),
+        ("gamma", vp), ("mean", vp), ("rstd", vp),
+        ("dx", vp), ("ld_dx", c_i64),
+        ("dx_masked", vp), ("ld_dxm", c_i64),
+        ("dgamma", vp), ("dbeta", vp), ("partials", vp),
+        ("mask_mode", c_i32),
+        ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_seed_ptr", vp), ("dropout_site", c_u32),
+    ]
+
+
 class StepMetrics(C.Structure):
     _fields_ = [("B", c_i64), ("recon", vp), ("kl", vp), ("kl_weight", c_f32), ("total", vp), ("metric", vp)]
 
@@ -95,6 +108,7 @@ SIGNATURES = {
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
+    "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln_parts": (c_i64, [c_i64]),
     "mst_partial_sums": (C.c_int, [C.POINTER(PartialSum), C.c_int, vp]),

@@ -616,8 +616,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 // (d(pre-activation) = (dff W2) * alpha, then the ReLU gate a > 0), the second the FFN1 dgrad with the LayerNorm backward in
 // its epilogue (mst_gemm_nt_ln mode 2). The gate is applied in a row-layout pass over the parked chunk (coalesced 16-byte
 // reads of `a`), which is also the pass that stores the chunk for the weight-gradient launch.
-template <typename T, int BN, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln) {
+// LEAD (backward only): the block's input tile is not loaded but COMPUTED — the layer's leading LayerNorm backward on the
+// workgroup's 64 rows (mst_ffn_ln_bwd_lead), one launch and one 8 + 8 MB round trip less.
+template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD>
+__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln, mst_ln_bwd_in lead) {
   constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
@@ -640,18 +642,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const T* __restrict__ W1 = reinterpret_cast<const T*>(g1.B);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(g2.B);
 
-  // ---- the x tile (rows past M read as zero)
-  {
-    const T* X = reinterpret_cast<const T*>(g1.A);
-    constexpr int CPR = BN / 8;
-#pragma unroll
-    for (int i = 0; i < BM * CPR / NT; ++i) {
-      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (m0 + row < g1.M) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
-      *reinterpret_cast<u32x4*>(sX + row * LDA + ch * 8) = v;
-    }
-  }
   // ---- weight stream: stage s of chunk c is GEMM 1 (s < KST: W1 rows c*BN.., columns s*64..) or GEMM 2 (W2 rows 0..BN-1,
   // columns c*BN + (s-KST)*64..). Per-thread element offsets are constants; the uniform base moves.
   uint32_t off1[B_CH], off2[B_CH];
@@ -685,6 +675,107 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
   };
+  // the first AHEAD stages are requested before the input tile is built: their latency runs under it
+  {
+    auto pro = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j < AHEAD && (j < SPC || n_chunks > 1)) load_stage(j / SPC, j % SPC, ring[j % RING]);
+    };
+    pro(std::integral_constant<int, 0>()); pro(std::integral_constant<int, 1>()); pro(std::integral_constant<int, 2>());
+  }
+  if constexpr (LEAD) {
+    // ---- the input tile = LayerNorm backward of the incoming gradient (the arithmetic of gemm_epilogue_ln's mode 2 on dy)
+    constexpr int CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
+    const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
+    const float inv_n = 1.f / (float)BN;
+    const bool has_drop = lead.dropout_p > 0.f && lead.mask_mode == 1;
+    const uint64_t dseed = lead.dropout_seed ^ ((has_drop && lead.dropout_seed_ptr) ? lead.dropout_seed_ptr[0] : 0ull);
+    const uint32_t dkey = dropout_key(dseed, lead.dropout_site), dthr = dropout_thr(lead.dropout_p);
+    const float inv_keep = dropout_inv_keep(lead.dropout_p);
+    float gam8[8], dg8[8], db8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gam8[e] = lead.gamma[nc + e]; dg8[e] = 0.f; db8[e] = 0.f; }
+    u32x4 dyv[ITERS], xv[ITERS];
+    float mean_r[ITERS], rstd_r[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int64_t m = m0 + row0 + it * RSTEP;
+      dyv[it] = u32x4{0u, 0u, 0u, 0u}; xv[it] = dyv[it]; mean_r[it] = 0.f; rstd_r[it] = 0.f;
+      if (m < g1.M) {
+        dyv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(lead.dy) + m * lead.ld_dy + nc);
+        xv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(lead.x) + m * lead.ld_x + nc);
+        mean_r[it] = lead.mean[m];
+        rstd_r[it] = lead.rstd[m];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = row0 + it * RSTEP;
+      const int64_t m = m0 + row;
+      Pack8 db, xb;
+      db.u = dyv[it]; xb.u = xv[it];
+      float xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = bits_to_f32<T>(db.h[e]);
+        xh[e] = (bits_to_f32<T>(xb.h[e]) - mean_r[it]) * rstd_r[it];
+        g[e] = d * gam8[e];
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+        dg8[e] += d * xh[e];
+        db8[e] += d;
+      }
+      s1 = row_sum<CPR>(s1) * inv_n;
+      s2 = row_sum<CPR>(s2) * inv_n;
+      uint32_t keep8 = 0xFFu;
+      if (has_drop) {
+        const uint64_t w = (uint64_t)(m * BN + nc) >> 2;
+        keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
+      }
+      Pack8 ob, mb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float o = rstd_r[it] * (g[e] - s1 - xh[e] * s2);
+        const float k = has_drop ? (((keep8 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
+        ob.h[e] = f32_to_bits<T>(o);
+        mb.h[e] = f32_to_bits<T>(o * k);
+      }
+      if (m < g1.M) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(lead.dx) + m * lead.ld_dx + nc) = ob.u;
+        if (lead.mask_mode == 1) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(lead.dx_masked) + m * lead.ld_dxm + nc) = mb.u;
+      }
+      *reinterpret_cast<u32x4*>(sX + row * LDA + nc) = (m < g1.M) ? (lead.mask_mode == 1 ? mb.u : ob.u) : u32x4{0u, 0u, 0u, 0u};
+    }
+    // dgamma / dbeta: the RSTEP row groups summed through LDS (the weight-stage region is not in use yet)
+    float* red = reinterpret_cast<float*>(smem);  // [2][RSTEP][BN]
+    static_assert((size_t)2 * RSTEP * BN * 4 <= (size_t)2 * BN * BK * 2, "reduction scratch must fit the weight stages");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[row0 * BN + nc + e] = dg8[e];
+      red[(RSTEP + row0) * BN + nc + e] = db8[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int which = c / BN, col = c % BN;
+      float sm = 0.f;
+      for (int r = 0; r < RSTEP; ++r) sm += red[(which * RSTEP + r) * BN + col];
+      if (lead.partials) lead.partials[(int64_t)blockIdx.x * 2 * BN + c] = sm;
+      else atomicAdd((which ? lead.dbeta : lead.dgamma) + col, sm);
+    }
+    __syncthreads();  // the scratch becomes the first weight stage
+  } else
+  // ---- the x tile (rows past M read as zero)
+  {
+    const T* X = reinterpret_cast<const T*>(g1.A);
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / NT; ++i) {
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m0 + row < g1.M) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
+      *reinterpret_cast<u32x4*>(sX + row * LDA + ch * 8) = v;
+    }
+  }
   // one 64-deep K stage: acc += A[64, 64] (LDS tile `sA`, columns k0..) x stage `buf`
   auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf) {
     const u32x4* cB = sB + buf * BN * CHUNKS;
@@ -720,14 +811,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const bool relu1 = g1.act == MST_ACT_RELU;
   T* Aout = reinterpret_cast<T*>(g1.C);
 
-  // prologue: stages 0 .. AHEAD-1 requested, stage 0 in LDS
-  {
-    auto pro = [&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (j < AHEAD && (j < SPC || n_chunks > 1)) load_stage(j / SPC, j % SPC, ring[j % RING]);
-    };
-    pro(std::integral_constant<int, 0>()); pro(std::integral_constant<int, 1>()); pro(std::integral_constant<int, 2>());
-  }
   store_stage(0, ring[0]);
   __syncthreads();  // (also publishes the x tile)
   for (int c = 0; c < n_chunks; ++c) {
@@ -823,22 +906,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 }
 
 template <typename T, int BN>
-static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, hipStream_t s) {
+static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, const mst_ln_bwd_in* lead, hipStream_t s) {
   constexpr int BM = 64;
   const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  const int mi = ln.mode == 2 ? 1 : 0;
-  typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args);
-  const kern_t fns[2] = {&ffn_ln_kernel<T, BN, 2, 4, 1>, &ffn_ln_kernel<T, BN, 2, 4, 2>};
+  const int mi = lead ? 2 : (ln.mode == 2 ? 1 : 0);
+  typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args, mst_ln_bwd_in);
+  const kern_t fns[3] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true>};
   if (lds > 64 * 1024) {
-    static bool opted[2] = {false, false};
+    static bool opted[3] = {false, false, false};
     if (!opted[mi]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
       opted[mi] = true;
     }
   }
-  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln);
+  mst_ln_bwd_in none = {};
+  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln, lead ? *lead : none);
   MST_CHECK_LAUNCH("ffn_ln_kernel");
   return MST_OK;
 }
@@ -924,7 +1008,7 @@ static int check_gemm_common(const mst_gemm_args& a) {
 extern "C" int64_t mst_gemm_nt_ln_parts(int64_t M) { return M > 0 ? cdiv(M, 64) : 0; }  // launch_gemm_ln's 64-row tiles
 
 static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_gemm_args* second, const mst_ln_args* ln, int mode,
-                       mst_stream_t stream) {
+                       mst_stream_t stream, const mst_ln_bwd_in* lead = nullptr) {
   MST_CHECK_ARG(first != nullptr && second != nullptr && ln != nullptr, "%s: null args", who);
   const mst_gemm_args& a = *first;
   const mst_gemm_args& b = *second;
@@ -960,12 +1044,31 @@ static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_ge
                   (l.mask_mode != 1 || (l.out && l.ld_out % 8 == 0 && l.ld_out >= b.N && (uintptr_t)l.out % 16 == 0)),
                   "%s: mask_mode must be 0, 1 (with out) or 2", who);
   }
+  if (lead) {
+    const mst_ln_bwd_in& q = *lead;
+    MST_CHECK_ARG(mode == 2, "%s: a leading LayerNorm belongs to the backward form", who);
+    MST_CHECK_ARG(q.dy && q.x && q.gamma && q.mean && q.rstd && q.dx && (q.partials || (q.dgamma && q.dbeta)), "%s: leading LayerNorm: null pointer", who);
+    MST_CHECK_ARG(q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dx % 8 == 0 && q.ld_dy >= b.N && q.ld_x >= b.N && q.ld_dx >= b.N &&
+                  ((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dx | (uintptr_t)q.partials) % 16 == 0, "%s: leading LayerNorm: bad layout", who);
+    MST_CHECK_ARG(q.mask_mode == 0 || (q.mask_mode == 1 && q.dx_masked && q.ld_dxm % 8 == 0 && q.ld_dxm >= b.N && (uintptr_t)q.dx_masked % 16 == 0),
+                  "%s: leading LayerNorm: mask_mode must be 0 or 1 (with dx_masked)", who);
+    MST_CHECK_ARG(q.dropout_p >= 0.f && q.dropout_p < 1.f, "%s: leading LayerNorm: dropout_p must be in [0,1)", who);
+    const void* tile = q.mask_mode == 1 ? q.dx_masked : q.dx;
+    const int64_t tile_ld = q.mask_mode == 1 ? q.ld_dxm : q.ld_dx;
+    MST_CHECK_ARG(a.A == tile && a.lda == tile_ld, "%s: the first GEMM's A operand must be the leading LayerNorm's (masked) output", who);
+  }
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, s);
-    return launch_ffn_ln<T, 128>(a, b, l, s);
+    if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, lead, s);
+    return launch_ffn_ln<T, 128>(a, b, l, lead, s);
   });
+}
+
+extern "C" int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
+                                   const mst_ln_args* ln, mst_stream_t stream) {
+  MST_CHECK_ARG(lead != nullptr, "mst_ffn_ln_bwd_lead: null args");
+  return ffn_ln_impl("mst_ffn_ln_bwd_lead", ff2_dgrad, ff1_dgrad, ln, 2, stream, lead);
 }
 
 extern "C" int mst_ffn_ln_fwd(const mst_gemm_args* ff1, const mst_gemm_args* ff2, const mst_ln_args* ln, mst_stream_t stream) {

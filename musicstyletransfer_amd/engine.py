@@ -597,6 +597,16 @@ class StepPlan:
         dk = dict(dropout_p=p, dropout_seed_ptr=self.rng_state) if p > 0 else {}
         fuse = o.ln_bwd_fusion_pays(D)
         M = L.h1.shape[0]
+        ffn_fused = o.ffn_fusion_pays(D, 4 * D)
+        lead = None
+        if side == "encoder" and not dy_done and ffn_fused:
+            # LayerNorm-2 backward rides in the prologue of the fused feed-forward backward (mst_ffn_ln_bwd_lead)
+            lead = dict(dy=dy, x=L.h2, gamma=st.p(f"{pre}.ln2.gamma"), mean=L.mean2, rstd=L.rstd2, dx=t.dh,
+                        dgamma=st.grad(f"{pre}.ln2.gamma"), dbeta=st.grad(f"{pre}.ln2.beta"),
+                        partials=self._ln_partials(f"{pre}.ln2", o.gemm_nt_ln_parts(M)))
+            if p > 0:
+                lead.update(dx_masked=t.dhm, dropout_site=site0 + 2, **dk)
+            dy_done = True
         if side == "encoder":
             if not dy_done:
                 part = self._ln_partials(f"{pre}.ln2", o.layernorm_bwd_parts(M, D))
@@ -618,10 +628,10 @@ class StepPlan:
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
         ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
-        if o.ffn_fusion_pays(D, 4 * D):  # both dgrads of the block + LayerNorm-1 backward in one launch (mst_ffn_ln_bwd)
+        if ffn_fused:  # both dgrads of the block + LayerNorm-1 backward in one launch (mst_ffn_ln_bwd)
             o.ffn_ln_bwd(dff, st.t(f"{pre}.ff2.weight"), t.dpre, L.a, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"),
                          L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), alpha=inv_keep, resid=resid_ff,
-                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), **ln1)
+                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), lead=lead, **ln1)
         else:
             o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
             if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)

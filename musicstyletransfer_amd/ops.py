@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import LnArgs, PartialSum, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, LnBwdIn, PartialSum, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -126,10 +126,12 @@ def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5
 
 
 def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgamma, dbeta, alpha=1.0, dx_masked=None, mask_mode=0,
-               partials=None, **kw):
+               partials=None, lead=None, **kw):
     """dpre_out = ((dff @ W2t^T) * alpha) gated by gate > 0; dx_out = LayerNorm-backward(dpre_out @ W1t^T + resid; x, mean, rstd,
     gamma) in one launch (mst_ffn_ln_bwd). W2t / W1t: the transposed 16-bit weights ([F, D] and [D, F]); **kw: resid and the
-    dropout fields of the LayerNorm-backward mask, as for gemm_nt_ln_bwd"""
+    dropout fields of the LayerNorm-backward mask, as for gemm_nt_ln_bwd.
+    lead: dict(dy, x, gamma, mean, rstd, dx, [dx_masked, dropout_*], [dgamma, dbeta | partials]) -> the layer's leading
+    LayerNorm backward runs in the prologue (mst_ffn_ln_bwd_lead); dff must then be lead's dx_masked (or dx)"""
     g1 = _gemm_args(dff, W2t, dpre_out, gate=gate, alpha=alpha)
     g2 = _gemm_args(dpre_out, W1t, dx_out, **kw)
     l = LnArgs()
@@ -142,7 +144,23 @@ def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgam
     l.partials = ptr(partials)
     if partials is not None:
         assert partials.shape[0] >= gemm_nt_ln_parts(g1.M) and partials.shape[1] == 2 * g2.N and partials.is_contiguous()
-    call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+    if lead is None:
+        call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+        return
+    q = LnBwdIn()
+    q.dy, q.ld_dy = ptr(lead["dy"]), ld(lead["dy"])
+    q.x, q.ld_x = ptr(lead["x"]), ld(lead["x"])
+    q.gamma, q.mean, q.rstd = ptr(lead["gamma"]), ptr(lead["mean"]), ptr(lead["rstd"])
+    q.dx, q.ld_dx = ptr(lead["dx"]), ld(lead["dx"])
+    dxm = lead.get("dx_masked")
+    q.dx_masked, q.ld_dxm = ptr(dxm), (ld(dxm) if dxm is not None else 0)
+    q.dgamma, q.dbeta, q.partials = ptr(lead.get("dgamma")), ptr(lead.get("dbeta")), ptr(lead.get("partials"))
+    q.mask_mode = 1 if dxm is not None else 0
+    q.dropout_p, q.dropout_seed = lead.get("dropout_p", 0.0), lead.get("dropout_seed", 0)
+    q.dropout_seed_ptr, q.dropout_site = ptr(lead.get("dropout_seed_ptr")), lead.get("dropout_site", 0)
+    if lead.get("partials") is not None:
+        assert lead["partials"].shape[0] >= gemm_nt_ln_parts(g1.M) and lead["partials"].shape[1] == 2 * g2.N
+    call("mst_ffn_ln_bwd_lead", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), stream())
 
 
 def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):

@@ -315,6 +315,38 @@ def test_ffn_ln_bwd_equals_the_separate_launches(gpu, M, D, F, mode, with_resid)
     close(dxm1, dxm0, 1e-2, 1e-2 * scale, "dx masked")
     close(dg1, dg0, 1e-3, 1e-3 * dg0.abs().max().item(), "dgamma")
     close(db1, db0, 1e-3, 1e-3 * db0.abs().max().item(), "dbeta")
+    # ---- with the leading LayerNorm backward in the prologue: dff is itself the (masked) LayerNorm backward of a gradient
+    dyin, xin = rnd((M, D), gpu, seed=507), rnd((M, D), gpu, seed=508, scale=1.5)
+    gin = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=509)
+    mean_in, rstd_in = xin.float().mean(1), 1.0 / torch.sqrt(xin.float().var(1, unbiased=False) + 1e-5)
+    lead_drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=7) if mode == 1 else {}
+    res = []
+    for lead_fused in (False, True):
+        dh, dhm = torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+        dgi, dbi = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+        dpre = torch.zeros(M, F, dtype=BF, device=gpu)
+        dx = torch.zeros(M, D, dtype=BF, device=gpu)
+        dg, db = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+        masked = dhm if mode == 1 else None
+        a_op = dhm if mode == 1 else dh
+        rk2 = dict(resid=dh) if with_resid else {}
+        if lead_fused:
+            pin = torch.full((parts, 2 * D), float("nan"), device=gpu)
+            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, alpha=1.25, **rk2,
+                         lead=dict(dy=dyin, x=xin, gamma=gin, mean=mean_in, rstd=rstd_in, dx=dh, dx_masked=masked, partials=pin, **lead_drop))
+            o.partial_sums([o.partial_sum_job(pin, parts, dgi, length=D), o.partial_sum_job(pin, parts, dbi, col_off=D, length=D)])
+        else:
+            o.layernorm_bwd(xin, gin, mean_in, rstd_in, dyin, dh, dgi, dbi, D=D, dx_masked=masked, mask_mode=1 if mode == 1 else 0, **lead_drop)
+            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, alpha=1.25, **rk2)
+        torch.cuda.synchronize()
+        res.append((dh.clone(), dhm.clone(), dgi.clone(), dbi.clone(), dpre.clone(), dx.clone()))
+    sc = res[0][0].float().abs().max().item()
+    close(res[1][0], res[0][0], 1e-2, 1e-2 * sc, "leading dx")
+    close(res[1][1], res[0][1], 1e-2, 1e-2 * sc, "leading dx masked")
+    close(res[1][2], res[0][2], 1e-3, 1e-3 * res[0][2].abs().max().item(), "leading dgamma")
+    close(res[1][3], res[0][3], 1e-3, 1e-3 * res[0][3].abs().max().item(), "leading dbeta")
+    close(res[1][4], res[0][4], 2e-2, 2e-2 * res[0][4].float().abs().max().item(), "d(pre) after the fused leading LayerNorm")
+    close(res[1][5], res[0][5], 2e-2, 2e-2 * res[0][5].float().abs().max().item(), "dx after the fused leading LayerNorm")
 
 
 # ------------------------------------------------------------------------------------------ wgrad
