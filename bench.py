@@ -97,11 +97,17 @@ def dominant_kernel_roofline(plan, o, iters=50):
     L = plan.enc[0]
     pre = "encoder.layer0"
     cands = {
-        "gemm_nt_kernel[enc ff1 fwd: M=16384 N=1024 K=256]": (
-            lambda: o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU),
-            2.0 * M * 4 * De * De, 6 * cfg.e_layers,  # same-sized GEMMs per step: ff1/ff2 fwd + 2 dgrads each, per layer
-            2.0 * (M * De + 4 * De * De + M * 4 * De) + 4.0 * 4 * De,  # x1 + W + a (16-bit) + fp32 bias
-            "gemm_nt_kernel<128,128,2,2,64>@%d" % (((M + 127) // 128) * ((4 * De + 127) // 128) * 256)),
+        # the feed-forward block + LayerNorm of a full-size layer in its one-launch form (what the step runs): forward here;
+        # the backward form and the decoder's quarter-size pair are the same kernel (4 launches, ~20 % of the step)
+        "ffn_ln_kernel[enc FFN + LayerNorm fwd: M=16384, 256 -> 1024 -> 256]": (
+            lambda: o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.ln2.gamma"),
+                                 st.p(f"{pre}.ln2.beta"), L.x2, L.mean2, L.rstd2,
+                                 ff1=dict(K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **plan._drop(cfg.e_dropout, 1)),
+                                 ff2=dict(K=4 * De, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1, **plan._drop(cfg.e_dropout, 2))),
+            2.0 * 2.0 * M * 4 * De * De, 2 * max(cfg.e_layers - 1, 1) + 1,  # fwd + bwd per full layer, + the decoder's pair ~ one more
+            # x1 in; W1, W2; a, h2, x2 out (16-bit) + biases / gamma / beta; mean, rstd
+            2.0 * (M * De + 8 * De * De + M * 4 * De + 2 * M * De) + 4.0 * (4 * De + 3 * De + 2 * M),
+            "ffn_ln_kernel<256,2,4,1>@%d" % (((M + 63) // 64) * 512)),
         "wgrad_kernel[enc layer: 4 problems, M=16384]": (
             lambda: o.gemm_wgrad_batch([
                 o.wgrad_problem(plan.be.dh, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=De, K=4 * De),
