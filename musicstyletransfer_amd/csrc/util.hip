@@ -57,8 +57,18 @@ __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_st
                                                          double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
                                                          const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                                                          int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d,
-                                                         u32x4* zero_a, int64_t n16_a, u32x4* zero_b, int64_t n16_b) {
-  const int64_t gid = (int64_t)blockIdx.x * SB_THREADS + threadIdx.x, gsz = (int64_t)gridDim.x * SB_THREADS;
+                                                         u32x4* zero_a, int64_t n16_a, u32x4* zero_b, int64_t n16_b, int n_state) {
+  // workgroups [0, n_state) do the bookkeeping (and take part in the arrival count); the rest of the grid only helps
+  // clearing the two buffers — the 7.5 MB gradient bucket is most of this launch's bytes and has no business waiting on
+  // 64 workgroups' worth of store bandwidth
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  {
+    const int64_t zid = (int64_t)blockIdx.x * SB_THREADS + threadIdx.x, zsz = (int64_t)gridDim.x * SB_THREADS;
+    for (int64_t i = zid; i < n16_a; i += zsz) zero_a[i] = z4;
+    for (int64_t i = zid; i < n16_b; i += zsz) zero_b[i] = z4;
+  }
+  if ((int)blockIdx.x >= n_state) return;
+  const int64_t gid = (int64_t)blockIdx.x * SB_THREADS + threadIdx.x, gsz = (int64_t)n_state * SB_THREADS;
   uint64_t step = 0, s = 0;
   if (rng_state) {
     step = rng_state[1] + 1;
@@ -87,15 +97,12 @@ __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_st
     for (int64_t i = gid; i < B * Se; i += gsz) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
   if (mask_d)
     for (int64_t i = gid; i < B * Sd; i += gsz) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
-  const u32x4 z4 = {0u, 0u, 0u, 0u};
-  for (int64_t i = gid; i < n16_a; i += gsz) zero_a[i] = z4;
-  for (int64_t i = gid; i < n16_b; i += gsz) zero_b[i] = z4;
   if (rng_state) {
     __syncthreads();  // every thread of this workgroup has read the old counter
     if (threadIdx.x == 0) {
       __threadfence();
       const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(rng_state + 3), 1ull);
-      if (arrived == (unsigned long long)gridDim.x - 1) {
+      if (arrived == (unsigned long long)n_state - 1) {
         rng_state[3] = 0;
         rng_state[1] = step;
         rng_state[0] = s;
@@ -130,11 +137,15 @@ extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double l
   if (n16_b > work) work = n16_b;
   // few, fat workgroups: every workgroup ends with one atomic on the SAME arrival counter, and same-address atomics
   // are serialised at ~40 ns each (512 workgroups measured 20 us for this launch)
-  int64_t grid = cdiv(work > 0 ? work : 1, SB_THREADS * 4);
-  if (grid > 64) grid = 64;
+  int64_t n_state = cdiv(work > 0 ? work : 1, SB_THREADS * 4);
+  if (n_state > 64) n_state = 64;
+  // (+ workgroups that only clear: 16 KiB of the zero lists each, one per CU at most)
+  int64_t grid = cdiv(n16_a + n16_b, SB_THREADS);
+  if (grid > 256) grid = 256;
+  if (grid < n_state) grid = n_state;
   hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(SB_THREADS), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
                      eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
-                     n16_b);
+                     n16_b, (int)n_state);
   MST_CHECK_LAUNCH("step_begin_kernel");
   return MST_OK;
 }
