@@ -107,8 +107,11 @@ __global__ __launch_bounds__(BCE_THREADS) void sigmoid_bce_kernel(int64_t rows_p
   float acc = 0.f;
 #pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * BCE_THREADS + tid; i < nvec; i += (int64_t)gridDim.x * BCE_THREADS) {
-    const int64_t r = b * rows_per_sample + i / vec_per_row;
-    const int c0 = (int)(i % vec_per_row) * 4;
+    // (32-bit quotient / remainder: nvec < 2^31 is checked on the host; the 64-bit forms were ~200 instructions per thread
+    // in a kernel whose threads handle one vector each)
+    const uint32_t iq = (uint32_t)i / (uint32_t)vec_per_row;
+    const int64_t r = b * rows_per_sample + iq;
+    const int c0 = (int)((uint32_t)i - iq * (uint32_t)vec_per_row) * 4;
     float x[4];
     {
       u32x2 raw = *reinterpret_cast<const u32x2*>(logits + r * ld + c0);
@@ -237,6 +240,7 @@ extern "C" int mst_sigmoid_bce(int dtype, int64_t B, int64_t T, int64_t P, const
   MST_CHECK_ARG(!dlogits || (ldd % 4 == 0 && ldd >= P), "mst_sigmoid_bce: bad ldd");
   MST_CHECK_ARG(!downweight || npos, "mst_sigmoid_bce: down-weighting needs the npos scratch");
   MST_CHECK_ARG(B <= 65535, "mst_sigmoid_bce: B too large for grid.y");
+  MST_CHECK_ARG(T * ((P + 3) / 4) < (1ll << 31), "mst_sigmoid_bce: T * P / 4 must stay below 2^31");
   hipStream_t s = (hipStream_t)stream;
   if (!pre_zeroed) {
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * B, s);
