@@ -266,7 +266,7 @@ __device__ __forceinline__ void batch_outer(int64_t blk, int tid, int64_t B, int
   const int64_t per = (B + 3) / 4, b0 = part * per, b1 = b0 + per < B ? b0 + per : B;
   float acc = 0.f, accb = 0.f;
   if (idx < (int64_t)J * I) {
-    const int j = (int)(idx / I), i = (int)(idx % I);
+    const int j = (int)((uint32_t)idx / (uint32_t)I), i = (int)((uint32_t)idx - (uint32_t)j * (uint32_t)I);  // (J * I < 2^31: host check)
     float a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = 0.f;
@@ -315,7 +315,10 @@ __global__ __launch_bounds__(256) void latent_param_grads_kernel(int64_t B, int 
     batch_outer<float>(blk - n_wl, threadIdx.x, B, Dd, Z, tvec, z, Z, dWh, dbh, red);
   } else {
     const int64_t idx = (int64_t)(blk - n_wl - n_wh) * 256 + threadIdx.x;
-    if (idx < B * Dd) atomicAdd(dcls + (int64_t)classes[idx / Dd] * ld_cls + idx % Dd, tvec[idx]);
+    if (idx < B * Dd) {
+      const uint32_t bq = (uint32_t)idx / (uint32_t)Dd, dr = (uint32_t)idx - bq * (uint32_t)Dd;
+      atomicAdd(dcls + (int64_t)classes[bq] * ld_cls + dr, tvec[idx]);
+    }
   }
 }
 
@@ -358,6 +361,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   float* tvec = scratch;            // [B, Dd]
   float* dlat = scratch + B * Dd;   // [B, 2Z]
   MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd: latent size above %d", LAT_THREADS);
+  MST_CHECK_ARG(2 * Z * De < (1ll << 31) && Dd * Z < (1ll << 31) && B * Dd < (1ll << 31), "mst_latent_bwd: sizes above 2^31 elements");
   const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
   const int n_wl = (int)cdiv(2 * Z * De, 64), n_wh = (int)cdiv(Dd * Z, 64), n_cls = (int)cdiv(B * Dd, 256);
   return dispatch_act(dtype, [&](auto tag) -> int {

@@ -93,10 +93,18 @@ __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_st
       if (2 * i + 1 < n_eps) eps_out[2 * i + 1] = r * sn;
     }
   }
+  // (32-bit quotients: B * S < 2^31 is checked on the host; each thread handles about one element of each mask, and the
+  // 64-bit division it used to start with was several hundred instructions)
   if (mask_e)
-    for (int64_t i = gid; i < B * Se; i += gsz) mask_e[i] = ((i % Se) < (int64_t)lens[i / Se] + add_e) ? 1 : 0;
+    for (int64_t i = gid; i < B * Se; i += gsz) {
+      const uint32_t q = (uint32_t)i / (uint32_t)Se, r = (uint32_t)i - q * (uint32_t)Se;
+      mask_e[i] = ((int64_t)r < (int64_t)lens[q] + add_e) ? 1 : 0;
+    }
   if (mask_d)
-    for (int64_t i = gid; i < B * Sd; i += gsz) mask_d[i] = ((i % Sd) < (int64_t)lens[i / Sd] + add_d) ? 1 : 0;
+    for (int64_t i = gid; i < B * Sd; i += gsz) {
+      const uint32_t q = (uint32_t)i / (uint32_t)Sd, r = (uint32_t)i - q * (uint32_t)Sd;
+      mask_d[i] = ((int64_t)r < (int64_t)lens[q] + add_d) ? 1 : 0;
+    }
   if (rng_state) {
     __syncthreads();  // every thread of this workgroup has read the old counter
     if (threadIdx.x == 0) {
@@ -129,6 +137,7 @@ extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double l
                 "mst_step_begin: zero buffers must be 16-byte aligned with sizes that are multiples of 16");
   MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
   MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
+  MST_CHECK_ARG((!mask_e || (Se > 0 && B * Se < (1ll << 31))) && (!mask_d || (Sd > 0 && B * Sd < (1ll << 31))), "mst_step_begin: B * S must stay below 2^31");
   int64_t work = n_eps / 2;
   if (mask_e && B * Se > work) work = B * Se;
   if (mask_d && B * Sd > work) work = B * Sd;
