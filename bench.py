@@ -1,27 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — VarAutoEncoder training-step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,4}] [--data {resident,host}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one full training step (forward, BCE + KL, backward, gradient all-reduce when N > 1,
-MXNet-rule Adam) over one batch of synthetic piano-rolls already resident in HBM: BASELINE.json
-configs[1] per GPU (T=256, pitch=128, latent=64, batch=64, bf16; widths from scripts/train-vae.sh:
-encoder 256 x 2 layers x 8 heads, decoder 128 x 1 layer x 8 heads, dropout 0.2), weak scaling
-(configs[3] is the same per-GPU batch on 8 GPUs). Rank 0 prints ONE JSON line.
+A "step" is one full training step (forward, BCE + KL, backward, gradient all-reduce when N > 1, MXNet-rule Adam) over
+one batch of synthetic piano-rolls. --config names the BASELINE.json configuration (per GPU; weak scaling):
+    1  configs[1]  single-track, T 256, 128 pitches, latent 64, batch 64, bf16        (default; on 8 GPUs = configs[3])
+    2  configs[2]  multi-instrument, 16 x 128 pitches, latent 256, batch 64, bf16
+    4  configs[4]  long sequence T 1024, 128 pitches, fp16, batch 32 per GPU (256 over 8 GPUs)
+widths from scripts/train-vae.sh (encoder 256 x 2 layers x 8 heads, decoder 128 x 1 layer x 8 heads, dropout 0.2).
+--data resident (default): the batches are in HBM before the timed region (`value` is defined on this);
+--data host: every step's batch travels pinned host -> HBM through PinnedBatchPipeline inside the timed region.
+Rank 0 prints ONE JSON line. `value` follows the contract (K steps between barrier + synchronize, max over ranks);
+`ms_per_step_median` is the median of the same K steps timed one by one with HIP events on the step's stream.
 
 The line also carries
-  roofline     : the dominant kernel of the step, re-launched on the step's own operands and timed with
-                 HIP events on its stream; algorithmic FLOPs (or bytes) / average launch duration against
-                 the gfx950 peak (profiles/ holds the rocprofv3 summary of the same command)
-  cpu_baseline : the CPU oracle (oracle/vae_oracle.py, a restatement of the reference — the MXNet
-                 reference itself cannot run here) timed on this node's host cores on a bounded sample of
-                 the same workload. A reported baseline, not the optimisation target.
+  roofline     : the step's heavy kernel families, each re-launched on the step's own operands and timed with HIP
+                 events on its stream (`families`), and the one with the largest share of the step as the headline:
+                 algorithmic bytes (or FLOPs) per launch / average launch duration against the gfx950 peak
+                 (profiles/ holds the rocprofv3 summary of the same command)
+  cpu_baseline : the CPU oracle (oracle/vae_oracle.py, a restatement of the reference — the MXNet reference itself
+                 cannot run here) timed on this node's host cores on a bounded sample of the same workload, same
+                 dropout. A reported baseline, not the optimisation target.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -32,12 +37,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG2 = dict(kind="pianoroll", in_dim=128, out_dim=128, num_classes=2, latent_dim=64, e_model=256, e_layers=2, e_heads=8,
-            d_model=128, d_layers=1, d_heads=8)
-B_LOCAL, T_LEN = 64, 256
+WIDTHS = dict(num_classes=2, e_model=256, e_layers=2, e_heads=8, d_model=128, d_layers=1, d_heads=8)  # scripts/train-vae.sh:22-28
+CONFIGS = {
+    1: dict(name="BASELINE configs[1]: single-track piano-roll VAE train step", P=128, Z=64, B=64, T=256, dtype="bf16"),
+    2: dict(name="BASELINE configs[2]: multi-instrument piano-roll (16 tracks x 128 pitches) VAE train step", P=2048, Z=256, B=64,
+            T=256, dtype="bf16"),
+    4: dict(name="BASELINE configs[4]: long-sequence piano-roll VAE train step (per-GPU share of batch 256 on 8 GPUs)", P=128, Z=64,
+            B=32, T=1024, dtype="fp16"),
+}
 DROPOUT = 0.2  # scripts/train-vae.sh:23,29
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+
+
+def model_dims(c):
+    return dict(kind="pianoroll", in_dim=c["P"], out_dim=c["P"], latent_dim=c["Z"], **WIDTHS)
 
 
 def fwd_flops(cfg, B, T):
@@ -47,6 +61,17 @@ def fwd_flops(cfg, B, T):
     layer = lambda S, D: 24 * S * D * D + 4 * S * S * D
     per = (Le * layer(T, De) + 2 * T * P * De + 4 * De * Z + 2 * Z * Dd + Ld * layer(T + 1, Dd) + 2 * T * Dd * V)
     return B * per
+
+
+def executed_fwd_flops(cfg, B, T):
+    """what the forward pass actually executes: the top encoder layer is read at position 0 only (model.py:97), so after
+    its dense K/Q/V projection and the key-row statistics (which run over every query) its attention output, W_proj, FFN
+    and LayerNorms are computed for ONE row per sample (engine._top_encoder_layer_fwd)"""
+    De = cfg["e_model"]
+    full = fwd_flops(cfg, B, T)
+    layer = 24 * T * De * De + 4 * T * T * De
+    top = 6 * T * De * De + 2 * T * T * De + 2 * T * De + 18 * De * De  # QKV, K Q^T, P^T V for query 0, W_proj + FFN on one row
+    return full - B * (layer - top)
 
 
 def synthetic_batches(n, B, T, P, seed):
@@ -62,8 +87,9 @@ def synthetic_batches(n, B, T, P, seed):
     return out
 
 
-def cpu_baseline(steps=3):
-    """time the CPU oracle on a bounded sample: `steps` training steps of the same B=64, T=256 batch"""
+def cpu_baseline(c, dropout, budget_s=20.0):
+    """time the CPU oracle on a bounded sample: training steps of one batch of this configuration's shape, same dropout
+    (explicit keep masks, drawn once), until ~budget_s of CPU work"""
     from oracle import vae_oracle as O
     # the GPU box gives one GPU's share of the host: 16 cores (asking torch for every core the kernel
     # reports oversubscribes that share and runs ~50x slower)
@@ -73,99 +99,148 @@ def cpu_baseline(steps=3):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    cfg = O.OracleConfig(CFG2["kind"], CFG2["in_dim"], CFG2["out_dim"], CFG2["num_classes"], CFG2["latent_dim"],
-                         CFG2["e_model"], CFG2["e_layers"], CFG2["e_heads"], CFG2["d_model"], CFG2["d_layers"], CFG2["d_heads"])
+    md = model_dims(c)
+    cfg = O.OracleConfig(md["kind"], md["in_dim"], md["out_dim"], md["num_classes"], md["latent_dim"], md["e_model"], md["e_layers"],
+                         md["e_heads"], md["d_model"], md["d_layers"], md["d_heads"])
+    B, T = c["B"], c["T"]
+    if c["T"] > 256:
+        B = 4  # T = 1024: the oracle materialises [B, H, S, S] attention tensors for autograd; a 4-sample slice of the batch
     rng = np.random.default_rng(1234)
     tr = O.OracleTrainer(cfg, O.init_params(cfg, rng), lr=3e-4, clip_gradient=1.0)
-    batch = O.synthetic_pianoroll_batch(rng, B_LOCAL, T_LEN, CFG2["in_dim"])
-    eps = torch.from_numpy(rng.standard_normal((B_LOCAL, CFG2["latent_dim"])).astype(np.float32))
-    tr.step(batch, eps)  # warm-up (thread pool, allocator)
+    batch = O.synthetic_pianoroll_batch(rng, B, T, md["in_dim"])
+    eps = torch.from_numpy(rng.standard_normal((B, md["latent_dim"])).astype(np.float32))
+    masks = None
+    if dropout > 0:
+        masks = {}
+        keep = lambda *shape: torch.from_numpy((rng.random(shape) >= dropout).astype(np.float32) / (1.0 - dropout))
+        for side, n_l, D, S in (("encoder", md["e_layers"], md["e_model"], T), ("decoder", md["d_layers"], md["d_model"], T + 1)):
+            for i in range(n_l):
+                p = f"{side}.layer{i}"
+                masks[f"{p}.att"], masks[f"{p}.ffh"], masks[f"{p}.ffo"] = keep(B, S, D), keep(B, S, 4 * D), keep(B, S, D)
+    tr.step(batch, eps, masks)  # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(batch, eps)
+    steps = 0
+    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 50):
+        tr.step(batch, eps, masks)
+        steps += 1
     dt = (time.perf_counter() - t0) / steps
-    return {"value": B_LOCAL * T_LEN / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training steps of one B={B_LOCAL}, T={T_LEN}, P={CFG2['in_dim']} batch, fp32 torch-CPU restatement "
-                      f"(dropout 0), {dt * 1e3:.0f} ms/step"}
+    return {"value": B * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps of one B={B}, T={T}, P={md['in_dim']} batch, fp32 torch-CPU restatement of the reference "
+                      f"(not MXNet), dropout {dropout}, {dt * 1e3:.0f} ms/step"}
 
 
-def dominant_kernel_roofline(plan, o, iters=50):
-    """Re-launch the step's heaviest kernels on the step's own buffers, time each with HIP events on the
-    launch stream and report the one with the largest share of the step."""
-    st, cfg = plan.store, plan.cfg
-    De, M = cfg.e_model, plan.Me
-    L = plan.enc[0]
-    pre = "encoder.layer0"
-    cands = {
-        # the feed-forward block + LayerNorm of a full-size layer in its one-launch form (what the step runs): forward here;
-        # the backward form and the decoder's quarter-size pair are the same kernel (4 launches, ~20 % of the step)
-        "ffn_ln_kernel[enc FFN + LayerNorm fwd: M=16384, 256 -> 1024 -> 256]": (
-            lambda: o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.ln2.gamma"),
-                                 st.p(f"{pre}.ln2.beta"), L.x2, L.mean2, L.rstd2,
-                                 ff1=dict(K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **plan._drop(cfg.e_dropout, 1)),
-                                 ff2=dict(K=4 * De, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1, **plan._drop(cfg.e_dropout, 2))),
-            2.0 * 2.0 * M * 4 * De * De, 2 * max(cfg.e_layers - 1, 1) + 1,  # fwd + bwd per full layer, + the decoder's pair ~ one more
-            # x1 in; W1, W2; a, h2, x2 out (16-bit) + biases / gamma / beta; mean, rstd
-            2.0 * (M * De + 8 * De * De + M * 4 * De + 2 * M * De) + 4.0 * (4 * De + 3 * De + 2 * M),
-            "ffn_ln_kernel<256,2,4,1>@%d" % (((M + 63) // 64) * 512)),
-        "wgrad_kernel[enc layer: 4 problems, M=16384]": (
-            lambda: o.gemm_wgrad_batch([
-                o.wgrad_problem(plan.be.dh, L.a, st.grad(f"{pre}.ff2.weight"), st.grad(f"{pre}.ff2.bias"), N=De, K=4 * De),
-                o.wgrad_problem(plan.be.dpre, L.x1, st.grad(f"{pre}.ff1.weight"), st.grad(f"{pre}.ff1.bias"), N=4 * De, K=De),
-                o.wgrad_problem(plan.be.dh1, L.att, st.grad(f"{pre}.att.W_proj.weight"), st.grad(f"{pre}.att.W_proj.bias"), N=De, K=De),
-                o.wgrad_problem(plan.be.dqkv, plan.x0_e, st.fused(st.g, pre, "weight"), st.fused(st.g, pre, "bias"), N=3 * De, K=De)]),
-            2.0 * M * 12 * De * De, cfg.e_layers,
-            2.0 * M * (De + 4 * De + 4 * De + De + De + De + 3 * De + De) + 4.0 * 12 * De * De,  # 8 operand reads + fp32 dW
-            "wgrad_kernel<128,128,2,2>@122880"),
-        "attn_bwd(kv+q)[enc: B*H=512, S=256, dh=32]": (
-            lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, plan.be.datt, plan.be.dqkv, plan.be.delta, plan.B, plan.T,
-                               cfg.e_heads, De // cfg.e_heads, 0, De, 2 * De),
-            2.0 * 4 * plan.B * plan.T * plan.T * De, cfg.e_layers,  # algorithmic: 2x the forward's 4*S^2*D per sample
-            2.0 * M * (3 * De + De + 3 * De), "attn_bwd_res_kernel<32>@262144"),  # qkv + dO in, dqkv out
-    }
-    best = None
-    for name, (fn, flops, per_step, nbytes, pmc_key) in cands.items():
+def time_launch(o, fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = o.Event(), o.Event()
+    e0.record()
+    for _ in range(iters):
         fn()
-        torch.cuda.synchronize()
-        e0, e1 = o.Event(), o.Event()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        e1.sync()
-        ms = e0.elapsed_ms(e1) / iters
-        rec = dict(kernel=name, ms=ms, flops=flops, share_ms=ms * per_step, bytes=nbytes, pmc_key=pmc_key)
-        if best is None or rec["share_ms"] > best["share_ms"]:
-            best = rec
-    # Which roof binds? Algorithmic intensity (flops / compulsory bytes) against the ridge PEAK_MFMA / PEAK_HBM.
-    tflops = best["flops"] / (best["ms"] * 1e-3) / 1e12
-    gbs = best["bytes"] / (best["ms"] * 1e-3) / 1e9
+    e1.record()
+    e1.sync()
+    return e0.elapsed_ms(e1) / iters
+
+
+def kernel_families(plan, o, iters=30):
+    """Re-launch the step's heavy kernels on the step's own buffers, each timed with HIP events on the launch stream.
+    launches_per_step follows from the layer counts (the top encoder layer runs its row-wise part on B rows and is not
+    counted); algorithmic bytes = compulsory operand + result traffic of one launch, FLOPs = 2 M N K per contraction."""
+    st, cfg = plan.store, plan.cfg
+    De, Dd, H = cfg.e_model, cfg.d_model, cfg.e_heads
+    M, B, T = plan.Me, plan.B, plan.T
+    L, t = plan.enc[0], plan.be_l[0]
+    pre = "encoder.layer0"
+    fams = []
+    full_e = max(cfg.e_layers - 1, 0)  # encoder layers that run at full width in every row
+    if full_e and o.ffn_fusion_pays(De, 4 * De):
+        ffn_bytes = 2.0 * (M * De + 8 * De * De + M * 4 * De + 2 * M * De) + 4.0 * (4 * De + 3 * De + 2 * M)
+        fams.append(dict(
+            kernel=f"ffn_ln_kernel fwd [FFN + LayerNorm, M={M}, {De} -> {4 * De} -> {De}]",
+            fn=lambda: o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.ln2.gamma"),
+                                    st.p(f"{pre}.ln2.beta"), L.x2, L.mean2, L.rstd2,
+                                    ff1=dict(K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **plan._drop(cfg.e_dropout, 1)),
+                                    ff2=dict(K=4 * De, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1, **plan._drop(cfg.e_dropout, 2))),
+            flops=2.0 * 2.0 * M * 4 * De * De, bytes=ffn_bytes, launches_per_step=full_e,
+            pmc_key="ffn_ln_kernel<256,2,4,1>@%d" % (((M + 63) // 64) * 512)))
+        # backward form: dff in, a (gate) in, dpre out, h1 in, dh1 (+ masked copy) out
+        fams.append(dict(
+            kernel=f"ffn_ln_kernel bwd [FFN dgrads + LayerNorm backward, M={M}, width {De}]",
+            fn=lambda: o.ffn_ln_bwd(t.dh, st.t(f"{pre}.ff2.weight"), t.dpre, L.a, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1,
+                                    st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"),
+                                    resid=t.dh, partials=plan._ln_part[f"{pre}.ln1"]),
+            flops=2.0 * 2.0 * M * 4 * De * De, bytes=2.0 * (M * De + 8 * De * De + 2 * M * 4 * De + 3 * M * De),
+            launches_per_step=full_e, pmc_key="ffn_ln_kernel<256,2,4,2>@%d" % (((M + 63) // 64) * 512)))
+    fams.append(dict(
+        kernel=f"gemm_nt [K,Q,V projection, M={M}, N={3 * De}, K={De}]",
+        fn=lambda: o.gemm_nt(plan.x0_e, st.fused(st.w16, pre, "weight"), L.qkv, K=De, bias=st.fused(st.w, pre, "bias")),
+        flops=2.0 * M * 3 * De * De, bytes=2.0 * (M * De + 3 * De * De + M * 3 * De), launches_per_step=cfg.e_layers, pmc_key=None))
+    fams.append(dict(
+        kernel=f"attention fwd [B*H={B * H}, S={T}, dh={De // H}]",
+        fn=lambda: o.attn_fwd(L.qkv, plan.keymask_e, L.lse, L.att, B, T, H, De // H, 0, De, 2 * De),
+        flops=4.0 * B * T * T * De, bytes=2.0 * M * (3 * De + De), launches_per_step=full_e,
+        pmc_key="attn_fwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
+    fams.append(dict(
+        kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
+        fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),
+        flops=2.0 * 4 * B * T * T * De, bytes=2.0 * M * (3 * De + De + 3 * De), launches_per_step=full_e,
+        pmc_key="attn_bwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
+    wg, ps = plan.last_wgrad_launch
+    if wg:
+        fl = sum(2.0 * w.M * w.N * w.K for w in wg)
+        by = sum(2.0 * w.M * (w.N + w.K) + 4.0 * w.N * w.K for w in wg)
+        fams.append(dict(
+            kernel=f"wgrad batch [the step's {len(wg)} weight-gradient problems in one launch + reduction pass]",
+            fn=lambda: o.gemm_wgrad_batch(wg, scratch=plan.wgrad_scratch, sums=ps), flops=fl, bytes=by, launches_per_step=1,
+            pmc_key="wgrad_kernel<256,256,4,2>@122880"))
     ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-    hbm_bound = best["flops"] / best["bytes"] < ridge
-    traffic = None
+    out = []
+    for f in fams:
+        ms = time_launch(o, f["fn"], iters)
+        tflops, gbs = f["flops"] / (ms * 1e-3) / 1e12, f["bytes"] / (ms * 1e-3) / 1e9
+        hbm = f["flops"] / f["bytes"] < ridge
+        out.append(dict(kernel=f["kernel"], avg_launch_ms=ms, launches_per_step=f["launches_per_step"], share_ms=ms * f["launches_per_step"],
+                        bound="hbm" if hbm else "mfma", algorithmic_bytes_per_launch=f["bytes"], algorithmic_flops_per_launch=f["flops"],
+                        gbs=gbs, tflops=tflops, hbm_frac=gbs / PEAK_HBM_GBS, mfma_frac=tflops / PEAK_MFMA_TFLOPS,
+                        frac=(gbs / PEAK_HBM_GBS) if hbm else (tflops / PEAK_MFMA_TFLOPS), pmc_key=f["pmc_key"]))
+    return out, ridge
+
+
+def roofline(plan, o, config_id):
+    fams, ridge = kernel_families(plan, o)
+    best = max(fams, key=lambda f: f["share_ms"])
+    traffic, src = None, None
     try:  # HBM bytes per launch from the committed PMC passes (tools/make_profile_summary.py), not measured here
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
-            traffic = json.load(f)["bytes_per_launch"].get(best["pmc_key"])
+            j = json.load(f)
+        if config_id == 1 and best["pmc_key"]:
+            traffic, src = j["bytes_per_launch"].get(best["pmc_key"]), j.get("source")
     except (OSError, ValueError, KeyError):
         pass
-    out = {"bound": "hbm" if hbm_bound else "mfma", "kernel": best["kernel"],
-           "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
-           "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_MFMA_TFLOPS),
-           "traffic": traffic, "avg_launch_ms": best["ms"], "algorithmic_bytes_per_launch": best["bytes"],
-           "algorithmic_flops_per_launch": best["flops"], "tflops": tflops, "mfma_frac": tflops / PEAK_MFMA_TFLOPS,
-           "intensity_flop_per_byte": best["flops"] / best["bytes"], "ridge_flop_per_byte": ridge}
-    return out
+    hbm = best["bound"] == "hbm"
+    return {"bound": best["bound"], "kernel": best["kernel"], "achieved": best["gbs"] if hbm else best["tflops"],
+            "peak": PEAK_HBM_GBS if hbm else PEAK_MFMA_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s", "frac": best["frac"],
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": best["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": best["algorithmic_bytes_per_launch"],
+            "algorithmic_flops_per_launch": best["algorithmic_flops_per_launch"], "tflops": best["tflops"], "mfma_frac": best["mfma_frac"],
+            "intensity_flop_per_byte": best["algorithmic_flops_per_launch"] / best["algorithmic_bytes_per_launch"],
+            "ridge_flop_per_byte": ridge,
+            "families": [{k: v for k, v in f.items() if k != "pmc_key"} for f in sorted(fams, key=lambda f: -f["share_ms"])]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1)
+    ap.add_argument("--data", choices=["resident", "host"], default="resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=DROPOUT)
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="default: the configuration's own")
     args = ap.parse_args()
+    c = CONFIGS[args.config]
+    dtype = args.dtype or c["dtype"]
+    B, T, P = c["B"], c["T"], c["P"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,35 +259,57 @@ def main():
     from musicstyletransfer_amd import ops as o
     from musicstyletransfer_amd import parallel
 
-    dist = parallel.init_process_group(world, rank, backend=os.environ.get("MST_DIST_BACKEND")) if world > 1 else None
-    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    cfg = E.VAEConfig(e_dropout=args.dropout, d_dropout=args.dropout, **CFG2)
+    dist = parallel.init_process_group(world, rank) if world > 1 else None
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    md = model_dims(c)
+    cfg = E.VAEConfig(e_dropout=args.dropout, d_dropout=args.dropout, **md)
     store = E.ParamStore(cfg, dev, adt, seed=1234)  # identical initial weights on every rank
-    plan = E.StepPlan(store, B_LOCAL, T_LEN, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B_LOCAL * world,
-                      internal_eps=True, seed=1000 + rank)
-    # synthetic piano-rolls, uploaded once: inputs are resident in HBM before the timed region
-    host = synthetic_batches(4, B_LOCAL, T_LEN, CFG2["in_dim"], seed=1234 + rank)
-    resident = [plan.pack_batch(hb["x"], hb["seq_lens"], hb["classes"], hb["labels"]).to(dev) for hb in host]
+    plan = E.StepPlan(store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B * world, internal_eps=True, seed=1000,
+                      sample_offset=rank * B, site_base=64 * rank)
+    host = synthetic_batches(4, B, T, P, seed=1234 + rank)
     reduce_fn = parallel.make_grad_allreduce(dist) if world > 1 else None
     # data parallel: the early part of the gradient bucket is all-reduced while the rest of backward runs
     reducer = parallel.GradReducer(dist) if world > 1 and os.environ.get("MST_DP_OVERLAP", "1") != "0" else None
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        # one captured step per resident batch buffer, each reading its batch in place (StepPlan.bind_inputs): a batcher
-        # that fills a ring of input buffers needs no device-to-device hop, so the timed region has none either
-        plan.bind_inputs(resident[0])
+        if args.data == "resident":
+            # synthetic piano-rolls, uploaded once: inputs are resident in HBM before the timed region. One captured step
+            # per resident batch buffer, each reading its batch in place (StepPlan.bind_inputs)
+            blobs = [plan.pack_batch(hb["x"], hb["seq_lens"], hb["classes"], hb["labels"]).to(dev) for hb in host]
+            feed = None
+        else:
+            # every step's batch goes pinned host -> HBM inside the timed region: the Trainer's batcher, three ring slots
+            from musicstyletransfer_amd.pianoroll import PinnedBatchPipeline
+            from musicstyletransfer_amd.VarAutoEncoder.data import Batch
+            pipe = PinnedBatchPipeline(dev, lambda b, t: plan, n_slots=3)
+            batches = [Batch([hb["x"], hb["seq_lens"], hb["classes"]], [hb["labels"]]) for hb in host]
+            staged0 = [pipe.stage(batches[i % len(batches)]) for i in range(3)]
+            blobs = [s.slot.dev for s in staged0]
+        plan.bind_inputs(blobs[0])
         plan.step_kernels(True, reduce_fn=reduce_fn)  # first step eager (HIP module loads), then capture
         torch.cuda.synchronize()
-        graphs = []
-        for buf in resident:
+        graphs = {}
+        for buf in blobs:
             plan.bind_inputs(buf)
             plan.capture(True, split_optimizer=world > 1, overlap=reducer is not None)
-            graphs.append((plan.graph, plan.graph_late, plan.graph_opt))
+            graphs[buf.data_ptr()] = (plan.graph, plan.graph_late, plan.graph_opt)
 
-        def one_step(i):
-            plan.graph, plan.graph_late, plan.graph_opt = graphs[i % len(graphs)]
+        def launch(buf):
+            plan.graph, plan.graph_late, plan.graph_opt = graphs[buf.data_ptr()]
             plan.run(reduce_fn=reduce_fn, reducer=reducer)
+
+        if args.data == "resident":
+            def one_step(i):
+                launch(blobs[i % len(blobs)])
+        else:
+            feed = pipe.feed((batches[i % len(batches)] for i in range(args.warmup + args.steps)))
+
+            def one_step(i):
+                s = next(feed)  # batch i was staged while step i-1 ran; the generator stages batch i+1 at the next call
+                stream.wait_event(s.slot.uploaded)
+                launch(s.slot.dev)
+                s.slot.consumed.record(stream)
 
         for i in range(args.warmup):
             one_step(i)
@@ -220,42 +317,54 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        ev = [o.Event() for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
+        ev[0].record()
         for i in range(args.steps):
-            one_step(i)
+            one_step(args.warmup + i)
+            ev[i + 1].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        per_step = sorted(ev[i].elapsed_ms(ev[i + 1]) for i in range(args.steps))
+        median_ms = per_step[len(per_step) // 2]
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, median_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, median_ms = float(t[0].item()), float(t[1].item())
         m = plan.metrics()
-        roof = dominant_kernel_roofline(plan, o) if rank == 0 else None
+        if args.data == "host":
+            plan.bind_inputs(blobs[0])
+        roof = roofline(plan, o, args.config) if rank == 0 else None
 
     if rank != 0:
         return
     ms = elapsed / args.steps * 1e3
-    frames = B_LOCAL * T_LEN * world * args.steps
-    step_flops = 3.0 * fwd_flops(CFG2, B_LOCAL, T_LEN)
+    frames = B * T * world * args.steps
+    step_flops = 3.0 * fwd_flops(md, B, T)
+    exec_flops = 3.0 * executed_fwd_flops(md, B, T)
     out = {
         "metric": "piano-roll frames/s (VAE train step)", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: single-track piano-roll VAE train step, T=256, pitch=128, latent=64, "
-                               f"batch={B_LOCAL}/GPU, {args.dtype}; encoder 256x2x8h, decoder 128x1x8h (scripts/train-vae.sh), "
-                               f"dropout {args.dropout}; Xavier-initialised weights",
-                   "global_batch": B_LOCAL * world, "seq_len": T_LEN, "pitches": CFG2["in_dim"], "parallelism": f"dp{world}",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_median": median_ms,
+        "value_at_median": B * T * world / (median_ms * 1e-3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype,
+        "data": "synthetic" if args.data == "resident" else "synthetic (host batches through the pinned pipeline inside the timed region)",
+        "config": {"workload": f"{c['name']}, T={T}, pitch={P}, latent={c['Z']}, batch={B}/GPU, {dtype}; encoder 256x2x8h, decoder "
+                               f"128x1x8h (scripts/train-vae.sh), dropout {args.dropout}; Xavier-initialised weights",
+                   "baseline_config_index": args.config if world == 1 or args.config != 1 else 3,
+                   "global_batch": B * world, "seq_len": T, "pitches": P, "latent": c["Z"], "parallelism": f"dp{world}",
                    "params": store.n_params},
         "step_tflops": step_flops / (ms * 1e-3) / 1e12,
         "step_mfma_frac": step_flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+        "executed_flops_per_step": exec_flops, "algorithmic_flops_per_step": step_flops,
+        "executed_tflops": exec_flops / (ms * 1e-3) / 1e12,
         "elbo": m["total_loss"], "kl": m["kl_loss"],
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(c, args.dropout)
     print(json.dumps(out), flush=True)
 
 

@@ -357,13 +357,28 @@ int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma
  *   loss[b] = (1/T) * sum_t -log p[b,t,label] * (label != 0)     (fp32 [B], written)
  *   probs  : optional fp32 [M, ldp] output (reconstruction)
  *   dlogits: optional act dtype [M, ld]: (p - onehot) * (label != 0) / T * gscale; pad cols zero
+ *   tok_parts: optional fp32 [MST_CE_MAX_WORKGROUPS, 4], the masked token metrics of trainer.py:107-113 kept on the
+ *            device: every workgroup ADDS {sum -log max(p[label], 1e-10), #(label is the arg-max), #(label among
+ *            the top_k), #(label != 0)} of its rows to its own row (no atomics; the caller clears the buffer when it
+ *            reads the metrics and sums the rows): ppl = exp([0]/[3]), acc = [1]/[3], topk = [2]/[3].
  * ------------------------------------------------------------------------ */
+#define MST_CE_MAX_WORKGROUPS 4096
 int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V,
                    const void* logits, int64_t ld, const int32_t* labels,
                    float* loss, float* probs, int64_t ldp,
                    void* dlogits, int64_t ldd, float gscale,
                    int pre_zeroed /* 1: loss[] is already zero (mst_step_begin's zero list), skip the memset node */,
-                   mst_stream_t stream);
+                   float* tok_parts, int top_k, mst_stream_t stream);
+
+/* The reference's own call forms of the two reconstruction losses, on PROBABILITIES (what Model(...) returns):
+ *   SoftmaxCrossEntropy()(probs, labels)                  loss.py:16-23: -log(pick(pred, label)) * (label != 0), / padded T
+ *   BinaryCrossEntropy(from_sigmoid=True)(probs, labels)  loss.py:40-56 without the sigmoid
+ * probs: dtype MST_F32 / MST_BF16 / MST_F16, [B*T, ldp] resp. contiguous [B, n_per_sample]; loss fp32 [B], written.
+ * Forward only (the training step differentiates the fused logit forms above). */
+int mst_ce_from_probs(int dtype, int64_t B, int64_t T, int64_t V, const void* probs, int64_t ldp,
+                      const int32_t* labels, float* loss, mst_stream_t stream);
+int mst_bce_from_probs(int dtype, int64_t B, int64_t n_per_sample, const void* probs, const uint8_t* labels,
+                       float label_smoothing, int downweight, float* loss, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K14: sigmoid + BinaryCrossEntropy (loss.py:27-80), piano-roll head.
@@ -419,6 +434,10 @@ int mst_transpose_shadows(int dtype, const float* w, void* wt16, const int64_t* 
                           const int64_t* tile_prefix, int64_t n_mat, int64_t total_tiles,
                           mst_stream_t stream);
 
+/* out[i] = sum of squares of x[ranges[2i] .. ranges[2i+1]) (device int64 [n_segments, 2]): the per-parameter gradient
+ * norms of the reference's periodic gradient log (trainer.py:257-270) in one launch over the flat bucket */
+int mst_segment_sumsq(const float* x, const int64_t* ranges, int64_t n_segments, float* out, mst_stream_t stream);
+
 /* fp32 -> act dtype cast of a flat range (initial shadow fill) */
 int mst_cast_f32_to_act(int dtype, int64_t n, const float* src, void* dst, mst_stream_t stream);
 
@@ -435,9 +454,11 @@ int mst_rng_advance(uint64_t* state, mst_stream_t stream);
  * step counter / bias-corrected lr (then call mst_adam_flat with advance_step = 0), mst_randn into eps_out, and the two
  * mst_mask_from_lengths masks (model.py:246-247), and two optional buffers to clear (16-byte aligned, sizes multiples
  * of 16: the per-sample loss sums and the gradient bucket, instead of two memset nodes). Any pointer may be NULL to
- * skip that part. rng_state is the uint64[4] state of mst_rng_advance. */
+ * skip that part. rng_state is the uint64[4] state of mst_rng_advance.
+ * eps_index0 (even): eps_out[i] is draw number eps_index0 + i of the step's stream, so a data-parallel rank that
+ * passes its first global sample index times Z draws exactly what a single process draws for those samples. */
 int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2,
-                   float* eps_out, int64_t n_eps, uint32_t eps_site,
+                   float* eps_out, int64_t n_eps, uint32_t eps_site, int64_t eps_index0,
                    const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se, int32_t add_e,
                    uint8_t* mask_d, int64_t Sd, int32_t add_d,
                    void* zero_a, int64_t zero_a_bytes, void* zero_b, int64_t zero_b_bytes, mst_stream_t stream);

@@ -1,14 +1,36 @@
-"""The three loss blocks with the reference's constructor / call signatures (VarAutoEncoder/loss.py:4-80),
-each a single fused HIP kernel over device tensors; all return the per-sample loss [B].
+"""The three loss blocks with the reference's constructor / call signatures AND call semantics
+(VarAutoEncoder/loss.py:4-80), each one HIP kernel over device tensors; all return the per-sample loss [B].
 
-`pred` for SoftmaxCrossEntropy and for BinaryCrossEntropy(from_sigmoid=False) is the PRE-activation
-output of the decoder's output layer in 16-bit: the kernels apply softmax / sigmoid themselves (the reference
-applies softmax inside the model, model.py:256, and takes log(pred) in the loss; the composition is the
-same function). BinaryCrossEntropy(from_sigmoid=True) is not offered: the probabilities are produced, and
-the loss computed, in the same pass."""
+As in the reference, `pred` is what `Model(...)` returns:
+  SoftmaxCrossEntropy()(probs, labels)                     probabilities (model.py:256 applies the softmax); loss.py:21 log(pred)
+  BinaryCrossEntropy(from_sigmoid=True)(probs, labels)     probabilities
+  BinaryCrossEntropy(from_sigmoid=False)(pred, labels)     pre-sigmoid outputs; loss.py:40-42 applies the sigmoid
+so `loss(Model(...)[0], labels)` means what it means there. The training step does not go through these classes:
+engine.StepPlan fuses softmax / sigmoid, the loss and its gradient over the 16-bit output-layer result in one pass. That
+fused form is reachable here as an explicit extra, `from_logits=True` (pre-activation input, 16-bit)."""
 import torch
 
 from .. import ops as o
+
+
+def _rows(pred):
+    """[B, T, V] -> contiguous [B*T, ld] view (a copy only if the input is not already laid out that way)"""
+    B, T, V = pred.shape
+    p2 = pred.reshape(B * T, V)
+    return p2 if p2.is_contiguous() else p2.contiguous()
+
+
+def _padded_logits(pred):
+    """the fused kernels read 16-bit rows whose leading dimension is a multiple of 8 elements"""
+    B, T, V = pred.shape
+    ld = o.roundup(V, 8)
+    if pred.dtype not in (torch.bfloat16, torch.float16):
+        pred = pred.to(torch.bfloat16)
+    if ld == V and pred.is_contiguous():
+        return pred.view(B * T, V)
+    logits = torch.zeros(B * T, ld, dtype=pred.dtype, device=pred.device)
+    logits[:, :V] = pred.reshape(B * T, V)
+    return logits
 
 
 class VariationalKLLoss:
@@ -21,33 +43,35 @@ class VariationalKLLoss:
 
 
 class SoftmaxCrossEntropy:
-    def __init__(self, axis=-1, batch_axis=0):
+    def __init__(self, axis=-1, batch_axis=0, from_logits=False):
         assert axis in (-1, 2) and batch_axis == 0
+        self.from_logits = from_logits
 
     def __call__(self, pred, label):
         B, T, V = pred.shape
-        ld = o.roundup(V, 8)
-        logits = torch.zeros(B * T, ld, dtype=pred.dtype, device=pred.device)
-        logits[:, :V] = pred.reshape(B * T, V)
         loss = torch.zeros(B, dtype=torch.float32, device=pred.device)
-        o.softmax_ce(logits, label.to(torch.int32).contiguous().view(-1), loss, B, T, V)
+        labels = label.to(torch.int32).contiguous().view(-1)
+        if self.from_logits:
+            o.softmax_ce(_padded_logits(pred), labels, loss, B, T, V)
+        else:
+            o.ce_from_probs(_rows(pred), labels, loss, B, T, V)
         return loss
 
 
 class BinaryCrossEntropy:
     def __init__(self, from_sigmoid=False, label_smoothing=0.0, negative_label_downweighting=True):
-        if from_sigmoid:
-            raise NotImplementedError("pass pre-sigmoid outputs: the kernel fuses the sigmoid (see module docstring)")
+        self.from_sigmoid = from_sigmoid
         self.label_smoothing = label_smoothing
         self.negative_label_downweighting = negative_label_downweighting
 
     def __call__(self, pred, label):
         B, T, P = pred.shape
-        ld = o.roundup(P, 8)
-        logits = torch.zeros(B * T, ld, dtype=pred.dtype, device=pred.device)
-        logits[:, :P] = pred.reshape(B * T, P)
         loss = torch.zeros(B, dtype=torch.float32, device=pred.device)
-        npos = torch.zeros(B, dtype=torch.int32, device=pred.device)
-        o.sigmoid_bce(logits, label.to(torch.uint8).contiguous().view(B * T, P), loss, B, T, P,
-                      label_smoothing=self.label_smoothing, downweight=self.negative_label_downweighting, npos=npos)
+        labels = label.to(torch.uint8).contiguous().view(B * T, P)
+        if self.from_sigmoid:
+            o.bce_from_probs(pred.contiguous(), labels, loss, self.label_smoothing, self.negative_label_downweighting)
+        else:
+            npos = torch.zeros(B, dtype=torch.int32, device=pred.device)
+            o.sigmoid_bce(_padded_logits(pred), labels, loss, B, T, P, label_smoothing=self.label_smoothing,
+                          downweight=self.negative_label_downweighting, npos=npos)
         return loss

@@ -6,7 +6,9 @@ the MI355X step engine.
 `tokens` is [B, T] token ids (the reference's path) or [B, T, P] {0,1} piano-roll frames (the piano-roll
 ends). Parameters live in one flat HBM buffer (engine.ParamStore); `.encoder` / `.decoder` expose them by
 name. The model must be placed on a HIP device before it is called: there is no CPU forward."""
+import os
 import sys
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -68,7 +70,8 @@ class Model:
         self.config = config
         self.engine_config = config.to_engine()
         self.store = None
-        self._plans = {}
+        self._plans = OrderedDict()
+        self._evict_hooks = []
         self.encoder = _ParamGroup(self, "encoder.")
         self.decoder = _ParamGroup(self, "decoder.")
         self.act_dtype = torch.bfloat16
@@ -82,17 +85,41 @@ class Model:
         if act_dtype is not None:
             self.act_dtype = act_dtype
         self.store = E.ParamStore(self.engine_config, torch.device(dev), self.act_dtype, params_np=params_np, seed=seed)
-        self._plans = {}
+        self._plans = OrderedDict()
         return self
 
     def collect_params(self):
         return {n: self.store.p(n) for n in self.store.shapes}
 
+    # Plans are cached per (B, T, hyper): data.py:196-198 truncates every token batch to ITS OWN longest sample, so T
+    # changes from batch to batch, and a plan owns every activation / backward buffer of its shape plus its captured
+    # graphs. Padding T up to a bucket is not an option for parity — the reference's softmax runs over the query axis and
+    # padded keys are not excluded (transformer.py:100,111-125), so extra padded positions change the result — hence a
+    # least-recently-used cache with a byte cap instead (MST_PLAN_CACHE_GB, default 64 of the 288 GB).
+    PLAN_CACHE_BYTES = int(float(os.environ.get("MST_PLAN_CACHE_GB", "64")) * (1 << 30))
+
     def plan(self, B, T, **hyper):
         key = (B, T, tuple(sorted(hyper.items())))
-        if key not in self._plans:
-            self._plans[key] = E.StepPlan(self.store, B, T, **hyper)
-        return self._plans[key]
+        plan = self._plans.pop(key, None)
+        if plan is None:
+            dev = self.store.device
+            before = torch.cuda.memory_allocated(dev)
+            plan = E.StepPlan(self.store, B, T, **hyper)
+            plan.cache_bytes = max(0, torch.cuda.memory_allocated(dev) - before)
+            total = plan.cache_bytes + sum(p.cache_bytes for p in self._plans.values())
+            while self._plans and total > self.PLAN_CACHE_BYTES:
+                old_key = next(iter(self._plans))  # least recently used first
+                old = self._plans.pop(old_key)
+                torch.cuda.synchronize(dev)  # nothing in flight may still read its buffers / graphs
+                total -= old.cache_bytes
+                for cb in self._evict_hooks:
+                    cb(old)
+        self._plans[key] = plan  # most recently used last
+        return plan
+
+    def on_plan_evicted(self, callback):
+        """callback(plan) when the cache drops a plan (holders of per-plan state — graphs, input rings — forget it)"""
+        self._evict_hooks.append(callback)
 
     def __call__(self, tokens, seq_lens, classes, eps=None):
         """forward only (model.py:287-296): returns (probs, means, vars) as device tensors"""
@@ -105,7 +132,7 @@ class Model:
         dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
         plan.load_batch(x, seq_lens, classes, dummy, eps)
         plan.forward()
-        plan.losses(with_grad=False)
+        plan.losses(with_grad=False, combine=False)  # (no contribution to the trainer's running metric sums)
         V = cfg.out_dim
         probs = plan.probs[:, :V].float().view(B, T, V)
         return probs, plan.mu, plan.sigma

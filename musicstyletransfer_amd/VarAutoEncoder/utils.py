@@ -20,13 +20,46 @@ class Context:
 
 
 def gpu(index=None):
+    """this rank's GPU: LOCAL_RANK under torch.distributed.run (one process per GPU); MST_FORCE_DEVICE pins every rank
+    to one card (multi-rank rehearsal on a one-GPU box, with MST_DIST_BACKEND=gloo)"""
     if index is None:
-        index = int(os.environ.get("LOCAL_RANK", "0"))
+        index = int(os.environ.get("MST_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     return Context("gpu", index)
 
 
 def cpu():
     return Context("cpu")
+
+
+class ScalarWriter:
+    """what mxboard.SummaryWriter is used for in the reference (trainer.py:84,243-244,257-270): add_scalar(tag, value,
+    global_step). mxboard / tensorboard are not dependencies of this build: scalars are appended as JSON lines to
+    <logdir>/scalars.jsonl ({"tag", "value", "step", "time"}), which any plotting tool reads."""
+
+    def __init__(self, logdir="/tmp/out"):
+        self.path = None
+        try:
+            os.makedirs(logdir, exist_ok=True)
+            self.path = os.path.join(logdir, "scalars.jsonl")
+            self._f = open(self.path, "a")
+        except OSError:
+            self._f = None  # an unwritable log directory must not stop training
+
+    def add_scalar(self, tag, value, global_step=None):
+        if self._f is None:
+            return
+        import json
+        import time
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": global_step, "time": time.time()}) + "\n")
+
+    def flush(self):
+        if self._f is not None:
+            self._f.flush()
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
 
 
 def create_directory_if_not_present(path):

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libmst_hip.so")
 
 MST_BF16, MST_F16, MST_F32 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
+CE_MAX_WORKGROUPS = 4096  # MST_CE_MAX_WORKGROUPS: rows of mst_softmax_ce's token-metric partials
 
 c_i32, c_i64, c_f32, c_f64, c_u64, c_u32 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_uint32
 vp = C.c_void_p
@@ -136,13 +137,17 @@ SIGNATURES = {
                                  vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),
     "mst_reparam_kl_bwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, c_f32, vp, vp, vp]),
-    "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, C.c_int, vp]),
+    "mst_softmax_ce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, c_i64, vp, c_i64, c_f32, C.c_int, vp,
+                                 C.c_int, vp]),
+    "mst_ce_from_probs": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp]),
+    "mst_bce_from_probs": (C.c_int, [C.c_int, c_i64, c_i64, vp, vp, c_f32, C.c_int, vp, vp]),
     "mst_sigmoid_bce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, c_f32, C.c_int, vp, vp, vp, c_i64,
                                   vp, c_i64, c_f32, C.c_int, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
                                 vp, C.c_int, C.POINTER(StepMetrics), vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
+    "mst_segment_sumsq": (C.c_int, [vp, vp, c_i64, vp, vp]),
     "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),
     "mst_dropout_mask": (C.c_int, [c_i64, c_f32, c_u64, c_u32, vp, vp]),
     "mst_add_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp]),
@@ -150,7 +155,7 @@ SIGNATURES = {
     "mst_zero": (C.c_int, [vp, c_i64, vp]),
     "mst_rng_advance": (C.c_int, [vp, vp]),
     "mst_randn": (C.c_int, [c_i64, vp, c_u64, vp, c_u32, vp]),
-    "mst_step_begin": (C.c_int, [vp, vp, c_f64, c_f64, c_f64, vp, c_i64, c_u32, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32,
+    "mst_step_begin": (C.c_int, [vp, vp, c_f64, c_f64, c_f64, vp, c_i64, c_u32, c_i64, vp, c_i64, vp, c_i64, c_i32, vp, c_i64, c_i32,
                                  vp, c_i64, vp, c_i64, vp]),
 }
 

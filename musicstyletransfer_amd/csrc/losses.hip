@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int64_t M, int64_t T_le
                                                          int64_t ld, const int32_t* __restrict__ labels,
                                                          float* __restrict__ loss, float* __restrict__ probs,
                                                          int64_t ldp, T* __restrict__ dlogits, int64_t ldd,
-                                                         float gscale) {
+                                                         float gscale, float* __restrict__ tok_parts, int top_k) {
+  __shared__ float tred[4][4];
+  float t_nll = 0.f, t_acc = 0.f, t_topk = 0.f, t_n = 0.f;  // lane 0 of every wave: token metrics of the wave's rows
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -39,9 +41,26 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int64_t M, int64_t T_le
     const float lse = mx + __logf(se);
     const float inv = 1.f / se;
     const float maskv = (label != 0) ? 1.f : 0.f;
+    const float xl = to_f32(row[label]);
     if (lane == 0) {
-      const float lp = to_f32(row[label]) - lse;  // log p[label]
+      const float lp = xl - lse;  // log p[label]
       atomicAdd(loss + m / T_len, -lp * maskv * inv_T);
+    }
+    if (tok_parts && label != 0) {
+      // masked token metrics (trainer.py:107-113; metrics.py): rank of the label = number of entries that beat it
+      // (ties go to the lower index, as argmax does); perplexity term -log(max(p, 1e-10)) like mx.metric.Perplexity
+      float beat = 0.f;
+      for (int v = lane; v < V; v += 64) {
+        const float xv = to_f32(row[v]);
+        beat += (xv > xl || (xv == xl && v < label)) ? 1.f : 0.f;
+      }
+      beat = wave_sum(beat);
+      if (lane == 0) {
+        t_nll += -__logf(fmaxf(__expf(xl - lse), 1e-10f));
+        t_acc += beat == 0.f ? 1.f : 0.f;
+        t_topk += beat < (float)top_k ? 1.f : 0.f;
+        t_n += 1.f;
+      }
     }
     if (probs || dlogits) {
       const float gs = maskv * inv_T * gscale;
@@ -54,6 +73,32 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int64_t M, int64_t T_le
       }
     }
   }
+  if (tok_parts) {  // one row of partial sums per workgroup, owned by it: plain read-modify-write, no atomics
+    if (lane == 0) { float* r = tred[threadIdx.x >> 6]; r[0] = t_nll; r[1] = t_acc; r[2] = t_topk; r[3] = t_n; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int k = threadIdx.x;
+      tok_parts[(int64_t)blockIdx.x * 4 + k] += tred[0][k] + tred[1][k] + tred[2][k] + tred[3][k];
+    }
+  }
+}
+
+// SoftmaxCrossEntropy on PROBABILITIES, the reference's call form (loss.py:16-23: log(pred), pick, mask, mean over the
+// non-batch axes = / padded T): one element per row is read.
+template <typename TP>
+__global__ __launch_bounds__(256) void ce_probs_kernel(int64_t B, int64_t T_len, const TP* __restrict__ probs, int64_t ldp,
+                                                       const int32_t* __restrict__ labels, float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  float acc = 0.f;
+  for (int64_t t = threadIdx.x; t < T_len; t += 256) {
+    const int label = labels[b * T_len + t];
+    if (label != 0) acc += -__logf((float)probs[(b * T_len + t) * ldp + label]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[b] = (red[0] + red[1] + red[2] + red[3]) / (float)T_len;
 }
 
 // ------------------------------------------------------------------ sigmoid + BCE
@@ -166,6 +211,36 @@ __global__ __launch_bounds__(BCE_THREADS) void sigmoid_bce_kernel(int64_t rows_p
   if (tid == 0) atomicAdd(loss + b, total * inv_n);
 }
 
+// BinaryCrossEntropy(from_sigmoid=True) (loss.py:40-56): `pred` already holds probabilities. Forward only; one
+// workgroup per sample, deterministic (no atomics).
+template <typename TP>
+__global__ __launch_bounds__(BCE_THREADS) void bce_probs_kernel(int64_t n_per_sample, const TP* __restrict__ probs,
+                                                                const uint8_t* __restrict__ labels, float ls, int downweight,
+                                                                float* __restrict__ loss) {
+  __shared__ float red[BCE_THREADS / 64];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const TP* p0 = probs + b * n_per_sample;
+  const uint8_t* y0 = labels + b * n_per_sample;
+  float w = 0.f;
+  if (downweight) {
+    float cnt = 0.f;
+    for (int64_t i = tid; i < n_per_sample; i += BCE_THREADS) cnt += (y0[i] == 1) ? 1.f : 0.f;
+    const float np = block_sum_1024(cnt, red);
+    w = np / (((float)n_per_sample - np) + 1e-12f);
+  }
+  float acc = 0.f;
+  for (int64_t i = tid; i < n_per_sample; i += BCE_THREADS) {
+    const float p = (float)p0[i], y = (float)y0[i];
+    const float s = (1.f - ls) * y + 0.5f * ls;
+    float bce = -(s * __logf(1e-12f + p) + (1.f - s) * __logf(1e-12f + (1.f - p)));
+    if (downweight && y == 0.f) bce = w * bce * bce;
+    acc += bce;
+  }
+  const float total = block_sum_1024(acc, red);
+  if (tid == 0) loss[b] = total / (float)n_per_sample;
+}
+
 // ------------------------------------------------------------------ reparameterisation + KL
 __global__ __launch_bounds__(64) void reparam_kl_fwd_kernel(int Z, const float* __restrict__ mu,
                                                             const float* __restrict__ sigma,
@@ -209,7 +284,7 @@ using namespace mst;
 
 extern "C" int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V, const void* logits, int64_t ld,
                               const int32_t* labels, float* loss, float* probs, int64_t ldp, void* dlogits,
-                              int64_t ldd, float gscale, int pre_zeroed, mst_stream_t stream) {
+                              int64_t ldd, float gscale, int pre_zeroed, float* tok_parts, int top_k, mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && T > 0 && V > 0, "mst_softmax_ce: B,T,V must be positive");
   MST_CHECK_ARG(logits && labels && loss, "mst_softmax_ce: null pointer");
   MST_CHECK_ARG(ld >= V && (!probs || ldp >= V) && (!dlogits || ldd >= V), "mst_softmax_ce: leading dim < V");
@@ -219,12 +294,41 @@ extern "C" int mst_softmax_ce(int dtype, int64_t B, int64_t T, int64_t V, const 
     if (e != hipSuccess) { set_error("mst_softmax_ce: memset: %s", hipGetErrorString(e)); return MST_ERR_LAUNCH; }
   }
   const int64_t M = B * T;
-  const unsigned grid = (unsigned)(cdiv(M, 4) < 4096 ? cdiv(M, 4) : 4096);
+  const unsigned grid = (unsigned)(cdiv(M, 4) < MST_CE_MAX_WORKGROUPS ? cdiv(M, 4) : MST_CE_MAX_WORKGROUPS);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) TT;
     hipLaunchKernelGGL((softmax_ce_kernel<TT>), dim3(grid), dim3(256), 0, s, M, T, (int)V, (const TT*)logits, ld, labels,
-                       loss, probs, ldp, (TT*)dlogits, ldd, gscale);
+                       loss, probs, ldp, (TT*)dlogits, ldd, gscale, tok_parts, top_k);
     MST_CHECK_LAUNCH("softmax_ce_kernel");
+    return MST_OK;
+  });
+}
+
+template <typename F> static int dispatch_prob(int dtype, F&& f) {
+  if (dtype == MST_F32) return f(0.f);
+  return dispatch_act(dtype, f);
+}
+
+extern "C" int mst_ce_from_probs(int dtype, int64_t B, int64_t T, int64_t V, const void* probs, int64_t ldp,
+                                 const int32_t* labels, float* loss, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && T > 0 && V > 0 && probs && labels && loss && ldp >= V, "mst_ce_from_probs: bad argument");
+  return dispatch_prob(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) TP;
+    hipLaunchKernelGGL((ce_probs_kernel<TP>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, B, T, (const TP*)probs, ldp,
+                       labels, loss);
+    MST_CHECK_LAUNCH("ce_probs_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_bce_from_probs(int dtype, int64_t B, int64_t n_per_sample, const void* probs, const uint8_t* labels,
+                                  float label_smoothing, int downweight, float* loss, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && n_per_sample > 0 && probs && labels && loss, "mst_bce_from_probs: bad argument");
+  return dispatch_prob(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) TP;
+    hipLaunchKernelGGL((bce_probs_kernel<TP>), dim3((unsigned)B), dim3(BCE_THREADS), 0, (hipStream_t)stream, n_per_sample,
+                       (const TP*)probs, labels, label_smoothing, downweight, loss);
+    MST_CHECK_LAUNCH("bce_probs_kernel");
     return MST_OK;
   });
 }

@@ -164,6 +164,27 @@ extern "C" int mst_transpose_shadows(int dtype, const float* w, void* wt16, cons
   });
 }
 
+// per-tensor gradient norms for the reference's periodic gradient log (trainer.py:257-270): out[i] = sum of squares of
+// x[offsets[i] .. offsets[i+1]) — one workgroup per tensor of the flat bucket, one launch for all of them
+__global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4];
+  const int64_t lo = offsets[2 * blockIdx.x], hi = offsets[2 * blockIdx.x + 1];
+  float acc = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" int mst_segment_sumsq(const float* x, const int64_t* ranges, int64_t n_segments, float* out, mst_stream_t stream) {
+  MST_CHECK_ARG(x && ranges && out && n_segments > 0 && n_segments <= 65535, "mst_segment_sumsq: bad argument");
+  hipLaunchKernelGGL(segment_sumsq_kernel, dim3((unsigned)n_segments), dim3(256), 0, (hipStream_t)stream, x, ranges, out);
+  MST_CHECK_LAUNCH("segment_sumsq_kernel");
+  return MST_OK;
+}
+
 extern "C" int mst_cast_f32_to_act(int dtype, int64_t n, const float* src, void* dst, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && src && dst, "mst_cast_f32_to_act: bad argument");
   return dispatch_act(dtype, [&](auto tag) -> int {

@@ -54,7 +54,7 @@ __device__ __forceinline__ uint64_t step_seed(uint64_t base, uint64_t step) {
 // seed itself from (base seed, step counter + 1); the state is written back by the workgroup that ARRIVES LAST at
 // rng_state[3], i.e. after every other workgroup has read the old counter.
 __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1,
-                                                         double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site,
+                                                         double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site, int64_t eps_index0,
                                                          const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                                                          int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d,
                                                          u32x4* zero_a, int64_t n16_a, u32x4* zero_b, int64_t n16_b, int n_state) {
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_st
   }
   if (eps_out) {
     for (int64_t i = gid; i < (n_eps + 1) / 2; i += gsz) {
-      const uint32_t a = dropout_hash(s, eps_site, (uint64_t)(2 * i));
-      const uint32_t b = dropout_hash(s, eps_site, (uint64_t)(2 * i + 1));
+      const uint32_t a = dropout_hash(s, eps_site, (uint64_t)(eps_index0 + 2 * i));
+      const uint32_t b = dropout_hash(s, eps_site, (uint64_t)(eps_index0 + 2 * i + 1));
       const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
       const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
       const float r = sqrtf(-2.0f * logf(u1));
@@ -129,13 +129,14 @@ __global__ __launch_bounds__(256) void partial_sums_kernel(PartialSumBatch b) {
 using namespace mst;
 
 extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2, float* eps_out,
-                              int64_t n_eps, uint32_t eps_site, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
+                              int64_t n_eps, uint32_t eps_site, int64_t eps_index0, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                               int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, void* zero_a, int64_t zero_a_bytes,
                               void* zero_b, int64_t zero_b_bytes, mst_stream_t stream) {
   MST_CHECK_ARG((!zero_a || ((uintptr_t)zero_a % 16 == 0 && zero_a_bytes % 16 == 0)) &&
                     (!zero_b || ((uintptr_t)zero_b % 16 == 0 && zero_b_bytes % 16 == 0)),
                 "mst_step_begin: zero buffers must be 16-byte aligned with sizes that are multiples of 16");
   MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
+  MST_CHECK_ARG(eps_index0 >= 0 && eps_index0 % 2 == 0, "mst_step_begin: eps_index0 must be even (Box-Muller pairs)");
   MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
   MST_CHECK_ARG((!mask_e || (Se > 0 && B * Se < (1ll << 31))) && (!mask_d || (Sd > 0 && B * Sd < (1ll << 31))), "mst_step_begin: B * S must stay below 2^31");
   int64_t work = n_eps / 2;
@@ -153,7 +154,7 @@ extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double l
   if (grid > 256) grid = 256;
   if (grid < n_state) grid = n_state;
   hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(SB_THREADS), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
-                     eps_out, n_eps, eps_site, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
+                     eps_out, n_eps, eps_site, eps_index0, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
                      n16_b, (int)n_state);
   MST_CHECK_LAUNCH("step_begin_kernel");
   return MST_OK;

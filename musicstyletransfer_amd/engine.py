@@ -28,6 +28,11 @@ def roundup(a, b):
     return (a + b - 1) // b * b
 
 
+def _lib_ce_rows():
+    from . import _lib
+    return _lib.CE_MAX_WORKGROUPS
+
+
 class VAEConfig:
     """Shape of the model: the union of ModelConfig/EncoderConfig/DecoderConfig/TransformerConfig
     (model.py:22-54, transformer.py:8-21) flattened, plus which ends are attached:
@@ -171,9 +176,49 @@ class ParamStore:
         self.t_prefix = torch.tensor(prefix, dtype=torch.int64, device=device)
         self.t_tiles = prefix[-1]
 
+        # shared by every StepPlan of this store (plans run one after the other on one stream): the per-step RNG state
+        # — ONE stream of seeds however many (B, T) shapes a run goes through — and the weight-gradient work buffer
+        self._rng_state = None
+        self._wgrad_scratch = []
+        # running metric sums of every step since the last read (trainer.py:107-120,181-186), whatever plan ran it:
+        #   metric_acc = [sum kl, sum total, count]; tok_parts = per-workgroup partial rows of the masked token metrics
+        #   {sum -log p[label], #arg-max hits, #top-k hits, #valid} accumulated by mst_softmax_ce (token ends)
+        self.metric_acc = torch.zeros(3, **f32)
+        self.tok_parts = torch.zeros(_lib_ce_rows(), 4, **f32) if cfg.kind == "token" else None
         if params_np is None:
             params_np = xavier_init(cfg, np.random.default_rng(seed))
         self.load_numpy(params_np)
+
+    def rng_state(self, seed=0):
+        """uint64[4] device state of mst_step_begin / mst_rng_advance, created with the first plan's seed"""
+        if self._rng_state is None:
+            self._rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D, 0], dtype=torch.int64, device=self.device)
+        return self._rng_state
+
+    def read_metrics(self, reset=True):
+        """one device->host read of the running sums: {'kl_sum', 'total_sum', 'count'} and, for the token ends,
+        {'nll_sum', 'acc_hits', 'topk_hits', 'n_tokens'} (the caller orders this after the steps it wants included)"""
+        acc = self.metric_acc.cpu().tolist()
+        out = {"kl_sum": acc[0], "total_sum": acc[1], "count": acc[2]}
+        if self.tok_parts is not None:
+            t = self.tok_parts.cpu().double().sum(0).tolist()
+            out.update(nll_sum=t[0], acc_hits=t[1], topk_hits=t[2], n_tokens=t[3])
+        if reset:
+            o.zero(self.metric_acc)
+            if self.tok_parts is not None:
+                o.zero(self.tok_parts)
+        return out
+
+    def wgrad_scratch(self, n_floats=16 * 1024 * 1024):
+        """fp32 work buffer of the wgrad launch's two-pass reduction: one full resident round of 256 x 256 slab tiles
+        (256 work items x 256 KiB = 64 MiB) is all mst_gemm_wgrad_batch_sums ever asks for. Buffers are never freed:
+        captured graphs keep the pointer they were recorded with."""
+        for t in self._wgrad_scratch:
+            if t.numel() >= n_floats:
+                return t
+        t = torch.empty(n_floats, dtype=torch.float32, device=self.device)
+        self._wgrad_scratch.append(t)
+        return t
 
     # ---- views
     def _view(self, flat, name):
@@ -216,6 +261,28 @@ class ParamStore:
         return OrderedDict((n, host[self.offsets[n]: self.offsets[n] + int(np.prod(s))].reshape(s).copy())
                            for n, s in self.shapes.items())
 
+    def shadowed_names(self):
+        """parameters the kernels consume through a 16-bit shadow (GEMM B operands); every other tensor — biases,
+        LayerNorm gamma / beta, class tables, the latent block, token embedding tables — is read in fp32"""
+        names = set()
+        for key in self.t_specs:
+            if key.endswith(".att.W_kqv"):
+                p = key[: -len("W_kqv")]
+                names.update({p + "W_k.weight", p + "W_q.weight", p + "W_v.weight"})
+            else:
+                names.add(key)
+        return names
+
+    def as_consumed_numpy(self):
+        """name -> the values the kernels actually read: the 16-bit shadow (widened to fp32) for shadowed_names(), the
+        fp32 master otherwise. Feeding these to a reference separates weight rounding from kernel error."""
+        w = self.to_numpy("w")
+        w16 = self.w16.detach().float().cpu().numpy()
+        for n in self.shadowed_names():
+            s = self.shapes[n]
+            w[n] = w16[self.offsets[n]: self.offsets[n] + int(np.prod(s))].reshape(s).copy()
+        return w
+
     def refresh_shadows(self):
         o.cast_to_act(self.w, self.w16)
         o.transpose_shadows(self.w, self.wt16, self.t_desc, self.t_prefix, len(self.t_specs), self.t_tiles)
@@ -230,13 +297,20 @@ class StepPlan:
 
     def __init__(self, store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, label_smoothing=0.0,
                  negative_label_downscaling=False, global_batch=None, gscale=None, want_probs=False, seed=0,
-                 internal_eps=False, optimizer_params=None):
+                 internal_eps=False, optimizer_params=None, sample_offset=0, site_base=0):
+        """sample_offset: index of this plan's first sample in the global batch (data parallel: rank * B) — the in-graph eps
+        is drawn per GLOBAL sample index, so the result does not depend on the sharding.
+        site_base: added to every dropout site id (data parallel: a different value per rank gives every rank its own
+        masks under the common step seed)."""
         cfg = store.cfg
         self.store, self.cfg, self.B, self.T = store, cfg, B, T
         self.dev, self.adt = store.device, store.act_dtype
         self.lr, self.clip, self.kl_weight = lr, clip_gradient, kl_weight
         self.ls, self.nld = label_smoothing, negative_label_downscaling
         self.global_batch = global_batch or B
+        self.sample_offset, self.site_base = int(sample_offset), int(site_base)
+        if (self.sample_offset * cfg.latent_dim) % 2:
+            raise ValueError("sample_offset * latent_dim must be even (eps is drawn in Box-Muller pairs)")
         # fp16 needs loss scaling for the 1/(T*P)-sized reconstruction gradients (decoder side); bf16 does
         # not. The encoder side is fed by the KL term, whose sigma - 1/sigma gradient is huge near sigma = 0
         # (loss.py:9 has no epsilon), so it keeps scale 1: the two halves of the flat bucket carry their own
@@ -269,9 +343,10 @@ class StepPlan:
         for name, nbytes in seg:
             self.in_layout[name] = (off, nbytes)
             off = roundup(off + nbytes, 16)
-        self.bind_inputs(torch.zeros(off, dtype=torch.uint8, device=dev))
+        self.own_inbuf = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self.bind_inputs(self.own_inbuf)
         self.eps = torch.zeros(B, Z, **f32)
-        self.rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D, 0], dtype=torch.int64, device=dev)
+        self.rng_state = store.rng_state(seed)
 
         self.pos_e = torch.from_numpy(positional_table(De, Se)).to(dev)
         self.pos_d = torch.from_numpy(positional_table(Dd, Sd)).to(dev)
@@ -299,7 +374,8 @@ class StepPlan:
         # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B)
         self._recon_buf = torch.zeros((B + 3) // 4 * 4, **f32)
         self.recon = self._recon_buf[:B]
-        self.metric_acc = torch.zeros(3, **f32)  # [sum kl, sum total, count]  (trainer.py:115-116)
+        self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
+        self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
         self.logits = act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
         if cfg.kind == "token":
@@ -326,8 +402,7 @@ class StepPlan:
         self.bd_l = [bwd_bufs(self.Md, Dd, cfg.d_heads, Sd) for _ in range(cfg.d_layers)]
         self.be, self.bd = self.be_l[0], self.bd_l[0]
         self._wgrads = []
-        # work buffer of the single wgrad launch's two-pass reduction (tiles x split x 256 KiB; 64 MiB covers configs[1])
-        self.wgrad_scratch = torch.empty(16 * 1024 * 1024, **f32)
+        self.wgrad_scratch = store.wgrad_scratch()
         # LayerNorm parameter gradients: every LayerNorm-backward workgroup leaves one row of column sums here and ONE
         # launch per flush adds them into the bucket (256 workgroups x one atomic per column on the same 2D addresses
         # serialised for ~5 us per launch: 30 us of the step at configs[1])
@@ -400,30 +475,36 @@ class StepPlan:
         if eps is not None:
             self.eps.copy_(dev(eps, torch.float32))
 
-    def pack_batch(self, x, seq_lens, classes, labels, pin=False):
-        """host-side blob with the layout of `inbuf` (what PinnedBatchPipeline stages and bench.py keeps resident)"""
+    def pack_into(self, blob, x, seq_lens, classes, labels):
+        """write one batch into `blob`, a HOST uint8 tensor with the layout of `inbuf` (a persistent page-locked staging
+        buffer of PinnedBatchPipeline, or a fresh one from pack_batch); bytes between the segments are left alone"""
         cfg, B, T = self.cfg, self.B, self.T
-        blob = torch.zeros(self.inbuf.numel(), dtype=torch.uint8)
+        assert blob.dtype == torch.uint8 and not blob.is_cuda and blob.numel() >= self.inbuf.numel()
 
-        def put(name, t):
+        def seg(name, dtype, *shape):
             a, n = self.in_layout[name]
-            blob[a: a + n] = t.contiguous().view(-1).view(torch.uint8)
+            return blob[a: a + n].view(dtype).view(*shape)
 
-        def as_t(a, dtype):
-            return (torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a.cpu()).to(dtype)
+        def as_t(a):
+            return torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a.cpu()
 
         if cfg.kind == "token":
-            put("tokens", as_t(x, torch.int32).view(B, T))
-            put("labels", as_t(labels, torch.int32).view(B, T))
+            seg("tokens", torch.int32, B, T).copy_(as_t(x).reshape(B, T))
+            seg("labels", torch.int32, B, T).copy_(as_t(labels).reshape(B, T))
         else:
             ldp = roundup(cfg.in_dim, 8)
-            roll = torch.zeros(B * T, ldp, dtype=self.adt)
-            roll[:, : cfg.in_dim] = as_t(x, self.adt).view(B * T, cfg.in_dim)
-            put("roll", roll)
-            put("labels", as_t(labels, torch.uint8).view(B * T, cfg.out_dim))
-        put("seq_lens", as_t(seq_lens, torch.int32))
-        put("classes", as_t(classes, torch.int32))
-        return blob.pin_memory() if pin else blob
+            roll = seg("roll", self.adt, B * T, ldp)
+            roll[:, : cfg.in_dim].copy_(as_t(x).reshape(B * T, cfg.in_dim))
+            if ldp != cfg.in_dim:
+                roll[:, cfg.in_dim:].zero_()
+            seg("labels", torch.uint8, B * T, cfg.out_dim).copy_(as_t(labels).reshape(B * T, cfg.out_dim))
+        seg("seq_lens", torch.int32, B).copy_(as_t(seq_lens).reshape(B))
+        seg("classes", torch.int32, B).copy_(as_t(classes).reshape(B))
+        return blob
+
+    def pack_batch(self, x, seq_lens, classes, labels):
+        """a fresh host blob with the layout of `inbuf` (what bench.py keeps resident after one upload)"""
+        return self.pack_into(torch.zeros(self.inbuf.numel(), dtype=torch.uint8), x, seq_lens, classes, labels)
 
     def load_packed(self, blob):
         """one copy (host->device or device->device) of a pack_batch() blob into the step's input buffers"""
@@ -433,13 +514,20 @@ class StepPlan:
     def _drop(self, p, site):
         return dict(dropout_p=p, dropout_site=site, dropout_seed_ptr=self.rng_state) if p > 0 else {}
 
+    def _site_e(self, i):
+        """first of the three dropout site ids of encoder layer i (attention output, FFN hidden, FFN output)"""
+        return self.site_base + 3 * i
+
+    def _site_d(self, i):
+        return self.site_base + 3 * (self.cfg.e_layers + i)
+
     def _top_encoder_layer_fwd(self, i, L, x_in):
         """Last encoder layer: the model reads its output at position 0 only (model.py:97) and everything after the
         attention mix is row-wise, so after the dense K/Q/V projection and the softmax row statistics (which
         normalise over ALL queries) only query 0 is attended and only B rows go through W_proj, LN1, the FFN and LN2.
         The other rows of these buffers are never produced nor read (backward: _top_encoder_layer_bwd)."""
         cfg, st, B, S = self.cfg, self.store, self.B, self.T
-        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, 3 * i
+        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, self._site_e(i)
         pre = f"encoder.layer{i}"
 
         def row0(buf):
@@ -498,7 +586,8 @@ class StepPlan:
         need_rng = cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps
         o.step_begin(rng_state=self.rng_state if need_rng else None,
                      adam_state=st.step_state if self._tick_adam else None, lr=self.lr, beta1=self.opt["beta1"],
-                     beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None, lens=self.seq_lens,
+                     beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None,
+                     eps_index0=self.sample_offset * cfg.latent_dim, lens=self.seq_lens,
                      mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
                      zero_a=self._recon_buf, zero_b=st.g if self._tick_adam else None)
         # ---- encoder input (model.py:81-91, transformer.py:270)
@@ -510,7 +599,7 @@ class StepPlan:
                       grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T)
         x = self.x0_e
         for i, L in enumerate(self.enc):
-            x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, 3 * i)
+            x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, self._site_e(i))
         self.enc_out = x
         # ---- latent block + decoder position 0 (model.py:97-103,292,229-232)
         o.latent_fwd(x.view(B, Se, -1), st.p("encoder.latent_proj.weight"), st.p("encoder.latent_proj.bias"), self.eps,
@@ -524,7 +613,7 @@ class StepPlan:
             o.gemm_nt(self.roll, st.t("decoder.embedding.weight"), self.x0_d, M=B * T, N=Dd, alpha=sq_d,
                       rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1))
         x = self.x0_d
-        site_d = 3 * cfg.e_layers
+        site_d = self._site_d(0)
         for i, L in enumerate(self.dec):
             x = self._layer_fwd("decoder", i, L, x, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout, site_d + 3 * i)
         self.dec_out = x
@@ -538,7 +627,8 @@ class StepPlan:
         dl = self.dlogits if with_grad else None
         if cfg.kind == "token":
             o.softmax_ce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, probs=self.probs, dlogits=dl,
-                         gscale=self.gscale, pre_zeroed=True)
+                         gscale=self.gscale, pre_zeroed=True,
+                         tok_parts=self.store.tok_parts if self.track_token_metrics else None)
         else:
             o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
                           downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale,
@@ -566,6 +656,7 @@ class StepPlan:
     def _flush_grads(self):
         """the weight gradients collected so far in one wgrad launch; the LayerNorm column sums ride on its reduction pass"""
         o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch, sums=self._psums)
+        self.last_wgrad_launch = (self._wgrads, self._psums)  # (bench.py re-launches the step's own wgrad batch to time it)
         self._wgrads, self._psums = [], []
 
     def _out_ln_bwd(self, side, i, L, D, p, site0, t, M):
@@ -663,7 +754,7 @@ class StepPlan:
     def _top_encoder_layer_bwd(self, i, L, x_in, dx_in, t, next_ln=None):
         """_layer_bwd for the LAST encoder layer, on the B rows (position 0 of each sample) that carry gradient."""
         cfg, st, B, S = self.cfg, self.store, self.B, self.T
-        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, 3 * i
+        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, self._site_e(i)
         pre = f"encoder.layer{i}"
         c = self.top
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
@@ -736,7 +827,7 @@ class StepPlan:
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         fuse_d, fuse_e = o.ln_bwd_fusion_pays(Dd), o.ln_bwd_fusion_pays(De)
-        site_d = 3 * cfg.e_layers
+        site_d = self._site_d(0)
         last = cfg.d_layers - 1
         if fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
             o.gemm_nt_ln_bwd(self.dlogits, st.t("decoder.output_layer.weight"), self.bd_l[last].dh, M=B * T, N=Dd, K=ldv,
@@ -772,7 +863,7 @@ class StepPlan:
                      enc_scale=self.gscale_enc / self.gscale)
         top = cfg.e_layers - 1
         x_in = self.enc[top - 1].x2 if top > 0 else self.x0_e
-        below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, 3 * (top - 1), self.be_l[top - 1], self.Me),
+        below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, self._site_e(top - 1), self.be_l[top - 1], self.Me),
                  self.be_l[top - 1]) if (fuse_e and top > 0) else None
         self._top_encoder_layer_bwd(top, self.enc[top], x_in, self.be_l[0].dx_a, self.be_l[top], next_ln=below)
         if flush and cfg.e_layers >= 2:
@@ -787,10 +878,10 @@ class StepPlan:
         fuse_e = o.ln_bwd_fusion_pays(De)  # then every layer's leading LayerNorm backward already ran in the GEMM above it
         for i in reversed(range(cfg.e_layers - 1)):
             x_in = self.enc[i - 1].x2 if i > 0 else self.x0_e
-            below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, 3 * (i - 1), self.be_l[i - 1], self.Me),
+            below = (self._out_ln_bwd("encoder", i - 1, self.enc[i - 1], De, cfg.e_dropout, self._site_e(i - 1), self.be_l[i - 1], self.Me),
                      self.be_l[i - 1]) if (fuse_e and i > 0) else None
             self._layer_bwd("encoder", i, self.enc[i], x_in, dy, tgt, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout,
-                            3 * i, self.be_l[i], dy_done=fuse_e, next_ln=below)
+                            self._site_e(i), self.be_l[i], dy_done=fuse_e, next_ln=below)
             dy, tgt, nxt = tgt, nxt, tgt
         d_x0_e = dy
         if cfg.kind == "token":
@@ -890,8 +981,6 @@ class StepPlan:
 
     def metrics(self, reset=True):
         """(kl_loss, total_loss) batch means accumulated on the device (trainer.py:115-116,185-186); one sync."""
-        acc = self.metric_acc.cpu().tolist()
-        if reset:
-            self.metric_acc.zero_()
-        n = max(acc[2], 1.0)
-        return {"kl_loss": acc[0] / n, "total_loss": acc[1] / n, "count": acc[2]}
+        m = self.store.read_metrics(reset)
+        n = max(m["count"], 1.0)
+        return {"kl_loss": m["kl_sum"] / n, "total_loss": m["total_sum"] / n, "count": m["count"]}

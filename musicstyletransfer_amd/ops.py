@@ -26,6 +26,11 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_cuda, "mst ops need device tensors (there is no CPU fallback)"
+    # launches go to torch's current stream of the CURRENT device: a tensor living on another card would be reached
+    # across devices without peer access (a fault, not an error code), so refuse it here
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "call torch.cuda.set_device() for this rank's GPU first")
     return t.data_ptr()
 
 
@@ -345,10 +350,29 @@ def reparam_kl_bwd(mu, sigma, eps, dz, kl_weight, dmu, dsigma):
 
 
 # --------------------------------------------------------------------------- loss heads
-def softmax_ce(logits, labels, loss, B, T, V, probs=None, dlogits=None, gscale=1.0, pre_zeroed=False):
+def softmax_ce(logits, labels, loss, B, T, V, probs=None, dlogits=None, gscale=1.0, pre_zeroed=False, tok_parts=None, top_k=5):
+    """tok_parts: fp32 [CE_MAX_WORKGROUPS, 4] running partial sums of the masked token metrics (see the header)"""
+    if tok_parts is not None:
+        assert tok_parts.dtype == torch.float32 and tok_parts.is_contiguous() and tuple(tok_parts.shape) == (_lib.CE_MAX_WORKGROUPS, 4)
     call("mst_softmax_ce", dt(logits), B, T, V, ptr(logits), ld(logits), ptr(labels), ptr(loss), ptr(probs),
          (ld(probs) if probs is not None else 0), ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale,
-         1 if pre_zeroed else 0, stream())
+         1 if pre_zeroed else 0, ptr(tok_parts), top_k, stream())
+
+
+_PROB_DT = {torch.float32: _lib.MST_F32, torch.bfloat16: MST_BF16, torch.float16: MST_F16}
+
+
+def ce_from_probs(probs2, labels, loss, B, T, V):
+    """SoftmaxCrossEntropy on probabilities (the reference's call form); probs2: [B*T, ld] fp32 / 16-bit"""
+    call("mst_ce_from_probs", _PROB_DT[probs2.dtype], B, T, V, ptr(probs2), ld(probs2), ptr(labels), ptr(loss), stream())
+
+
+def bce_from_probs(probs, labels, loss, label_smoothing=0.0, downweight=False):
+    """BinaryCrossEntropy(from_sigmoid=True): probs / labels contiguous [B, ...] with the same number of elements per sample"""
+    B = probs.shape[0]
+    assert probs.is_contiguous() and labels.is_contiguous() and labels.dtype == torch.uint8 and labels.numel() == probs.numel()
+    call("mst_bce_from_probs", _PROB_DT[probs.dtype], B, probs.numel() // B, ptr(probs), ptr(labels), label_smoothing,
+         1 if downweight else 0, ptr(loss), stream())
 
 
 def sigmoid_bce(logits, labels, loss, B, T, P, label_smoothing=0.0, downweight=False, npos=None, probs=None,
@@ -379,6 +403,11 @@ def transpose_shadows(w, wt16, desc, tile_prefix, n_mat, total_tiles):
     call("mst_transpose_shadows", dt(wt16), ptr(w), ptr(wt16), ptr(desc), ptr(tile_prefix), n_mat, total_tiles, stream())
 
 
+def segment_sumsq(x, ranges, out):
+    """out[i] = sum of squares of x[ranges[i,0]:ranges[i,1]]; ranges: device int64 [n, 2]"""
+    call("mst_segment_sumsq", ptr(x), ptr(ranges), ranges.shape[0], ptr(out), stream())
+
+
 def cast_to_act(src, dst):
     call("mst_cast_f32_to_act", dt(dst), src.numel(), ptr(src), ptr(dst), stream())
 
@@ -403,12 +432,12 @@ def randn(out, seed=0, seed_ptr=None, site=0):
     call("mst_randn", out.numel(), ptr(out), seed, ptr(seed_ptr), site, stream())
 
 
-def step_begin(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, lens=None,
+def step_begin(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, eps_index0=0, lens=None,
                mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None):
     B = lens.shape[0] if lens is not None else 0
     nbytes = lambda t: t.numel() * t.element_size() if t is not None else 0
     call("mst_step_begin", ptr(rng_state), ptr(adam_state), lr, beta1, beta2, ptr(eps_out),
-         (eps_out.numel() if eps_out is not None else 0), eps_site, ptr(lens), B, ptr(mask_e),
+         (eps_out.numel() if eps_out is not None else 0), eps_site, eps_index0, ptr(lens), B, ptr(mask_e),
          (mask_e.shape[1] if mask_e is not None else 0), add_e, ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d,
          ptr(zero_a), nbytes(zero_a), ptr(zero_b), nbytes(zero_b), stream())
 

@@ -21,13 +21,16 @@ import torch
 
 
 def init_process_group(world, rank, backend=None):
-    """env:// rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    """env:// rendezvous on 127.0.0.1 (the container hostname may not resolve). The launcher (torch.distributed.run)
+    exports MASTER_PORT; the fallback below only serves hand-started ranks, which must agree on a port anyway.
+    Call torch.cuda.set_device() for this rank's GPU FIRST: the nccl (= RCCL) group binds to the current device.
+    MST_DIST_BACKEND=gloo rehearses the multi-rank path with the ranks sharing one card (tests, one-GPU boxes)."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("MST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
@@ -78,6 +81,8 @@ def shard_batch(batch, world, rank):
 
 
 def global_eps(seed, step, global_batch, latent_dim, lo, hi):
-    """eps drawn per GLOBAL sample index, so results do not depend on how the batch is sharded"""
+    """Host-side eps drawn per GLOBAL sample index, for callers that INJECT eps (StepPlan(internal_eps=False)): results
+    then do not depend on how the batch is sharded. The in-graph draw of the training step follows the same rule on the
+    device: mst_step_begin(eps_index0 = first global sample index * Z), see StepPlan(sample_offset=...)."""
     rng = np.random.default_rng([seed, step])
     return rng.standard_normal((global_batch, latent_dim)).astype(np.float32)[lo:hi]

@@ -8,8 +8,8 @@ a pitch is 1 in every frame it sounds in. Batches follow the Dataset protocol of
 tokens -> frames [B, T, P]: input = [start row, frames 0..T-2], labels = frames 0..T-1 (next-frame target,
 the analogue of tokens=[SOS,data], labels=[data,PAD], data.py:160-168); the start row has only pitch 0 set.
 
-`PinnedBatchPipeline` is the pinned-host -> HBM leg: batches are staged in page-locked buffers and copied
-on a side HIP stream while the previous step computes."""
+`PinnedBatchPipeline` is the pinned-host -> HBM leg: batches are packed into persistent page-locked ring buffers and
+copied on a side HIP stream while the previous step computes; Trainer.fit drives it."""
 import numpy as np
 import torch
 
@@ -161,39 +161,76 @@ class SyntheticPianoRollDataset(_ArrayDataset):
             yield Batch([self.x[idx], self.seq_lens[idx], self.classes[idx]], [self.labels[idx]], pad)
 
 
+class _Slot:
+    """one stage of a plan's input ring: a page-locked host blob, its device twin, and the two events that order reuse"""
+
+    def __init__(self, nbytes, device):
+        self.host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.uploaded = torch.cuda.Event()  # recorded on the copy stream after the H2D copy of this slot
+        self.consumed = torch.cuda.Event()  # recorded on the compute stream after the step that read this slot
+        self.used = False
+
+
+class StagedBatch:
+    def __init__(self, plan, slot, batch):
+        self.plan, self.slot, self.batch = plan, slot, batch
+
+
 class PinnedBatchPipeline:
-    """Iterate a Dataset one batch ahead: batch i+1 is packed into ONE page-locked blob (engine.StepPlan.pack_batch) and
-    copied host -> device on a side stream while step i runs; `next_into` makes the compute stream wait for that copy and
-    moves the blob into the plan's static input buffer with a single device-to-device copy."""
+    """The pinned-host -> HBM leg of the batcher (north_star: "pinned-host pipeline overlapped on a side HIP stream";
+    reference hook: data.py:181-198 -> trainer.py:156-157, where every step begins with four synchronous as_in_context copies).
 
-    def __init__(self, dataset, device, plan_for):
-        """plan_for(B, T) -> StepPlan (shapes may change from batch to batch on the token path)"""
-        self.it, self.device, self.plan_for = iter(dataset), device, plan_for
+    Per (B, T) plan a ring of `n_slots` PERSISTENT page-locked host blobs and matching device blobs (allocated and pinned
+    once, reused for the whole run). stage(batch) packs the batch into the next slot's host blob (engine.StepPlan.pack_into)
+    and enqueues ONE host->device copy on the pipeline's own stream, behind the event of the step that last read that device
+    blob; the step that consumes the slot makes the compute stream wait for the copy's event and replays a graph captured
+    on that device blob (StepPlan.bind_inputs: no device-to-device hop). feed(dataset) runs one batch ahead: batch i+1 is
+    packed and uploaded while the graph of step i executes."""
+
+    def __init__(self, device, plan_for, n_slots=3):
+        """plan_for(B, T) -> StepPlan (shapes change from batch to batch on the token path)"""
+        assert n_slots >= 2
+        self.device, self.plan_for, self.n_slots = device, plan_for, n_slots
         self.stream = torch.cuda.Stream(device=device)
-        self.staged = None
-        self._stage()
+        self.rings = {}
 
-    def _stage(self):
-        try:
-            b = next(self.it)
-        except StopIteration:
-            self.staged = None
-            return
-        x = np.asarray(b.data[0])
+    def stage(self, batch, shard=None):
+        """pack + upload one batch; shard = (lo, hi) rows of the global batch this rank keeps (data parallel)"""
+        x, seq_lens, classes = batch.data
+        labels = batch.label[0]
+        if shard is not None:
+            lo, hi = shard
+            x, seq_lens, classes, labels = x[lo:hi], seq_lens[lo:hi], classes[lo:hi], labels[lo:hi]
+        x = np.asarray(x)
         plan = self.plan_for(x.shape[0], x.shape[1])
-        host = plan.pack_batch(x, b.data[1], b.data[2], b.label[0], pin=True)
+        ring = self.rings.get(id(plan))
+        if ring is None:
+            ring = self.rings[id(plan)] = {"slots": [_Slot(plan.own_inbuf.numel(), self.device) for _ in range(self.n_slots)], "next": 0,
+                                           "plan": plan}
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self.n_slots
+        if slot.used:
+            slot.uploaded.synchronize()  # the previous copy OUT of this host blob has finished (long ago, normally)
+        plan.pack_into(slot.host, x, seq_lens, classes, labels)
         with torch.cuda.stream(self.stream):
-            dev = host.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self.staged = (plan, dev, ev, host, b)
+            if slot.used:
+                self.stream.wait_event(slot.consumed)  # the step that read the device blob is done with it
+            slot.dev.copy_(slot.host, non_blocking=True)
+            slot.uploaded.record(self.stream)
+        slot.used = True
+        return StagedBatch(plan, slot, batch)
 
-    def next_into(self):
-        """returns (plan, batch) with the batch loaded into plan's inputs, or None at the end of the epoch"""
-        if self.staged is None:
-            return None
-        plan, dev, ev, _host, b = self.staged
-        torch.cuda.current_stream().wait_event(ev)
-        plan.load_packed(dev)
-        self._stage()
-        return plan, b
+    def feed(self, dataset, shard_of=None):
+        """yields StagedBatch objects, staging batch i+1 right after the consumer has launched step i"""
+        it = iter(dataset)
+        cur = next(it, None)
+        staged = self.stage(cur, shard_of(cur) if shard_of else None) if cur is not None else None
+        while staged is not None:
+            yield staged
+            cur = next(it, None)
+            staged = self.stage(cur, shard_of(cur) if shard_of else None) if cur is not None else None
+
+    def drop(self, plan):
+        """forget a plan's ring (the plan cache evicted it)"""
+        self.rings.pop(id(plan), None)
