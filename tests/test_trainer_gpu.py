@@ -241,17 +241,19 @@ def test_validation_pass_early_stopping_and_scalar_log(gpu, tmp_path, monkeypatc
     flags[flags.index("--checkpoint-frequency") + 1] = "5"
     flags[flags.index("--num-checkpoints-not-improved") + 1] = "2"
     flags[flags.index("--learning-rate") + 1] = "0.0"  # nothing improves: the second checkpoint onwards counts as not improved
-    flags[flags.index("--validation-split") + 1] = "0.2"
+    flags[flags.index("--validation-split") + 1] = "0.5"  # (2 + 3 files: one of each class for validation)
     t = main.main(flags + ["--data", MIDI, "--model-output", str(folder), "--out-samples", str(tmp_path / "s"), "--max-steps", "200"])
-    # stopped by early stopping, not by max-steps: checkpoint 1 sets the best loss, 2 and 3 do not improve on it
-    assert t.train_state.n_checkpoints == 3 and t.train_state.num_checkpoints_not_improved == 2, t.train_state.__dict__
-    assert t.train_state.n_batches == 15
+    # stopped by early stopping, not by max-steps: checkpoint 1 sets the best loss; with lr = 0 later ones only differ by
+    # the fresh eps / dropout masks of every validation step (trainer.py:166-167: dropout stays on), so two of them soon
+    # fail to improve
+    assert t.train_state.num_checkpoints_not_improved == 2 and t.train_state.n_checkpoints >= 3, t.train_state.__dict__
+    assert t.train_state.n_batches == 5 * t.train_state.n_checkpoints < 200
     assert np.isfinite(t.train_state.best_resconstruction_loss)
     assert set(t.last_validation) >= {"ppl", "acc", "topk", "kl_loss", "total_loss"}
     # a validation step leaves weights, moments and the step counter alone
     st = t.model.store
     w, steps = st.w.clone(), int(st.step_state[0].item())
-    train, valid = D.load_dataset(D.Loader(MIDI, 64, 4), 8, 0.2)
+    train, valid = D.load_dataset(D.Loader(MIDI, 64, 4), 8, 0.5)
     for b in valid:
         t._step(b, is_train=False)
     t.stream.synchronize()
@@ -288,7 +290,17 @@ def test_pinned_pipeline_feeds_the_same_training_as_direct_copies(gpu, tmp_path)
                                  label_smoothing=0.0, negative_label_downscaling=False, verbose=False, max_steps=9)
         return trainer.Trainer(tc, gpu_ctx(0), model.Model(cfg), None)
 
-    ds = SyntheticPianoRollDataset(8, 32, 72, n_pitches=128, density=0.05, seed=3)
+    class Fixed:  # one epoch's batches, the same objects for both trainers (the dataset reshuffles on every pass)
+        def __init__(self, batches):
+            self.batches, self.batch_size = batches, 8
+
+        def __iter__(self):
+            return iter(self.batches)
+
+        def num_classes(self):
+            return 2
+
+    ds = Fixed(list(SyntheticPianoRollDataset(8, 32, 72, n_pitches=128, density=0.05, seed=3)))
     a = make()
     a.fit(ds, str(tmp_path / "a"), epochs=1)
     assert a.train_state.n_batches == 9
