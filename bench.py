@@ -91,13 +91,10 @@ def cpu_baseline(c, dropout, budget_s=20.0):
     """time the CPU oracle on a bounded sample: training steps of one batch of this configuration's shape, same dropout
     (explicit keep masks, drawn once), until ~budget_s of CPU work"""
     from oracle import vae_oracle as O
-    # the GPU box gives one GPU's share of the host: 16 cores (asking torch for every core the kernel
+    # the GPU box gives one GPU's share of the host (a cgroup quota of 16 cores; asking torch for every core the kernel
     # reports oversubscribes that share and runs ~50x slower)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
+    from musicstyletransfer_amd.VarAutoEncoder.utils import host_cpu_share
+    cores = max(1, min(host_cpu_share(), 16))
     torch.set_num_threads(cores)
     md = model_dims(c)
     cfg = O.OracleConfig(md["kind"], md["in_dim"], md["out_dim"], md["num_classes"], md["latent_dim"], md["e_model"], md["e_layers"],
@@ -258,6 +255,8 @@ def main():
     from musicstyletransfer_amd import engine as E
     from musicstyletransfer_amd import ops as o
     from musicstyletransfer_amd import parallel
+    from musicstyletransfer_amd.VarAutoEncoder.utils import limit_host_threads
+    limit_host_threads()
 
     dist = parallel.init_process_group(world, rank) if world > 1 else None
     adt = torch.bfloat16 if dtype == "bf16" else torch.float16
@@ -348,6 +347,7 @@ def main():
     out = {
         "metric": "piano-roll frames/s (VAE train step)", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_median": median_ms,
+        "ms_per_step_max": per_step[-1], "ms_per_step_p90": per_step[int(0.9 * (len(per_step) - 1))],
         "value_at_median": B * T * world / (median_ms * 1e-3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype,
         "data": "synthetic" if args.data == "resident" else "synthetic (host batches through the pinned pipeline inside the timed region)",

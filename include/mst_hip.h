@@ -105,6 +105,9 @@ typedef struct mst_gemm_args {
   float dropout_p; uint64_t dropout_seed; uint32_t dropout_site;
   int32_t self_resid;
   const uint64_t* dropout_seed_ptr; /* optional DEVICE word XORed into dropout_seed (per-step seed under graph replay) */
+  int32_t a_u8; /* 1: A is uint8 [M, lda bytes] (piano-roll frames as they arrive from the batcher), widened to the
+                 * activation type while the tile is staged into LDS: the frames are never stored in 16 bits. Offered
+                 * for the embedding GEMMs' form: 16-bit C, no dropout / self_resid, lda % 8 == 0. */
 } mst_gemm_args;
 
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
@@ -204,6 +207,8 @@ typedef struct mst_wgrad_args {
   float scale;
   int64_t a_rows_per_group, a_group_stride, a_group_offset;
   int64_t b_rows_per_group, b_group_stride, b_group_offset;
+  int32_t a_u8; /* 1: A is uint8 [M, lda bytes] (the embedding tables' gradient contracts the piano-roll frames), widened on
+                 * the way into LDS; lda % 8 == 0 */
 } mst_wgrad_args;
 
 int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream);

@@ -72,6 +72,7 @@ class Trainer:
         # THIS rank's GPU becomes the current device before anything touches HIP: the process group binds to it, and
         # every launch goes to torch's current stream of the current device (ops.ptr refuses tensors of another card)
         torch.cuda.set_device(device)
+        utils.limit_host_threads()
         self.dist = parallel.init_process_group(self.world, self.rank) if self.world > 1 else None
         self.reduce_fn = parallel.make_grad_allreduce(self.dist) if self.dist is not None else None
         # data parallel: asynchronous two-range all-reduce overlapped with the tail of backward (engine.StepPlan.capture)

@@ -31,6 +31,37 @@ def cpu():
     return Context("cpu")
 
 
+def host_cpu_share():
+    """CPU cores this process may actually use: the cgroup CPU quota when there is one (a GPU box hands each GPU's job a
+    16-core share of a 128-core host, and sched_getaffinity still reports all 128), else the affinity mask"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+def limit_host_threads():
+    """keep torch's intra-op pool within the process's CPU share: oversubscribed pool threads spin when idle and run the
+    process into its quota, which stalls the batcher thread for tens of milliseconds at a time"""
+    import torch
+    n = host_cpu_share()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return n
+
+
 class ScalarWriter:
     """what mxboard.SummaryWriter is used for in the reference (trainer.py:84,243-244,257-270): add_scalar(tag, value,
     global_step). mxboard / tensorboard are not dependencies of this build: scalars are appended as JSON lines to

@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_site", c_u32),
         ("self_resid", c_i32),
         ("dropout_seed_ptr", vp),
+        ("a_u8", c_i32),
     ]
 
 
@@ -89,6 +90,7 @@ class WgradArgs(C.Structure):
         ("scale", c_f32),
         ("a_rows_per_group", c_i64), ("a_group_stride", c_i64), ("a_group_offset", c_i64),
         ("b_rows_per_group", c_i64), ("b_group_stride", c_i64), ("b_group_offset", c_i64),
+        ("a_u8", c_i32),
     ]
 
 

@@ -88,6 +88,14 @@ template <typename T> __device__ __forceinline__ uint16_t f32_to_bits(float f) {
   return b;
 }
 
+// 8 uint8 values (piano-roll frame bytes) -> 8 activation elements, exact for 0..255 in both 16-bit types
+template <typename T> __device__ __forceinline__ u32x4 expand_u8x8(u32x2 raw) {
+  Pack8 p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) p.h[e] = f32_to_bits<T>((float)((raw[e >> 2] >> (8 * (e & 3))) & 0xFFu));
+  return p.u;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -274,7 +274,8 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 // The tile's K loop, shared by the kernels below: locates the workgroup's tile (m0, n0) and leaves the fp32
 // accumulators in `acc`; on return every wave has passed the loop's last barrier, so `smem` is free to reuse.
 // AREMAP: the A row remap is compiled in (a 64-bit division per staged chunk of the prologue).
-template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true>
+// AU8: A holds uint8 elements (mst_gemm_args.a_u8): a chunk is an 8-byte load, widened when it is written to LDS.
+template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false>
 __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0) {
   constexpr int CHUNKS = BK / 8;
@@ -305,11 +306,12 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   m0 = (bid / tiles_n) * BM;
   n0 = (bid % tiles_n) * BN;
 
-  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  typedef typename std::conditional<AU8, uint8_t, T>::type TA;
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(a.A);
   const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
 
   // per-thread staging assignment: chunk c -> (row = c / CHUNKS, ch = c % CHUNKS)
-  const T* a_ptr[A_CH];
+  const TA* a_ptr[A_CH];
   bool a_ok[A_CH];
   int a_lds[A_CH], a_ch[A_CH];
 #pragma unroll
@@ -336,19 +338,24 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   }
 
   u32x4 ra[A_CH], rb[B_CH];
+  u32x2 ra8[AU8 ? A_CH : 1];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   auto load_tile = [&](int64_t k0) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i)
-      ra[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
+    for (int i = 0; i < A_CH; ++i) {
+      if constexpr (AU8) ra8[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x2*>(a_ptr[i] + k0) : u32x2{0u, 0u};
+      else ra[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
+    }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       rb[i] = (b_ok[i] && (k0 + b_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(b_ptr[i] + k0) : zero4;
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i)
+    for (int i = 0; i < A_CH; ++i) {
+      if constexpr (AU8) ra[i] = expand_u8x8<T>(ra8[i]);
       if (BM * CHUNKS >= NT || tid < BM * CHUNKS) sA[buf * BM * CHUNKS + a_lds[i]] = ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) sB[buf * BN * CHUNKS + b_lds[i]] = rb[i];
   };
@@ -396,12 +403,12 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS, int PATH, bool DROP>
+template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, int BK, bool ROWOPS, int PATH, bool DROP, bool AU8 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
-  gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS>(a, smem, acc, m0, n0);
+  gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS, AU8>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0);
 }
@@ -969,14 +976,16 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
                                  (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
   const bool drop = a.dropout_p > 0.f || a.self_resid;
   // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
-  const int variant = (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
+  const int variant = a.a_u8 ? (fast ? 8 : 9) : (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
   typedef void (*kern_t)(mst_gemm_args);
-  const kern_t fns[8] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
+  // [8], [9]: uint8 A operand (the piano-roll embedding GEMMs: row ops, 16-bit C, no dropout), fast / general
+  const kern_t fns[10] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, true>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2, true>};
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2, true>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, false, true>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[8] = {false, false, false, false, false, false, false, false};
+    static bool opted[10] = {false, false, false, false, false, false, false, false, false, false};
     if (!opted[variant]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
@@ -1130,6 +1139,8 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
   MST_CHECK_ARG(a.dropout_p == 0.f || a.N % 4 == 0, "mst_gemm_nt: dropout needs N to be a multiple of 4");
   MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.C % 16 == 0),
                 "mst_gemm_nt: operands must be 16-byte aligned");
+  MST_CHECK_ARG(!a.a_u8 || (!a.c_f32 && a.dropout_p == 0.f && !a.self_resid),
+                "mst_gemm_nt: a uint8 A operand comes with a 16-bit C and without dropout / self_resid");
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;

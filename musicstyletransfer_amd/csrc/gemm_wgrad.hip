@@ -10,6 +10,7 @@
 // workgroups (≫256 of them) and partial tiles are accumulated with fp32 atomics into the flat
 // gradient bucket, which the step zeroes once. Several layers' problems go into ONE launch
 // (mst_wgrad_batch) so the split factor, and with it the atomic traffic, stays small.
+#include <type_traits>
 #include "common.hpp"
 #include "partial_sums.hpp"
 
@@ -41,8 +42,12 @@ __device__ __forceinline__ i16x4 tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
 }
 
-template <typename T, int BN, int BKO, int WGN, int WGK>
-__global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
+// AU8: this problem's A operand is uint8 (mst_wgrad_args.a_u8). A template switch on purpose: the 256x256 form sits at
+// exactly 256 VGPRs, and a run-time branch in the stage loop (an extra register array, or partial-register updates)
+// cost EVERY problem of the launch (92 -> 160 us for the step's batch); as two bodies in one kernel the 16-bit problems
+// keep their code and the two embedding-table problems take the other copy.
+template <typename T, int BN, int BKO, int WGN, int WGK, bool AU8>
+__device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* smem, int pi, int64_t item) {
   constexpr int NT = WGN * WGK * 64;
   constexpr int WTN = BN / WGN, WTK = BKO / WGK;
   constexpr int TN = WTN / 16, TK = WTK / 16;
@@ -54,25 +59,10 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 
   constexpr int LDA_S = BN + LDS_PAD, LDB_S = BKO + LDS_PAD;  // LDS row strides in elements
   constexpr int A_RSTEP = NT / A_CPR, B_RSTEP = NT / B_CPR;   // row distance between a thread's consecutive chunks
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* sA = reinterpret_cast<T*>(smem);          // [2][BMR][LDA_S]
   T* sB = sA + 2 * BMR * LDA_S;                // [2][BMR][LDB_S]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WGK, wk = wave % WGK;
-
-  // locate (problem, slab, tile)
-  // Workgroup ids are dealt round-robin to the 8 XCDs. Work items are numbered problem, then M-slab, then tile, and
-  // every XCD takes a contiguous eighth of them: the tiles of a problem that read the same rows then mostly share
-  // one XCD's L2, and the operands cross the fabric about once (117 MB for the encoder layer's four problems)
-  // instead of once per XCD that owns a tile needing them (312 MB with the tile-major order).
-  const int64_t n_items = b.item_prefix[b.n];
-  const int64_t per_xcd = (n_items + 7) / 8;
-  const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (item >= n_items) return;
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < WG_MAXP; ++i)
-    if (i < b.n && item >= b.item_prefix[i]) pi = i;
   const mst_wgrad_args& a = b.p[pi];
   const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
   const int64_t in_p = item - b.item_prefix[pi];
@@ -86,7 +76,9 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const int64_t m_end = (m_begin + m_chunk < a.M) ? m_begin + m_chunk : a.M;
   if (m_begin >= m_end) return;  // uniform for the whole workgroup
 
-  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  typedef typename std::conditional<AU8, uint8_t, T>::type TA;  // element of A as it sits in HBM
+  typedef typename std::conditional<AU8, u32x2, u32x4>::type RA;  // one 8-element chunk of A in registers
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(a.A);
   const T* __restrict__ B = reinterpret_cast<const T*>(a.B);
   const bool do_bias = (a.db != nullptr) && (k0 == 0);
 
@@ -100,8 +92,11 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const bool plain = !remap_a && !remap_b && n0 + BN <= a.N && k0 + BKO <= a.K;
   const int a_off = (int)(a_r0 * a.lda) + a_c, b_off = (int)(b_r0 * a.ldb) + b_c;  // per-thread element offsets
 
-  u32x4 ra[A_CH], rb[B_CH];
+  RA ra[A_CH];
+  u32x4 rb[B_CH];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  RA zeroA;
+  if constexpr (AU8) zeroA = u32x2{0u, 0u}; else zeroA = zero4;
 
   // Row remaps (decoder rows 1..T of each sample): the physical row of the thread's first chunk and its offset inside
   // the group are carried from stage to stage, so the per-chunk mapping is an add and a compare. (Recomputing it with
@@ -117,7 +112,7 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
     if (plain && full) {
       // uniform row pointer (scalar registers) + the thread's 32-bit offset
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const u32x4*>(A + (mb + i * A_RSTEP) * a.lda + n0 + a_off);
+      for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const RA*>(A + (mb + i * A_RSTEP) * a.lda + n0 + a_off);
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(B + (mb + i * B_RSTEP) * a.ldb + k0 + b_off);
       return;
@@ -128,7 +123,7 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
       int64_t pm = m;
       if (div_a) pm = remap_row(m, a.a_rows_per_group, a.a_group_stride, a.a_group_offset);
       else if (remap_a) pm = pa0 + i * A_RSTEP + ((oa0 + i * A_RSTEP >= a.a_rows_per_group) ? a.a_group_stride - a.a_rows_per_group : 0);
-      ra[i] = (a_ok && m < m_end) ? *reinterpret_cast<const u32x4*>(A + pm * a.lda + n0 + a_c) : zero4;
+      ra[i] = (a_ok && m < m_end) ? *reinterpret_cast<const RA*>(A + pm * a.lda + n0 + a_c) : zeroA;
     }
     if (remap_a && !div_a) {
       oa0 += BMR; pa0 += BMR;
@@ -151,7 +146,11 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   T* const wB = sB + b_r0 * LDB_S + b_c;
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(wA + buf * BMR * LDA_S + i * A_RSTEP * LDA_S) = ra[i];
+    for (int i = 0; i < A_CH; ++i) {
+      u32x4 v;
+      if constexpr (AU8) v = expand_u8x8<T>(ra[i]); else v = ra[i];
+      *reinterpret_cast<u32x4*>(wA + buf * BMR * LDA_S + i * A_RSTEP * LDA_S) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(wB + buf * BMR * LDB_S + i * B_RSTEP * LDB_S) = rb[i];
   };
@@ -277,6 +276,26 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
         if (n < a.N) atomicAdd(a.db + n, acc_b[j][r] * a.scale);
       }
   }
+}
+
+template <typename T, int BN, int BKO, int WGN, int WGK>
+__global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // locate (problem, slab, tile)
+  // Workgroup ids are dealt round-robin to the 8 XCDs. Work items are numbered problem, then M-slab, then tile, and
+  // every XCD takes a contiguous eighth of them: the tiles of a problem that read the same rows then mostly share
+  // one XCD's L2, and the operands cross the fabric about once (117 MB for the encoder layer's four problems)
+  // instead of once per XCD that owns a tile needing them (312 MB with the tile-major order).
+  const int64_t n_items = b.item_prefix[b.n];
+  const int64_t per_xcd = (n_items + 7) / 8;
+  const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (item >= n_items) return;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < b.n && item >= b.item_prefix[i]) pi = i;
+  if (b.p[pi].a_u8) wgrad_body<T, BN, BKO, WGN, WGK, true>(b, smem, pi, item);  // (uniform for the workgroup)
+  else wgrad_body<T, BN, BKO, WGN, WGK, false>(b, smem, pi, item);
 }
 
 // dW[n, k] += scale * sum over the M-slabs (in slab order) of the tiles wgrad_kernel left in the scratch buffer.

@@ -333,11 +333,12 @@ class StepPlan:
             return torch.zeros(rows, roundup(width, 8), dtype=adt, device=dev)
 
         # ---- inputs: ONE static device blob (so a batch arrives with a single copy) viewed as typed tensors
-        asz = torch.tensor([], dtype=adt).element_size()
         if cfg.kind == "token":
             seg = [("tokens", B * T * 4), ("labels", B * T * 4)]
         else:
-            seg = [("roll", B * T * roundup(cfg.in_dim, 8) * asz), ("labels", B * T * cfg.out_dim)]
+            # piano-roll frames stay uint8 in HBM, exactly as the batcher delivers them (1 byte per pitch; rows padded to 8):
+            # the embedding GEMMs and their weight gradients widen them while staging tiles into LDS (a_u8)
+            seg = [("roll", B * T * roundup(cfg.in_dim, 8)), ("labels", B * T * cfg.out_dim)]
         seg += [("seq_lens", B * 4), ("classes", B * 4)]
         self.in_layout, off = {}, 0
         for name, nbytes in seg:
@@ -452,7 +453,7 @@ class StepPlan:
             self.tokens = inview("tokens", torch.int32, B, T)
             self.labels = inview("labels", torch.int32, B, T)
         else:
-            self.roll = inview("roll", self.adt, B * T, roundup(cfg.in_dim, 8))
+            self.roll = inview("roll", torch.uint8, B * T, roundup(cfg.in_dim, 8))
             self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
         self.seq_lens = inview("seq_lens", torch.int32, B)
         self.classes = inview("classes", torch.int32, B)
@@ -468,7 +469,7 @@ class StepPlan:
             self.tokens.copy_(dev(x, torch.int32).view(B, T))
             self.labels.copy_(dev(labels, torch.int32).view(B, T))
         else:
-            self.roll[:, : cfg.in_dim].copy_(dev(x, self.adt).view(B * T, cfg.in_dim))
+            self.roll[:, : cfg.in_dim].copy_(dev(x, torch.uint8).view(B * T, cfg.in_dim))
             self.labels.copy_(dev(labels, torch.uint8).view(B * T, cfg.out_dim))
         self.seq_lens.copy_(dev(seq_lens, torch.int32))
         self.classes.copy_(dev(classes, torch.int32))
@@ -477,29 +478,33 @@ class StepPlan:
 
     def pack_into(self, blob, x, seq_lens, classes, labels):
         """write one batch into `blob`, a HOST uint8 tensor with the layout of `inbuf` (a persistent page-locked staging
-        buffer of PinnedBatchPipeline, or a fresh one from pack_batch); bytes between the segments are left alone"""
+        buffer of PinnedBatchPipeline, or a fresh one from pack_batch); bytes between the segments are left alone.
+        Plain numpy copies on the calling thread: a torch copy_ of a 2 MB tensor fans out over the intra-op thread pool,
+        whose idle spinning (128 threads on a 16-core share of the GPU box) ran the process into its CPU quota — a stall
+        of ~90 ms every few dozen batches."""
         cfg, B, T = self.cfg, self.B, self.T
         assert blob.dtype == torch.uint8 and not blob.is_cuda and blob.numel() >= self.inbuf.numel()
+        raw = blob.numpy()
 
         def seg(name, dtype, *shape):
             a, n = self.in_layout[name]
-            return blob[a: a + n].view(dtype).view(*shape)
+            return raw[a: a + n].view(dtype).reshape(*shape)
 
-        def as_t(a):
-            return torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a.cpu()
+        def as_np(a):
+            return a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
 
         if cfg.kind == "token":
-            seg("tokens", torch.int32, B, T).copy_(as_t(x).reshape(B, T))
-            seg("labels", torch.int32, B, T).copy_(as_t(labels).reshape(B, T))
+            np.copyto(seg("tokens", np.int32, B, T), as_np(x).reshape(B, T), casting="unsafe")
+            np.copyto(seg("labels", np.int32, B, T), as_np(labels).reshape(B, T), casting="unsafe")
         else:
             ldp = roundup(cfg.in_dim, 8)
-            roll = seg("roll", self.adt, B * T, ldp)
-            roll[:, : cfg.in_dim].copy_(as_t(x).reshape(B * T, cfg.in_dim))
+            roll = seg("roll", np.uint8, B * T, ldp)
+            np.copyto(roll[:, : cfg.in_dim], as_np(x).reshape(B * T, cfg.in_dim), casting="unsafe")
             if ldp != cfg.in_dim:
-                roll[:, cfg.in_dim:].zero_()
-            seg("labels", torch.uint8, B * T, cfg.out_dim).copy_(as_t(labels).reshape(B * T, cfg.out_dim))
-        seg("seq_lens", torch.int32, B).copy_(as_t(seq_lens).reshape(B))
-        seg("classes", torch.int32, B).copy_(as_t(classes).reshape(B))
+                roll[:, cfg.in_dim:] = 0
+            np.copyto(seg("labels", np.uint8, B * T, cfg.out_dim), as_np(labels).reshape(B * T, cfg.out_dim), casting="unsafe")
+        np.copyto(seg("seq_lens", np.int32, B), as_np(seq_lens).reshape(B), casting="unsafe")
+        np.copyto(seg("classes", np.int32, B), as_np(classes).reshape(B), casting="unsafe")
         return blob
 
     def pack_batch(self, x, seq_lens, classes, labels):

@@ -53,7 +53,8 @@ def _gemm_args(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=A
                rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
                dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None):
     g = GemmArgs()
-    g.dtype = dt(A)
+    g.a_u8 = 1 if A.dtype == torch.uint8 else 0  # piano-roll frames: widened to the activation type inside the kernel
+    g.dtype = dt(B if g.a_u8 else A)
     g.c_f32 = 1 if C_out.dtype == torch.float32 else 0
     g.M = A.shape[0] if M is None else M
     g.N = B.shape[0] if N is None else N
@@ -218,7 +219,8 @@ def partial_sums(jobs):
 
 def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=(0, 0, 0), b_remap=(0, 0, 0)):
     w = WgradArgs()
-    w.dtype = dt(A)
+    w.a_u8 = 1 if A.dtype == torch.uint8 else 0
+    w.dtype = dt(B if w.a_u8 else A)
     w.M = A.shape[0] if M is None else M
     w.N = dW.shape[0] if N is None else N
     w.K = dW.shape[1] if K is None else K

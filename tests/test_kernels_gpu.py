@@ -54,6 +54,45 @@ def test_gemm_nt_plain(gpu, M, N, K):
     assert (C[:, N:n4] == 0).all(), "pad columns up to roundup4(N) must be written as zeros"
 
 
+@pytest.mark.parametrize("M,P,N,period,dtype", [(16384, 128, 256, 256, BF), (512, 2048, 128, 128, torch.float16), (300, 40, 64, 50, BF)])
+def test_gemm_nt_and_wgrad_uint8_frames_equal_the_16bit_operand(gpu, M, P, N, period, dtype):
+    """a_u8: piano-roll frames stay uint8 in HBM and are widened while tiles are staged into LDS — the embedding GEMM
+    (row-indexed adds, fast and general epilogue) and the embedding tables' weight gradient must be BIT-identical to the
+    same launches on the frames stored in the activation type"""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    ld8 = o.roundup(P, 8)
+    frames = torch.zeros(M, ld8, dtype=torch.uint8)
+    frames[:, :P] = (torch.rand(M, P, generator=g) < 0.05).to(torch.uint8)
+    frames[0, :P] = torch.arange(P) % 7  # values other than {0,1} are widened exactly too
+    f8 = frames.to(gpu)
+    f16 = frames.to(dtype).to(gpu)
+    table_t = rnd((N, ld8), gpu, 0.1, dtype, seed=6)  # [D, P]: the transposed shadow of the embedding table
+    table_t[:, P:] = 0
+    pos = rnd((period, N), gpu, 1.0, torch.float32, seed=7)
+    cls = rnd((3, N), gpu, 1.0, torch.float32, seed=8)
+    idx = torch.randint(0, 3, (M // period + 1,), generator=g).to(torch.int32).to(gpu)
+    outs = []
+    for A in (f8, f16):
+        C = torch.zeros(M, N, dtype=dtype, device=gpu)
+        o.gemm_nt(A, table_t, C, N=N, K=ld8, alpha=2.0, grpadd=cls, grp_index=idx, rowadd=pos, rowadd_period=period)
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = 2.0 * (frames[:, :P].float() @ table_t[:, :P].float().cpu().t() + cls.cpu()[idx.cpu().long()[torch.arange(M) // period]]) \
+        + pos.cpu()[torch.arange(M) % period]
+    close(outs[0], ref, 2e-2, 2e-2, "embedding GEMM on uint8 frames")
+    dY = rnd((M, N), gpu, 1.0, dtype, seed=9)
+    grads = []
+    for A in (f8, f16):
+        dW = torch.zeros(P, N, dtype=torch.float32, device=gpu)
+        o.gemm_wgrad(A, dY, dW, N=P, K=N, scale=0.5)
+        grads.append(dW)
+    torch.cuda.synchronize()
+    assert torch.allclose(grads[0], grads[1], rtol=0, atol=1e-5 * float(grads[1].abs().max()))  # (fp32 atomics: last bits only)
+    close(grads[0], 0.5 * frames[:, :P].float().t() @ dY.float().cpu(), 1e-3, 1e-3 * math.sqrt(M), "embedding wgrad on uint8 frames")
+
+
 def test_gemm_nt_integer_exact_asymmetric(gpu):
     """small-integer operands: exact in bf16 and fp32, catches any transposed / permuted fragment"""
     o = ops()
