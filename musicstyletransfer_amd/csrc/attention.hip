@@ -173,6 +173,52 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// Output tiles are accumulated "owner row on the lane": the accumulator of a 32-wide block of d holds rows d (registers)
+// x owner rows (lane & 31) — the X-as-B-operand form of the accumulator-as-operand products below — so a lane holds
+// elements d = 32 blk + 8 g + 4 (lane >> 5) + e (g, e = 0..3) of ITS row in registers 4 g + e: four 8-byte row pieces
+// per block instead of sixteen 2-byte stores scattered over 16 rows.
+template <typename T, int DH>
+__device__ __forceinline__ void owner_store(T* __restrict__ row /* this lane's output row; nullptr: nothing to store */,
+                                            const f32x16 (&acc)[(DH + 31) / 32], int lane) {
+  if (!row) return;
+  const int h4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int d = 0; d < (DH + 31) / 32; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (32 * d + 8 * g < DH) {
+        u32x2 o;
+        o[0] = (uint32_t)f32_to_bits<T>(acc[d][4 * g]) | ((uint32_t)f32_to_bits<T>(acc[d][4 * g + 1]) << 16);
+        o[1] = (uint32_t)f32_to_bits<T>(acc[d][4 * g + 2]) | ((uint32_t)f32_to_bits<T>(acc[d][4 * g + 3]) << 16);
+        *reinterpret_cast<u32x2*>(row + 32 * d + 8 * g + h4) = o;
+      }
+}
+
+// delta[k] = sum_q P[k,q] dP[k,q] with dP[k,q] = dO[q].V[k]  =  V[k] . (sum_q P[k,q] dO[q])  =  V[k] . dV[k]
+// (the key-row analogue of flash attention's rowsum(dO o O)): one dot product per key from the finished dV accumulator
+// instead of two MFMAs and sixteen FMAs per 32 x 32 tile of the dV sweep. acc is in owner_store's layout (key on the
+// lane); vf is the key's V row as an MFMA fragment (lane half h' holds d = 16 u + 8 h' + j), so each lane half gets the
+// four elements per 16 it lacks from its partner lane.
+template <typename T, int DH>
+__device__ __forceinline__ float delta_from_dv(const f32x16 (&acc)[(DH + 31) / 32], const typename Act<T>::vec8 (&vf)[DH / 16], int lane) {
+  const bool hi_half = (lane >> 5) != 0;
+  float dsum = 0.f;
+#pragma unroll
+  for (int u = 0; u < DH / 16; ++u) {
+    const u32x4 w = __builtin_bit_cast(u32x4, vf[u]);
+    const uint32_t s0 = hi_half ? w[0] : w[2], s1 = hi_half ? w[1] : w[3];
+    const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
+    const uint32_t e4[4] = {hi_half ? r0 : w[0], hi_half ? r1 : w[1], hi_half ? w[2] : r0, hi_half ? w[3] : r1};
+    const int blk = u / 2, g = 2 * (u % 2);  // registers 4 g .. 4 g + 7 of block blk: d = 16 u + {4 h + e, 8 + 4 h + e}
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint16_t bits = (uint16_t)((e4[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+      dsum = fmaf(acc[blk][4 * g + e], bits_to_f32<T>(bits), dsum);
+    }
+  }
+  return dsum + __shfl_xor(dsum, 32, 64);
+}
+
 struct AttnArgs {
   int64_t B, S, H;
   const void* qkv; int64_t ld_qkv, k_off, q_off, v_off;
@@ -330,15 +376,17 @@ __device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const flo
   for (int s2 = 0; s2 < 2; ++s2) {
     const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
 #pragma unroll
-    for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(pf, vfr[s2][d], o[d]);
+    for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(vfr[s2][d], pf, o[d]);  // O^T += V^T P: rows d, query on the lane
   }
 }
 
-// dQ tile: x = P * (dP*scale - delta*scale), then acc += x^T-product with the staged K rows.
+// dQ tile. With sCk holding ck2 + log2(scale) (so the exponential IS P * scale) and the dP accumulator started at
+// -delta[k] (sNd, one value per accumulator row), dL = P (dP - delta) scale is one multiply per element:
+//   x = exp2(S sk2 + ck2') * (dO.V - delta);  acc^T += K^T-fragment x   (rows d, query on the lane)
 // LIGHT: the owned queries' dO rows are zero (dP = 0): no V fragments, no dP MFMAs.
 template <typename T, int DH, bool EXACT, bool LIGHT = false>
 __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
-                                           const float* sMax, const float* sLogl, const float* sDs, int blk, float scale,
+                                           const float* sMax, const float* sLogl, const float* sNd, int blk, float scale,
                                            const typename Act<T>::vec8 (&qf)[DH / 16], const typename Act<T>::vec8 (&dof)[DH / 16],
                                            f32x16 (&acc)[(DH + 31) / 32], int lane) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
@@ -353,7 +401,13 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int d = 0; d < DB; ++d) ktr[s2][d] = lds_tr_frag<T, DH>(sK, blk * 32, s2, d * 32, lane);
-  f32x16 x = zero16<DH>(), dp = zero16<DH>();
+  f32x16 x = zero16<DH>(), dp;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {  // accumulator rows 4g..4g+3 are 4 consecutive keys: one 16-byte read
+    const f32x4 nd = *reinterpret_cast<const f32x4*>(sNd + blk * 32 + 8 * g4 + 4 * (lane >> 5));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dp[4 * g4 + e] = nd[e];
+  }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     x = Act<T>::mfma32(kfr[s], qf[s], x);
@@ -362,22 +416,68 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
-    const f32x4 ds = *reinterpret_cast<const f32x4*>(sDs + kr);
     const f32x4 c0 = *reinterpret_cast<const f32x4*>((EXACT ? sMadd : sSk) + kr);
     const f32x4 c1 = *reinterpret_cast<const f32x4*>((EXACT ? sMax : sCk) + kr);
     f32x4 c2 = c1;
     if (EXACT) c2 = *reinterpret_cast<const f32x4*>(sLogl + kr);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float pr = EXACT ? exact_prob(x[4 * g4 + e], scale, c0[e], c1[e], c2[e]) : fast_exp2(fmaf(x[4 * g4 + e], c0[e], c1[e]));
-      x[4 * g4 + e] = LIGHT ? pr * (0.f - ds[e]) : pr * fmaf(dp[4 * g4 + e], scale, -ds[e]);
+      const float pr = EXACT ? exact_prob(x[4 * g4 + e], scale, c0[e], c1[e], c2[e]) * scale : fast_exp2(fmaf(x[4 * g4 + e], c0[e], c1[e]));
+      x[4 * g4 + e] = pr * dp[4 * g4 + e];  // (LIGHT: dp is still -delta)
     }
   }
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
     const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
 #pragma unroll
-    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, ktr[s2][d], acc[d]);
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(ktr[s2][d], pf, acc[d]);
+  }
+}
+
+// One 32-query x 32-key tile of the key-owner backward, key on the lane throughout.
+//   PASS 0: dV^T += dO^T-fragment P                     (delta follows from the finished dV: delta_from_dv)
+//   PASS 1: dK^T += Q^T-fragment (P scale (dP - delta)): ck2s = ck2 + log2(scale) makes the exponential P * scale, and the
+//           dP accumulator starts at -delta (the key's own value in every register), so dL is one multiply per element.
+// sQ / sdO are the staged query-side operands (rows >= S are zero, so query rows beyond the sequence contribute nothing
+// and need no guard).
+// LIGHT (PASS 1 only): the tile's dO rows are all zero, so dP = 0 and dL = -P * delta * s — no dO fragments, no dP MFMAs;
+// bit-identical to the full tile on zero dO rows (its accumulator stays at -delta).
+template <typename T, int DH, int PASS, bool EXACT, bool LIGHT = false>
+__device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, float scale, const typename Act<T>::vec8 (&kf)[DH / 16],
+                                            const typename Act<T>::vec8 (&vf)[DH / 16], float sk2, float ck2x /* PASS 1: ck2s */, float madd,
+                                            float rmax, float logl, float neg_delta, f32x16 (&acc)[(DH + 31) / 32], int lane) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
+  static_assert(!LIGHT || PASS == 1, "a light tile contributes nothing to pass 0");
+  constexpr bool NEED_DP = PASS == 1 && !LIGHT;
+  typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qfr[s] = lds_row_frag<T, DH>(sQ, qt * 32, s, lane);
+    if (NEED_DP) dofr[s] = lds_row_frag<T, DH>(sdO, qt * 32, s, lane);
+  }
+  const T* tr_src = (PASS == 0) ? sdO : sQ;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) trf[s2][d] = lds_tr_frag<T, DH>(tr_src, qt * 32, s2, d * 32, lane);
+  f32x16 x = zero16<DH>(), dp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dp[r] = neg_delta;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    x = Act<T>::mfma32(qfr[s], kf[s], x);
+    if (NEED_DP) dp = Act<T>::mfma32(dofr[s], vf[s], dp);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (PASS == 0) x[r] = EXACT ? exact_prob(x[r], scale, madd, rmax, logl) : fast_exp2(fmaf(x[r], sk2, ck2x));
+    else x[r] = (EXACT ? exact_prob(x[r], scale, madd, rmax, logl) * scale : fast_exp2(fmaf(x[r], sk2, ck2x))) * dp[r];
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(trf[s2][d], pf, acc[d]);
   }
 }
 
@@ -441,17 +541,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
     }
   }
   T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
-#pragma unroll
-  for (int d = 0; d < DB; ++d) {
-    const int col = d * 32 + (lane & 31);
-    if (col < DH) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t q = q_wave0 + acc_row(r, lane);
-        if (q < S && q < a.q_limit) og[q * a.ld_out + col] = (T)o[d][r];
-      }
-    }
-  }
+  owner_store<T, DH>((q_lane < S && q_lane < a.q_limit) ? og + q_lane * a.ld_out : nullptr, o, lane);
 }
 
 // ------------------------------------------------------------------------------------ bwd_kv
@@ -494,9 +584,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     key_consts(in, vk, rmax, in ? logl : 0.f, a.scale, sk2, ck2);
     exact = __any(in && !vk);  // wave-uniform: one of this wave's 32 keys is padded
   }
+  const float ck2s = ck2 + __log2f(a.scale);  // pass 1: the exponential is P * scale
 
   f32x16 acc[DB];
-  float delta = 0.f, delta_s = 0.f;
+  float neg_delta = 0.f;
+  T* const drow = (k_lane < S) ? reinterpret_cast<T*>(a.dqkv) + (b * S + k_lane) * a.ld_dqkv + hd * DH : nullptr;
   // pass 0: dV and delta; pass 1: dK
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -516,55 +608,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
       for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
         if (q0 + blk * 32 >= S) break;
-        f32x16 x = zero16<DH>(), dp = zero16<DH>();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, blk * 32, s, lane), kf[s], x);
-          dp = Act<T>::mfma32(lds_row_frag<T, DH>(sdO, blk * 32, s, lane), vf[s], dp);
-        }
-        // query rows >= S need no guard: their staged Q and dO rows are zero, so whatever P they get
-        // multiplies zeros in dV, delta and dK
-        if (exact) {  // wave-uniform
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = exact_prob(x[r], a.scale, madd, rmax, logl);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = fast_exp2(fmaf(x[r], sk2, ck2));
-        }
+        // (query rows >= S need no guard: their staged Q and dO rows are zero)
         if (pass == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) delta = fmaf(x[r], dp[r], delta);
+          if (exact) bwd_kv_tile<T, DH, 0, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+          else bwd_kv_tile<T, DH, 0, false>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
         } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] *= fmaf(dp[r], a.scale, -delta_s);
-        }
-        const T* tr_src = (pass == 0) ? sdO : sQ;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
-#pragma unroll
-          for (int d = 0; d < DB; ++d)
-            acc[d] = Act<T>::mfma32(pf, lds_tr_frag<T, DH>(tr_src, blk * 32, s2, d * 32, lane), acc[d]);
+          if (exact) bwd_kv_tile<T, DH, 1, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+          else bwd_kv_tile<T, DH, 1, false>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
         }
       }
     }
     if (pass == 0) {
-      delta += __shfl_xor(delta, 32, 64);
+      const float delta = delta_from_dv<T, DH>(acc, vf, lane);
       if (lane < 32 && k_lane < S) a.delta[bh * S + k_lane] = delta;
-      delta_s = delta * a.scale;
+      neg_delta = -delta;
     }
-    T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + (pass == 0 ? a.v_off : a.k_off);
-#pragma unroll
-    for (int d = 0; d < DB; ++d) {
-      const int col = d * 32 + (lane & 31);
-      if (col < DH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t k = k_wave0 + acc_row(r, lane);
-          if (k < S) dst[k * a.ld_dqkv + col] = (T)acc[d][r];
-        }
-      }
-    }
+    owner_store<T, DH>(drow ? drow + (pass == 0 ? a.v_off : a.k_off) : nullptr, acc, lane);
   }
 }
 
@@ -575,7 +634,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
   __shared__ __attribute__((aligned(16))) T sK[ATT_STAGE * LdsLd<DH>::V];
   __shared__ __attribute__((aligned(16))) T sV[ATT_STAGE * LdsLd<DH>::V];
-  __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sDs[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
+  __shared__ __attribute__((aligned(16))) float sSk[ATT_STAGE], sCk[ATT_STAGE], sNd[ATT_STAGE], sMadd[ATT_STAGE], sMax[ATT_STAGE], sLogl[ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tile; int64_t bh;
   attn_wg_coords(a.B, a.H, tile, bh);
@@ -589,6 +648,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
   const int64_t q_wave0 = (int64_t)tile * ATT_WG_ROWS + wave * 32;
   const int64_t q_lane = q_wave0 + (lane & 31);
+  const float log2_scale = __log2f(a.scale);
   StageRegs<T, DH> rk, rv;
   KeyRegs kr;
   stage_load<T, DH>(rk, Kg, a.ld_qkv, 0, S, tid);
@@ -611,9 +671,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
     stage_store<T, DH>(sV, rv, tid);
     int padded = 0;
     if (tid < ATT_STAGE) {
-      key_consts(kr.in, kr.valid, kr.rmax, kr.logl, a.scale, sSk[tid], sCk[tid]);
+      float sk2, ck2;
+      key_consts(kr.in, kr.valid, kr.rmax, kr.logl, a.scale, sk2, ck2);
+      sSk[tid] = sk2; sCk[tid] = ck2 + log2_scale;  // the exponential is P * scale (bwd_q_tile)
       sMadd[tid] = kr.valid ? 0.f : MASK_VALUE; sMax[tid] = kr.rmax; sLogl[tid] = kr.in ? kr.logl : INFINITY;
-      sDs[tid] = kr.delta * a.scale;
+      sNd[tid] = -kr.delta;
       padded = kr.in && !kr.valid;
     }
     if (k0 + ATT_STAGE < S) {
@@ -625,69 +687,12 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
     for (int blk = 0; blk < ATT_STAGE / 32; ++blk) {
       if (k0 + blk * 32 >= S) break;
-      if (exact) bwd_q_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sDs, blk, a.scale, qf, dof, acc, lane);
-      else bwd_q_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sDs, blk, a.scale, qf, dof, acc, lane);
+      if (exact) bwd_q_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sNd, blk, a.scale, qf, dof, acc, lane);
+      else bwd_q_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, sNd, blk, a.scale, qf, dof, acc, lane);
     }
   }
   T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + a.q_off;
-#pragma unroll
-  for (int d = 0; d < DB; ++d) {
-    const int col = d * 32 + (lane & 31);
-    if (col < DH) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t q = q_wave0 + acc_row(r, lane);
-        if (q < S) dst[q * a.ld_dqkv + col] = (T)acc[d][r];
-      }
-    }
-  }
-}
-
-// One 32-query x 32-key tile of the key-owner backward. PASS 0: dV += P^T dO and delta += sum_q P dP;
-// PASS 1: dK += (P (dP s - delta s))^T Q. sQ / sdO are the staged query-side operands (rows >= S are zero, so query
-// rows beyond the sequence contribute nothing and need no guard).
-// LIGHT (PASS 1 only): the tile's dO rows are all zero, so dP = 0 and dL = -P * delta * s — no dO fragments, no dP MFMAs.
-template <typename T, int DH, int PASS, bool EXACT, bool LIGHT = false>
-__device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, float scale, const typename Act<T>::vec8 (&kf)[DH / 16],
-                                            const typename Act<T>::vec8 (&vf)[DH / 16], float sk2, float ck2, float madd, float rmax,
-                                            float logl, float& delta, float delta_s, f32x16 (&acc)[(DH + 31) / 32], int lane) {
-  constexpr int KS = DH / 16, DB = (DH + 31) / 32;
-  static_assert(!LIGHT || PASS == 1, "a light tile contributes nothing to pass 0");
-  typename Act<T>::vec8 qfr[KS], dofr[KS], trf[2][DB];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    qfr[s] = lds_row_frag<T, DH>(sQ, qt * 32, s, lane);
-    if (!LIGHT) dofr[s] = lds_row_frag<T, DH>(sdO, qt * 32, s, lane);
-  }
-  const T* tr_src = (PASS == 0) ? sdO : sQ;
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int d = 0; d < DB; ++d) trf[s2][d] = lds_tr_frag<T, DH>(tr_src, qt * 32, s2, d * 32, lane);
-  f32x16 x = zero16<DH>(), dp = zero16<DH>();
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    x = Act<T>::mfma32(qfr[s], kf[s], x);
-    if (!LIGHT) dp = Act<T>::mfma32(dofr[s], vf[s], dp);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float pr = EXACT ? exact_prob(x[r], scale, madd, rmax, logl) : fast_exp2(fmaf(x[r], sk2, ck2));
-    if (PASS == 0) {
-      delta = fmaf(pr, dp[r], delta);
-      x[r] = pr;
-    } else if (LIGHT) {
-      x[r] = pr * (0.f - delta_s);  // = pr * fmaf(0, scale, -delta_s): bit-identical to the full tile on zero dO rows
-    } else {
-      x[r] = pr * fmaf(dp[r], scale, -delta_s);
-    }
-  }
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, s2);
-#pragma unroll
-    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(pf, trf[s2][d], acc[d]);
-  }
+  owner_store<T, DH>(q_lane < S ? dst + q_lane * a.ld_dqkv : nullptr, acc, lane);
 }
 
 // ------------------------------------------------------------------------------------ resident kernels
@@ -780,17 +785,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
       for (int kt = 0; kt < NB; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
     }
     T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
-#pragma unroll
-    for (int d = 0; d < DB; ++d) {
-      const int col = d * 32 + (lane & 31);
-      if (col < DH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t q = ob * 32 + acc_row(r, lane);
-          if (q < S && q < a.q_limit) og[q * a.ld_out + col] = (T)o[d][r];
-        }
-      }
-    }
+    const int64_t q_lane = ob * 32 + (lane & 31);
+    owner_store<T, DH>((q_lane < S && q_lane < a.q_limit) ? og + q_lane * a.ld_out : nullptr, o, lane);
   }
 }
 
@@ -803,10 +799,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
   T* bufA = reinterpret_cast<T*>(att_smem);  // phase A: Q   phase B: K
   T* bufB = bufA + SP * LD;                  // phase A: dO  phase B: V
   float* sSk = reinterpret_cast<float*>(bufB + SP * LD);
-  float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sDs = sLogl + SP;
+  float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sNd = sLogl + SP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
   const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
   const int64_t plane = a.B * a.H * S;
+  const float log2_scale = __log2f(a.scale);
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
   const T* Qg = base + a.q_off;
@@ -840,45 +837,36 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
     const float madd = vk ? 0.f : MASK_VALUE;
     float sk2, ck2;
     key_consts(in, vk, rmax, in ? logl : 0.f, a.scale, sk2, ck2);
+    const float ck2s = ck2 + log2_scale;  // pass 1 and phase B: the exponential is P * scale
     const bool exact_w = __any(in && !vk);  // wave-uniform: one of this block's 32 keys is padded
     padded |= (in && !vk);
     f32x16 acc[DB];
-    float delta = 0.f, delta_s = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
+    float neg_delta = 0.f;
+    T* const drow = in ? dbase + k_lane * a.ld_dqkv : nullptr;
+    // four straight-line tile loops (pass x exact) instead of branches inside one: the merged form shuffled the
+    // probability tile through 15 v_mov per tile to reconcile the two passes' register assignments
+    // ---- pass 0: dV, then delta = V . dV
 #pragma unroll
-      for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
-      // four straight-line tile loops (pass x exact) instead of branches inside one: the merged form shuffled the
-      // probability tile through 15 v_mov per tile to reconcile the two passes' register assignments
-      if (pass == 0) {
-        if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-      } else {
-        if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        if (exact_w) for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-        else for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, delta, delta_s, acc, lane);
-      }
-      if (pass == 0) {
-        delta += __shfl_xor(delta, 32, 64);
-        if (lane < 32 && in) a.delta[bh * S + k_lane] = delta;
-        delta_s = delta * a.scale;
-      }
-      T* dst = dbase + (pass == 0 ? a.v_off : a.k_off);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const int col = d * 32 + (lane & 31);
-        if (col < DH) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int64_t k = ob * 32 + acc_row(r, lane);
-            if (k < S) dst[k * a.ld_dqkv + col] = (T)acc[d][r];
-          }
-        }
-      }
+    for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+    if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+    else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+    {
+      const float delta = delta_from_dv<T, DH>(acc, vf, lane);
+      if (lane < 32 && in) a.delta[bh * S + k_lane] = delta;
+      neg_delta = -delta;
     }
+    owner_store<T, DH>(drow ? drow + a.v_off : nullptr, acc, lane);
+    // ---- pass 1: dK
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
+    if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    if (exact_w) for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    else for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    owner_store<T, DH>(drow ? drow + a.k_off : nullptr, acc, lane);
     if (lane < 32) {
-      sSk[k_lane] = sk2; sCk[k_lane] = ck2; sMadd[k_lane] = madd; sMax[k_lane] = rmax; sLogl[k_lane] = logl;
-      sDs[k_lane] = in ? delta_s : 0.f;
+      sSk[k_lane] = sk2; sCk[k_lane] = ck2s; sMadd[k_lane] = madd; sMax[k_lane] = rmax; sLogl[k_lane] = logl;
+      sNd[k_lane] = in ? neg_delta : 0.f;
     }
   }
   __syncthreads();  // every wave is done with the staged Q and dO
@@ -899,25 +887,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
     if (sparse && ob > 0) {  // this block's dO rows are zero
-      if (exact) for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
-      else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+      if (exact) for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else if (exact) {
-      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else {
-      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sDs, kt, a.scale, qf, dof, acc, lane);
+      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     }
-    T* dst = dbase + a.q_off;
-#pragma unroll
-    for (int d = 0; d < DB; ++d) {
-      const int col = d * 32 + (lane & 31);
-      if (col < DH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t q = ob * 32 + acc_row(r, lane);
-          if (q < S) dst[q * a.ld_dqkv + col] = (T)acc[d][r];
-        }
-      }
-    }
+    owner_store<T, DH>(q_lane < S ? dbase + a.q_off + q_lane * a.ld_dqkv : nullptr, acc, lane);
   }
 }
 
