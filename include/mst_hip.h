@@ -113,6 +113,26 @@ typedef struct mst_gemm_args {
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * K12 + K14 in one launch: the decoder's output layer Dense[D -> P] (model.py:253-256) with sigmoid + BinaryCrossEntropy
+ * (loss.py:27-80) in its epilogue, for P = 128 or 256 (a 64-row x P tile holds whole rows of pitches, and — T a multiple
+ * of 64 — rows of one sample). `args` is the output layer's GEMM (A = decoder output with its row remap, B = weight, bias,
+ * alpha); its C receives the LOGIT GRADIENT d(sum_b loss_b)/dlogit * gscale (NULL: forward only). The logits themselves
+ * are not stored (unless `logits` is set); they are rounded to the activation type before the loss arithmetic, so the
+ * result equals mst_gemm_nt followed by mst_sigmoid_bce. loss[b] must be zero on entry (mst_step_begin's zero list).
+ * ------------------------------------------------------------------------ */
+typedef struct mst_bce_args {
+  const uint8_t* labels;      /* {0,1} [M, N] */
+  int64_t T;                  /* rows per sample */
+  float label_smoothing;
+  int32_t downweight;         /* loss.py:50-54,58-81 negative-label down-weighting */
+  float* loss;                /* fp32 [M / T], accumulated */
+  void* probs; int64_t ldp;   /* optional act dtype [M, ldp]: sigmoid output */
+  void* logits; int64_t ldl;  /* optional act dtype [M, ldl] */
+  float gscale;
+} mst_bce_args;
+int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_args* bce, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Dense + LayerNorm in one launch (transformer.py:155,158,197,200 forward; their autograd backward): the GEMM's tile
  * spans the whole output row (N = 128 or 256), so the row statistics are available in its epilogue.
  *   mode 1, forward : C = h = epi(A B^T) as mst_gemm_nt (bias, alpha, dropout / self_resid, resid, C row remap);

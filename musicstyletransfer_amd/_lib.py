@@ -42,6 +42,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class BceArgs(C.Structure):
+    _fields_ = [("labels", vp), ("T", c_i64), ("label_smoothing", c_f32), ("downweight", c_i32), ("loss", vp),
+                ("probs", vp), ("ldp", c_i64), ("logits", vp), ("ldl", c_i64), ("gscale", c_f32)]
+
+
 class LnArgs(C.Structure):
     _fields_ = [
         ("mode", c_i32),
@@ -109,6 +114,7 @@ SIGNATURES = {
     "mst_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(c_f32)]),
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),

@@ -607,6 +607,115 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Output layer + per-pitch BCE in ONE launch (mst_gemm_sigmoid_bce): the decoder's Dense[D -> P] (model.py:253-256) with
+// sigmoid + BinaryCrossEntropy (loss.py:27-80) in its epilogue. The tile spans the whole row of P pitches (64 x 128 or
+// 64 x 256, the LDS-staged (time x pitch) tile), so logits never reach HBM: the epilogue turns the fp32 accumulators into the
+// logit gradient (the backward pass's operand), optionally the probabilities (reconstruction output), and the sample's
+// loss sum — the arithmetic of sigmoid_bce_kernel on the logit rounded to the activation type, which is what the two-launch
+// form reads back. A tile holds rows of ONE sample (the host requires T % 64 == 0): one atomic per workgroup.
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_args q) {
+  constexpr int BM = 64, WGM = 2, WGN = 4, NT = 512;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[NT / 64];
+  f32x4 acc[TN][TM];
+  int64_t m0, n0;
+  gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
+  float* sF = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+  const int64_t b = m0 / q.T;                  // the tile's sample
+  const int64_t per_sample = q.T * (int64_t)BN;
+  float w = 0.f;
+  if (q.downweight) {                          // loss.py:58-81: w_b = n_pos / (n_neg + 1e-12) over the SAMPLE's labels
+    const uint8_t* lab = q.labels + b * per_sample;
+    int cnt = 0;
+    for (int64_t i = (int64_t)tid * 8; i < per_sample; i += (int64_t)NT * 8)
+      cnt += __popcll(*reinterpret_cast<const uint64_t*>(lab + i) & 0x0101010101010101ull);
+    float c = wave_sum((float)cnt);
+    if (lane == 0) red[wave] = c;
+    __syncthreads();
+    float np = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) np += red[i];
+    w = np / (((float)q.T * (float)BN - np) + 1e-12f);
+  }
+  __syncthreads();                              // staged tile visible (and `red` free again)
+  const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
+  const float inv_n = 1.f / ((float)q.T * (float)BN), ls = q.label_smoothing;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = a.bias ? a.bias[nc + e] : 0.f;
+  float lsum = 0.f;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = row0 + it * RSTEP;
+    const int64_t m = m0 + row;
+    if (m >= a.M) continue;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
+    const float t8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const uint64_t lab8 = *reinterpret_cast<const uint64_t*>(q.labels + m * BN + nc);
+    Pack8 pb, gb, xb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xb.h[e] = f32_to_bits<T>((t8[e] + bias8[e]) * a.alpha);  // the logit as the unfused pipeline stores it
+      const float x = bits_to_f32<T>(xb.h[e]);
+      const float y = (float)((lab8 >> (8 * e)) & 0xFFull);
+      const float p = __frcp_rn(1.f + __expf(-x));
+      const float omp = 1.f - p;
+      const float sm = (1.f - ls) * y + 0.5f * ls;
+      const float lp = __logf(1e-12f + p), lq = __logf(1e-12f + omp);
+      float bce = -(sm * lp + (1.f - sm) * lq);
+      float dbce = -(sm * __frcp_rn(1e-12f + p) - (1.f - sm) * __frcp_rn(1e-12f + omp)) * p * omp;
+      if (q.downweight && y == 0.f) {  // loss.py:52-54: (w*bce)*bce where label == 0
+        dbce = 2.f * w * bce * dbce;
+        bce = w * bce * bce;
+      }
+      lsum += bce;
+      pb.h[e] = f32_to_bits<T>(p);
+      gb.h[e] = f32_to_bits<T>(dbce * inv_n * q.gscale);
+    }
+    if (a.C) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + m * a.ldc + nc) = gb.u;
+    if (q.probs) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.probs) + m * q.ldp + nc) = pb.u;
+    if (q.logits) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.logits) + m * q.ldl + nc) = xb.u;
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) tot += red[i];
+    atomicAdd(q.loss + b, tot * inv_n);
+  }
+}
+
+template <typename T, int BN>
+static int launch_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q, hipStream_t s) {
+  const size_t lds_loop = (size_t)2 * (64 + BN) * 64 * 2, lds_epi = (size_t)64 * (BN + 4) * 4;
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  if (lds > 64 * 1024) {
+    static bool opted = false;
+    if (!opted) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bce_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("gemm_bce_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted = true;
+    }
+  }
+  hipLaunchKernelGGL((gemm_bce_kernel<T, BN>), dim3((unsigned)cdiv(a.M, 64)), dim3(512), lds, s, a, q);
+  MST_CHECK_LAUNCH("gemm_bce_kernel");
+  return MST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The whole feed-forward block of a Transformer layer in ONE launch (mst_ffn_ln_fwd):
 //     a  = dropout(relu(x W1^T + b1))                 (transformer.py:38-40 / 152-153)
 //     h2 = epi(a W2^T + b2) with the layer's residual form, y = LayerNorm(h2)      (transformer.py:157-158 / 199-200)
@@ -1118,6 +1227,30 @@ extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, 
     // 8 waves on a 64-row x full-width tile (32-row tiles, two or three workgroups per CU, measured 8-25 % slower)
     if (a.N == 256) return launch_gemm_ln<T, 64, 256, 2, 4>(a, l, s);
     return launch_gemm_ln<T, 64, 128, 2, 4>(a, l, s);
+  });
+}
+
+extern "C" int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_args* bce, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && bce != nullptr, "mst_gemm_sigmoid_bce: null args");
+  const mst_gemm_args& a = *args;
+  const mst_bce_args& q = *bce;
+  MST_CHECK_ARG(a.M > 0 && a.K > 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.A && a.B,
+                "mst_gemm_sigmoid_bce: bad GEMM operands");
+  MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0), "mst_gemm_sigmoid_bce: operands must be 16-byte aligned");
+  MST_CHECK_ARG(a.N == 128 || a.N == 256, "mst_gemm_sigmoid_bce: the row of pitches must be 128 or 256 wide (got %lld): use mst_gemm_nt + "
+                "mst_sigmoid_bce for other widths", (long long)a.N);
+  MST_CHECK_ARG(q.T > 0 && q.T % 64 == 0 && a.M % q.T == 0, "mst_gemm_sigmoid_bce: T must be a multiple of 64 and divide M (a tile holds one sample's rows)");
+  MST_CHECK_ARG(!a.c_f32 && !a.resid && !a.gate && !a.rowadd && !a.grpadd && a.act == MST_ACT_NONE && a.dropout_p == 0.f && !a.self_resid &&
+                a.c_rows_per_group <= 0 && !a.a_u8, "mst_gemm_sigmoid_bce: only bias, alpha and an A row remap are supported");
+  MST_CHECK_ARG(q.labels && q.loss && (uintptr_t)q.labels % 8 == 0, "mst_gemm_sigmoid_bce: labels / loss missing or labels not 8-byte aligned");
+  MST_CHECK_ARG(!a.C || (a.ldc % 8 == 0 && a.ldc >= a.N && (uintptr_t)a.C % 16 == 0), "mst_gemm_sigmoid_bce: bad dlogits layout");
+  MST_CHECK_ARG(!q.probs || (q.ldp % 8 == 0 && q.ldp >= a.N && (uintptr_t)q.probs % 16 == 0), "mst_gemm_sigmoid_bce: bad probs layout");
+  MST_CHECK_ARG(!q.logits || (q.ldl % 8 == 0 && q.ldl >= a.N && (uintptr_t)q.logits % 16 == 0), "mst_gemm_sigmoid_bce: bad logits layout");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    if (a.N == 256) return launch_gemm_bce<T, 256>(a, q, s);
+    return launch_gemm_bce<T, 128>(a, q, s);
   });
 }
 

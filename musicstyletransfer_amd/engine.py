@@ -377,7 +377,9 @@ class StepPlan:
         self.recon = self._recon_buf[:B]
         self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
         self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
-        self.logits = act(B * T, cfg.out_dim)
+        # output layer + BCE in one launch when a tile can hold whole rows of pitches of one sample (configs[1]: P 128, T 256)
+        self.fuse_bce = cfg.kind == "pianoroll" and o.can_fuse_bce(cfg.out_dim, T)
+        self.logits = None if self.fuse_bce else act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
         if cfg.kind == "token":
             self.probs = torch.zeros(B * T, cfg.out_dim, **f32) if want_probs else None
@@ -622,9 +624,11 @@ class StepPlan:
         for i, L in enumerate(self.dec):
             x = self._layer_fwd("decoder", i, L, x, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout, site_d + 3 * i)
         self.dec_out = x
-        # ---- output layer on positions 1..T (model.py:253-256)
-        o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, M=B * T, K=Dd, bias=st.p("decoder.output_layer.bias"),
-                  a_remap=(T, Sd, 1))
+        # ---- output layer on positions 1..T (model.py:253-256); with a whole row of pitches per tile it runs inside the loss
+        # launch (losses(): mst_gemm_sigmoid_bce) and the logits never reach HBM
+        if not self.fuse_bce:
+            o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, M=B * T, K=Dd, bias=st.p("decoder.output_layer.bias"),
+                      a_remap=(T, Sd, 1))
 
     def losses(self, with_grad=True, combine=True):
         """combine=False: the total loss / running metric sums are left to optimizer() (they ride on the Adam launch)"""
@@ -634,6 +638,10 @@ class StepPlan:
             o.softmax_ce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, probs=self.probs, dlogits=dl,
                          gscale=self.gscale, pre_zeroed=True,
                          tok_parts=self.store.tok_parts if self.track_token_metrics else None)
+        elif self.fuse_bce:
+            o.gemm_sigmoid_bce(self.dec_out, self.store.h("decoder.output_layer.weight"), self.labels, self.recon, T, dlogits=dl,
+                               probs=self.probs, label_smoothing=self.ls, downweight=self.nld, gscale=self.gscale, M=B * T,
+                               K=cfg.d_model, bias=self.store.p("decoder.output_layer.bias"), a_remap=(T, T + 1, 1))
         else:
             o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
                           downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale,

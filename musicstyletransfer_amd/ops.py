@@ -84,6 +84,25 @@ def gemm_nt(A, B, C_out, **kw):
     call("mst_gemm_nt", C.byref(_gemm_args(A, B, C_out, **kw)), stream())
 
 
+def can_fuse_bce(P, T):
+    """shapes the output-layer GEMM + BCE launch exists for (mst_gemm_sigmoid_bce)"""
+    return P in (128, 256) and T % 64 == 0
+
+
+def gemm_sigmoid_bce(A, B, labels, loss, T, dlogits=None, probs=None, logits=None, label_smoothing=0.0, downweight=False, gscale=1.0,
+                     **kw):
+    """loss[b] += BCE(sigmoid(A @ B^T + bias), labels) and dlogits = its gradient, in one launch; **kw: M, K, bias, a_remap"""
+    g = _gemm_args(A, B, dlogits if dlogits is not None else A, N=B.shape[0], **kw)
+    if dlogits is None:
+        g.C, g.ldc = None, 0
+    q = _lib.BceArgs()
+    q.labels, q.T, q.label_smoothing, q.downweight, q.loss = ptr(labels), T, label_smoothing, 1 if downweight else 0, ptr(loss)
+    q.probs, q.ldp = ptr(probs), (ld(probs) if probs is not None else 0)
+    q.logits, q.ldl = ptr(logits), (ld(logits) if logits is not None else 0)
+    q.gscale = gscale
+    call("mst_gemm_sigmoid_bce", C.byref(g), C.byref(q), stream())
+
+
 def can_fuse_ln(D):
     """row widths the LayerNorm-fused GEMM exists for (mst_gemm_nt_ln)"""
     return D in (128, 256)

@@ -907,6 +907,47 @@ def test_sigmoid_bce(gpu, B, T, P, ls, dw):
     close(dlog[:, :P], x.grad, 1.6e-2, 1e-2 * gmax * 0.01 + 1e-12, "dlogits")
 
 
+@pytest.mark.parametrize("B,T,P,D,ls,dw,dtype", [(4, 128, 128, 128, 0.0, False, BF), (3, 64, 256, 64, 0.1, True, torch.float16),
+                                                 (64, 256, 128, 128, 0.0, False, BF)])
+def test_gemm_sigmoid_bce_equals_gemm_then_bce(gpu, B, T, P, D, ls, dw, dtype):
+    """mst_gemm_sigmoid_bce (output layer + sigmoid + BCE in one launch, logits never stored) against mst_gemm_nt followed
+    by mst_sigmoid_bce on the same operands, with the decoder's row remap (rows 1..T of T+1): bit-identical logit gradient
+    and probabilities (same MFMA order, logits rounded to the activation type before the loss arithmetic), loss to fp32
+    summation order"""
+    o = ops()
+    Sd = T + 1
+    x = rnd((B * Sd, D), gpu, 1.0, dtype, seed=21)
+    W = rnd((P, D), gpu, 0.2, dtype, seed=22)
+    bias = rnd((P,), gpu, 0.1, torch.float32, seed=23)
+    g = torch.Generator().manual_seed(24)
+    labels = (torch.rand(B * T, P, generator=g) < 0.05).to(torch.uint8).to(gpu)
+    # two launches
+    logits = torch.zeros(B * T, P, dtype=dtype, device=gpu)
+    o.gemm_nt(x, W, logits, M=B * T, K=D, bias=bias, a_remap=(T, Sd, 1))
+    loss2 = torch.zeros(B, dtype=torch.float32, device=gpu)
+    npos = torch.zeros(B, dtype=torch.int32, device=gpu)
+    dl2, pr2 = torch.zeros_like(logits), torch.zeros_like(logits)
+    o.sigmoid_bce(logits, labels, loss2, B, T, P, label_smoothing=ls, downweight=dw, npos=npos, probs=pr2, dlogits=dl2, gscale=4.0)
+    # one launch
+    loss1 = torch.zeros(B, dtype=torch.float32, device=gpu)
+    dl1, pr1, lg1 = torch.zeros_like(logits), torch.zeros_like(logits), torch.zeros_like(logits)
+    o.gemm_sigmoid_bce(x, W, labels, loss1, T, dlogits=dl1, probs=pr1, logits=lg1, label_smoothing=ls, downweight=dw, gscale=4.0,
+                       M=B * T, K=D, bias=bias, a_remap=(T, Sd, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(lg1, logits)
+    assert torch.equal(pr1, pr2)
+    if dw:  # w * bce^2 and its gradient: the two kernels' FMA contraction differs in the last bit of a few elements
+        assert torch.allclose(dl1.float(), dl2.float(), rtol=4e-3, atol=1e-9)
+    else:
+        assert torch.equal(dl1, dl2)
+    assert torch.allclose(loss1, loss2, rtol=2e-5, atol=0)
+    # forward only: no gradient buffer
+    loss3 = torch.zeros(B, dtype=torch.float32, device=gpu)
+    o.gemm_sigmoid_bce(x, W, labels, loss3, T, label_smoothing=ls, downweight=dw, M=B * T, K=D, bias=bias, a_remap=(T, Sd, 1))
+    torch.cuda.synchronize()
+    assert torch.allclose(loss3, loss2, rtol=2e-5, atol=0)
+
+
 def test_bce_logit_zero_known_answer(gpu):
     o = ops()
     B, T, P = 2, 4, 8
