@@ -377,6 +377,17 @@ int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma
                        const float* dz, float kl_weight, float* dmu, float* dsigma, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Incremental decode (inference; model.py:259-272, transformer.py:70-77,242-249): the new position's query against the
+ * K | Q | V rows cached so far. cache: act dtype [B, t_max, ld] with the training layout (k_off / q_off / v_off, head h at
+ * columns h*dh); the new row is row n_keys - 1 and is already cached. out: act dtype [B, ld_out].
+ *   mode 0: the reference's arithmetic — softmax over the QUERY axis, which holds the one new query: P = 1, out = sum of
+ *           the cached value rows;   mode 1: softmax over the cached keys.
+ * ------------------------------------------------------------------------ */
+int mst_attn_decode(int dtype, int64_t B, int64_t H, int64_t dh, int64_t n_keys, int64_t t_max, const void* cache,
+                    int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off, int mode, void* out, int64_t ld_out,
+                    mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * K12/K13: softmax over V + SoftmaxCrossEntropy (model.py:256; loss.py:15-23).
  *   logits : act dtype [M = B*T, ld]; labels int32 [M]
  *   loss[b] = (1/T) * sum_t -log p[b,t,label] * (label != 0)     (fp32 [B], written)

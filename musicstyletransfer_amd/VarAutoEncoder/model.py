@@ -52,6 +52,58 @@ class ModelConfig(Config):
                            te.num_heads, td.model_size, td.num_layers, td.num_heads, te.dropout, td.dropout)
 
 
+class DecoderState:
+    """Inference state (model.py:107-128): the tokens fed so far, the position counter, and the decoder layers' K | Q | V
+    caches, which live in HBM inside `plan` (decode.DecodePlan) and are appended to by every decode step."""
+
+    def __init__(self, batch_size: int, num_cache_layers: int, initial_state, plan=None):
+        from ..MIDIUtil.defaults import SOS_ID
+        self.initial_state = initial_state
+        self.plan = plan
+        self.num_cache_layers = num_cache_layers
+        self.tokens = np.full((batch_size, 1), SOS_ID, np.int64)
+        self.t = 1
+
+    def advance_state(self, tokens):
+        self.tokens = np.concatenate([self.tokens, np.asarray(tokens).reshape(-1, 1)], axis=1)
+        self.t += 1
+
+
+class _Decoder:
+    """the decoder half as the samplers use it (model.py:206-272): parameters by name, get_initial_state, forward_inference"""
+
+    def __init__(self, model):
+        self._model = model
+
+    def collect_params(self):
+        st = self._model.store
+        return {n: st.p(n) for n in st.shapes if n.startswith("decoder.")}
+
+    def get_initial_state(self, tokens, seq_lens, classes, t_max, attention="query", beam=1):
+        """encode the batch, take z = the latent MEANS (sampler.py:146-148: latent_vector = means), build position 0 of the
+        decoder input from it (model.py:229-232) and feed it: returns a DecoderState whose caches hold row 0.
+        beam > 1: every sample is repeated `beam` times (beam search's hypotheses, sampler.py:211-213)."""
+        from .. import decode
+        m = self._model
+        x = np.asarray(tokens.cpu() if torch.is_tensor(tokens) else tokens)
+        B, T = x.shape[0], x.shape[1]
+        plan = m.plan(B, T, want_probs=False, internal_eps=False)
+        cfg = m.engine_config
+        dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
+        plan.load_batch(x, seq_lens, classes, dummy, np.zeros((B, cfg.latent_dim), np.float32))  # eps = 0: z = means
+        plan.forward()
+        row0 = plan.x0_d.view(B, T + 1, -1)[:, 0, :]
+        if beam > 1:
+            row0 = row0.repeat_interleave(beam, dim=0)
+        dplan = decode.DecodePlan(m.store, B * beam, t_max, attention=attention)
+        dplan.start(row0.contiguous())
+        return DecoderState(B * beam, cfg.d_layers, row0, dplan)
+
+    def forward_inference(self, state):
+        """model.py:259-272: the distribution of the next position given the last token of `state` — [B, V] probabilities"""
+        return state.plan.step(state.tokens[:, -1])
+
+
 class _ParamGroup:
     """name -> fp32 parameter view of one half of the model (what collect_params() gives in the reference)"""
 
@@ -73,7 +125,7 @@ class Model:
         self._plans = OrderedDict()
         self._evict_hooks = []
         self.encoder = _ParamGroup(self, "encoder.")
-        self.decoder = _ParamGroup(self, "decoder.")
+        self.decoder = _Decoder(self)
         self.act_dtype = torch.bfloat16
 
     # -- placement / initialisation (model.initialize(mx.init.Xavier(), ctx), trainer.py:103-105)

@@ -177,6 +177,7 @@ class Trainer:
         start_time = time()
         self.train_state = TrainingState()
         self._load_latest_checkpoint(model_folder)
+        self._last_dataset = dataset
         for epoch in range(epochs):
             # the batcher runs one batch ahead: batch i+1 is packed into a page-locked ring slot and uploaded on the
             # pipeline's stream while the captured graph of step i executes (data.py:181-198 -> trainer.py:156-157)

@@ -136,6 +136,7 @@ SIGNATURES = {
                                           vp, vp, vp, c_i64, c_i64, vp]),
     "mst_attn_keysoftmax_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64,
                                           vp, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp]),
+    "mst_attn_decode": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64, C.c_int, vp, c_i64, vp]),
     "mst_layernorm_fwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, c_f32, vp, c_i64, vp, vp, c_i64, vp]),
     "mst_layernorm_bwd": (C.c_int, [C.c_int, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_i64, vp, c_i64,
                                     vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp, vp]),

@@ -980,6 +980,60 @@ static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   return MST_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ incremental decode
+// One new query row per sample against the rows cached so far (inference: model.py:259-272, transformer.py:70-77,242-249).
+// The cache holds the layer's K | Q | V projections of every position fed so far ([B, t_max, ld] with the training layout
+// k_off / q_off / v_off); the new row (position n_keys - 1) is already in it. Per (sample, head):
+//   mode 0, the reference's arithmetic: logits[k, q] = K[k].Q[q] / sqrt(dh) + mask[k], softmax over the QUERY axis — which
+//           holds the single new query, so every P[k, 0] is exp(0) / 1 = 1 and the output is the plain sum of the cached
+//           value rows (computed as such: the logit cancels exactly, a -1e9 mask included)
+//   mode 1, softmax over the cached KEYS (conventional incremental attention), offered beside it.
+// A wave per (sample, head): lanes stride over the keys, each accumulating its keys' value rows, then a cross-lane sum.
+template <typename T, int DH>
+__global__ __launch_bounds__(64) void attn_decode_kernel(int64_t H, int64_t n_keys, int64_t t_max, const T* __restrict__ cache,
+                                                          int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off, int mode,
+                                                          float scale, T* __restrict__ out, int64_t ld_out) {
+  const int64_t b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int lane = threadIdx.x;
+  const T* base = cache + b * t_max * ld + hd * DH;
+  float q[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) q[d] = to_f32(base[(n_keys - 1) * ld + q_off + d]);
+  float m = -INFINITY;
+  if (mode == 1) {
+    for (int64_t k = lane; k < n_keys; k += 64) {
+      float l = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) l = fmaf(to_f32(base[k * ld + k_off + d]), q[d], l);
+      m = fmaxf(m, l * scale);
+    }
+    m = wave_max(m);
+  }
+  float acc[DH], z = 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+  for (int64_t k = lane; k < n_keys; k += 64) {
+    float p = 1.f;
+    if (mode == 1) {
+      float l = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) l = fmaf(to_f32(base[k * ld + k_off + d]), q[d], l);
+      p = __expf(l * scale - m);
+    }
+    z += p;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, to_f32(base[k * ld + v_off + d]), acc[d]);
+  }
+  z = wave_sum(z);
+  const float inv = (mode == 1) ? 1.f / z : 1.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    const float v = wave_sum(acc[d]);
+    if (lane == 0) out[b * ld_out + hd * DH + d] = from_f32<T>(v * inv);
+  }
+}
+
 }  // namespace mst
 
 using namespace mst;
@@ -1026,5 +1080,25 @@ extern "C" int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t 
     if (dh == 16) return launch_bwd<T, 16>(a, s);
     if (dh == 32) return launch_bwd<T, 32>(a, s);
     return launch_bwd<T, 64>(a, s);
+  });
+}
+
+extern "C" int mst_attn_decode(int dtype, int64_t B, int64_t H, int64_t dh, int64_t n_keys, int64_t t_max, const void* cache,
+                               int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off, int mode, void* out, int64_t ld_out,
+                               mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && H > 0 && n_keys > 0 && n_keys <= t_max && cache && out, "mst_attn_decode: bad argument");
+  MST_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "mst_attn_decode: head size must be 16, 32 or 64 (got %lld)", (long long)dh);
+  MST_CHECK_ARG(mode == 0 || mode == 1, "mst_attn_decode: mode must be 0 (softmax over the query axis, the reference) or 1 (over the keys)");
+  MST_CHECK_ARG(ld_out >= H * dh, "mst_attn_decode: ld_out < H*dh");
+  const float scale = 1.f / sqrtf((float)dh);
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    const dim3 grid((unsigned)(B * H));
+    if (dh == 16) hipLaunchKernelGGL((attn_decode_kernel<T, 16>), grid, dim3(64), 0, s, H, n_keys, t_max, (const T*)cache, ld, k_off, q_off, v_off, mode, scale, (T*)out, ld_out);
+    else if (dh == 32) hipLaunchKernelGGL((attn_decode_kernel<T, 32>), grid, dim3(64), 0, s, H, n_keys, t_max, (const T*)cache, ld, k_off, q_off, v_off, mode, scale, (T*)out, ld_out);
+    else hipLaunchKernelGGL((attn_decode_kernel<T, 64>), grid, dim3(64), 0, s, H, n_keys, t_max, (const T*)cache, ld, k_off, q_off, v_off, mode, scale, (T*)out, ld_out);
+    MST_CHECK_LAUNCH("attn_decode_kernel");
+    return MST_OK;
   });
 }

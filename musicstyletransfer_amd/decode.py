@@ -1,0 +1,124 @@
+"""Incremental decoding with per-layer K | Q | V caches in HBM (reference model.py:107-128,259-272,
+transformer.py:70-77,242-249, sampler.py:155-257).
+
+The reference's own inference path is inconsistent with its decoder (`forward_inference` signatures do not
+match the samplers, `compute_with_cache` never appends because the decoder's self-attention is built with
+mask_future_timesteps=False, `mx.nd.concat([..], axis=1)` is a wrong call), so this is the evident intent, restated once in
+oracle/vae_oracle.py::decode_incremental and implemented here on the same kernels as the training step:
+
+  * position 0 is the initial state row, sqrt(D) * (latent2hid(z) + class2hid(c)) + pos[0] (model.py:229-232,
+    transformer.py:237) — exactly what mst_latent_fwd writes as decoder row 0 in training;
+  * position t >= 1 embeds the previous token (or frame) with pos[t] (transformer.py:246) and runs the layers on that ONE row
+    per sample; each layer's K | Q | V projection of the row is written straight into its cache at row t by the projection
+    GEMM's output row remap (no concat, no copy), and the new query attends to rows 0..t (mst_attn_decode);
+  * attention arithmetic is the reference's: the softmax runs over the QUERY axis (transformer.py:100), which in a decode
+    step holds the single new query — every weight is 1 and the head output is the sum of the cached value rows
+    (mode 'query'); the conventional softmax over the cached keys is offered as mode 'key';
+  * dropout layers are identities outside autograd.record() (inference).
+Everything is one row per sample: the GEMMs are launch-bound M = B problems of the same mst_gemm_nt used in training."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops as o
+from .engine import positional_table, roundup
+
+
+class DecodePlan:
+    """Buffers and the kernel sequence of incremental decoding for B hypotheses and up to t_max positions."""
+
+    MODES = {"query": 0, "key": 1}
+
+    def __init__(self, store, B, t_max, attention="query"):
+        cfg = store.cfg
+        self.store, self.cfg, self.B, self.t_max = store, cfg, B, t_max
+        self.mode = self.MODES[attention]
+        dev, adt = store.device, store.act_dtype
+        D = cfg.d_model
+        self.pos = torch.from_numpy(positional_table(D, t_max)).to(dev)
+
+        def act(rows, width):
+            return torch.zeros(rows, roundup(width, 8), dtype=adt, device=dev)
+
+        self.cache = [torch.zeros(B, t_max, 3 * D, dtype=adt, device=dev) for _ in range(cfg.d_layers)]
+        self.x, self.att, self.h1, self.x1, self.h2, self.x2 = (act(B, D) for _ in range(6))
+        self.a = act(B, 4 * D)
+        self.mean, self.rstd = torch.zeros(B, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.float32, device=dev)
+        self.logits = act(B, cfg.out_dim)
+        self.loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.npos = torch.zeros(B, dtype=torch.int32, device=dev)
+        if cfg.kind == "token":
+            self.probs = torch.zeros(B, cfg.out_dim, dtype=torch.float32, device=dev)
+            self.tokens = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+            self.zero_labels = torch.zeros(B, dtype=torch.int32, device=dev)
+        else:
+            self.probs = act(B, cfg.out_dim)
+            self.frames = torch.zeros(B, roundup(cfg.in_dim, 8), dtype=torch.uint8, device=dev)
+            self.zero_labels = torch.zeros(B, cfg.out_dim, dtype=torch.uint8, device=dev)
+        self.t = -1  # position of the last row fed
+
+    # ------------------------------------------------------------------ one position through the decoder layers
+    def _layers(self, x, t):
+        cfg, st, B = self.cfg, self.store, self.B
+        D, H = cfg.d_model, cfg.d_heads
+        for i in range(cfg.d_layers):
+            pre = f"decoder.layer{i}"
+            cache = self.cache[i]
+            # K | Q | V of the new row, written to row t of every sample's cache (C row remap: logical row b -> b * t_max + t)
+            o.gemm_nt(x, st.fused(st.w16, pre, "weight"), cache.view(B * self.t_max, 3 * D), M=B, K=D, bias=st.fused(st.w, pre, "bias"),
+                      c_remap=(1, self.t_max, t))
+            o.attn_decode(cache, t + 1, H, D // H, 0, D, 2 * D, self.att, mode=self.mode)
+            o.gemm_nt(self.att, st.h(f"{pre}.att.W_proj.weight"), self.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"), resid=x)
+            o.layernorm_fwd(self.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), self.x1, self.mean, self.rstd, D=D)
+            o.gemm_nt(self.x1, st.h(f"{pre}.ff1.weight"), self.a, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU)
+            # transformer.py:199-200: LN3(ff + dropout(ff)) — dropout is the identity here, so 2 * ff
+            o.gemm_nt(self.a, st.h(f"{pre}.ff2.weight"), self.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), self_resid=True)
+            o.layernorm_fwd(self.h2, st.p(f"{pre}.ln3.gamma"), st.p(f"{pre}.ln3.beta"), self.x2, self.mean, self.rstd, D=D)
+            x = self.x2 if i == cfg.d_layers - 1 else self._keep(self.x2)
+        return x
+
+    def _keep(self, x2):
+        """the next layer's input must survive that layer's own writes to x2"""
+        self.x.copy_(x2)
+        return self.x
+
+    # ------------------------------------------------------------------ API
+    def start(self, row0):
+        """position 0: the initial state rows [B, >= D] (16-bit), ALREADY scaled and positioned as the training step's
+        decoder row 0 (engine.StepPlan.x0_d[:, 0]); fills row 0 of every layer's cache"""
+        self.x.copy_(row0[:, : self.x.shape[1]])
+        self._layers(self.x, 0)
+        self.t = 0
+
+    def step(self, prev):
+        """position t = previous + 1: `prev` is the token fed at this position ([B] ids, token ends) or the frame ([B, P]
+        {0,1}); returns the output distribution of this position, [B, V] fp32 probabilities (token ends) or [B, P] 16-bit
+        per-pitch probabilities (piano-roll ends)"""
+        cfg, st, B = self.cfg, self.store, self.B
+        t = self.t + 1
+        if t >= self.t_max:
+            raise RuntimeError(f"decode buffers hold {self.t_max} positions")
+        D = cfg.d_model
+        sq = math.sqrt(float(D))
+        if cfg.kind == "token":
+            self.tokens.copy_(torch.as_tensor(np.asarray(prev.cpu() if torch.is_tensor(prev) else prev)).to(torch.int32).view(B, 1))
+            o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos[t:], self.x.view(B, 1, -1), 0, sq)
+        else:
+            self.frames[:, : cfg.in_dim].copy_(torch.as_tensor(np.asarray(prev.cpu() if torch.is_tensor(prev) else prev)).to(torch.uint8))
+            o.gemm_nt(self.frames, st.t("decoder.embedding.weight"), self.x, N=D, alpha=sq, rowadd=self.pos[t:], rowadd_period=1)
+        x = self._layers(self.x, t)
+        o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, K=D, bias=st.p("decoder.output_layer.bias"))
+        if cfg.kind == "token":
+            o.softmax_ce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, probs=self.probs)
+        else:
+            o.sigmoid_bce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, npos=self.npos, probs=self.probs)
+        self.t = t
+        return self.probs[:, : cfg.out_dim]
+
+    def reorder(self, index):
+        """beam search: hypothesis j continues hypothesis index[j] — gather the caches' rows (sampler.py:236-238)"""
+        idx = torch.as_tensor(np.asarray(index), dtype=torch.int64, device=self.store.device)
+        n = self.t + 1
+        for i, c in enumerate(self.cache):
+            c[:, :n] = c[:, :n].index_select(0, idx)

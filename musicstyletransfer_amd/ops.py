@@ -293,6 +293,14 @@ def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_
          ptr(lse), ptr(dout), ld(dout), ptr(dqkv), ld(dqkv), ptr(delta), q_limit, stream())
 
 
+def attn_decode(cache3, n_keys, H, dh, k_off, q_off, v_off, out, mode=0):
+    """cache3: [B, t_max, ld] K|Q|V rows fed so far (row n_keys - 1 = the new position); out [B, ld_out]"""
+    B, t_max = cache3.shape[0], cache3.shape[1]
+    assert cache3.stride(2) == 1 and cache3.stride(0) == t_max * cache3.stride(1)
+    call("mst_attn_decode", dt(cache3), B, H, dh, n_keys, t_max, ptr(cache3), cache3.stride(1), k_off, q_off, v_off, mode, ptr(out),
+         ld(out), stream())
+
+
 # --------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5, M=None, row_id_stride=1):
     M = x.shape[0] if M is None else M

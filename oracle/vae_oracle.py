@@ -248,6 +248,53 @@ def model_forward(P, cfg, x, seq_lens, classes, eps, masks=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# incremental decoding (inference)
+# ----------------------------------------------------------------------------------------------
+def decode_incremental(P, cfg, z, classes, fed, attention="query"):
+    """Decoder.forward_inference / TransformerDecoder.forward_inference / compute_with_cache as evidently intended
+    (model.py:259-272, transformer.py:70-77,242-249; the code as committed never appends to its cache and does not match
+    its callers): position 0 = the initial state latent2hid(z) + class2hid(c) (model.py:229-232), position
+    t >= 1 = the embedding of the token (or frame) fed there, each scaled by sqrt(D) and given pos[t] (transformer.py:246);
+    every layer appends the new row's keys and values to its cache (:74) and the ONE new query attends to all cached rows
+    with the layer's own arithmetic (:96-102): logits [B,H,T_K,1], mask, softmax over the LAST axis — the query axis, of
+    size 1, so every probability is 1 — then probs^T V. attention='key' is the conventional alternative (softmax over the
+    cached keys). Dropout is the identity (no autograd.record()).
+    fed: [B, n] token ids or [B, n, P] frames fed at positions 1..n. Returns the n output distributions [B, n, V]."""
+    B = z.shape[0]
+    Dd, H = cfg.d_model, cfg.d_heads
+    dh = Dd // H
+    dt = z.dtype
+    n = fed.shape[1]
+    pos = torch.from_numpy(positional_encodings(Dd, n + 1)).to(dt)
+    sq = torch.sqrt(torch.tensor(float(Dd), dtype=dt))
+    init = dense(z, P["decoder.latent2hid.weight"], P["decoder.latent2hid.bias"]) + P["decoder.class2hid.weight"][classes.long()]
+    caches = [{"k": [], "v": []} for _ in range(cfg.d_layers)]
+    outs = []
+    for t in range(n + 1):
+        x = init if t == 0 else input_embedding(cfg, P["decoder.embedding.weight"], fed[:, t - 1])
+        x = sq * x + pos[t]
+        for i in range(cfg.d_layers):
+            pre = f"decoder.layer{i}"
+            c = caches[i]
+            c["k"].append(dense(x, P[f"{pre}.att.W_k.weight"], P[f"{pre}.att.W_k.bias"]))   # transformer.py:74 (append)
+            c["v"].append(dense(x, P[f"{pre}.att.W_v.weight"], P[f"{pre}.att.W_v.bias"]))
+            K = torch.stack(c["k"], 1).reshape(B, t + 1, H, dh).transpose(1, 2)            # [B,H,T_K,dh]
+            V = torch.stack(c["v"], 1).reshape(B, t + 1, H, dh).transpose(1, 2)
+            Q = dense(x, P[f"{pre}.att.W_q.weight"], P[f"{pre}.att.W_q.bias"]).reshape(B, 1, H, dh).transpose(1, 2)
+            logits = torch.matmul(K, Q.transpose(-1, -2)) / math.sqrt(dh)                  # [B,H,T_K,1]; the mask is all ones (:243)
+            probs = torch.softmax(logits, dim=-1 if attention == "query" else -2)          # :100 softmax over the query axis
+            att = torch.matmul(probs.transpose(-1, -2), V).transpose(1, 2).reshape(B, Dd)
+            a = dense(att, P[f"{pre}.att.W_proj.weight"], P[f"{pre}.att.W_proj.bias"])
+            x1 = layer_norm(x + a, P[f"{pre}.ln1.gamma"], P[f"{pre}.ln1.beta"])
+            f = feed_forward(P, pre, x1, None)
+            x = layer_norm(f + f, P[f"{pre}.ln3.gamma"], P[f"{pre}.ln3.beta"])             # transformer.py:199-200
+        if t >= 1:  # position 0's output is dropped (model.py:253)
+            lg = dense(x, P["decoder.output_layer.weight"], P["decoder.output_layer.bias"])
+            outs.append(torch.softmax(lg, -1) if cfg.kind == "token" else torch.sigmoid(lg))
+    return torch.stack(outs, 1)
+
+
+# ----------------------------------------------------------------------------------------------
 # losses (loss.py)
 # ----------------------------------------------------------------------------------------------
 def variational_kl(means, stds):

@@ -1,0 +1,127 @@
+"""Incremental decoding with K | Q | V caches on a real GPU: the decode step against the oracle's
+restatement of the reference's inference path (oracle.decode_incremental), and the two samplers built on it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(kind, dims, gpu, seed=3):
+    from oracle import vae_oracle as O
+    from musicstyletransfer_amd import engine as E
+    rng = np.random.default_rng(seed)
+    ocfg = O.OracleConfig(kind, *dims)
+    params = O.init_params(ocfg, rng)
+    for k, v in params.items():  # non-trivial biases / LayerNorm parameters
+        if k.endswith("bias") or k.endswith("beta"):
+            params[k] = (0.05 * rng.standard_normal(v.shape)).astype(np.float32)
+        if k.endswith("gamma"):
+            params[k] = (1.0 + 0.1 * rng.standard_normal(v.shape)).astype(np.float32)
+    store = E.ParamStore(E.VAEConfig(kind, *dims), gpu, torch.bfloat16, params_np=params)
+    return O, ocfg, params, store, rng
+
+
+@pytest.mark.parametrize("kind,dims", [("token", (40, 40, 2, 16, 64, 1, 2, 64, 2, 4)), ("pianoroll", (48, 48, 2, 16, 64, 1, 2, 32, 1, 2))])
+@pytest.mark.parametrize("attention", ["query", "key"])
+def test_decode_step_matches_the_oracle(gpu, kind, dims, attention):
+    """teacher-forced: the same tokens / frames are fed to the GPU decode step and to oracle.decode_incremental, position by
+    position; the cached K | Q | V rows make step t cost one row per sample whatever t is"""
+    from musicstyletransfer_amd import decode
+    O, ocfg, params, store, rng = _model(kind, dims, gpu)
+    B, n, Z, Dd = 5, 9, dims[3], dims[7]
+    z = rng.standard_normal((B, Z)).astype(np.float32)
+    classes = rng.integers(0, 2, size=B)
+    fed = rng.integers(1, dims[0], size=(B, n)) if kind == "token" else (rng.random((B, n, dims[0])) < 0.1).astype(np.uint8)
+    P = O.to_torch_params(store.as_consumed_numpy(), requires_grad=False)
+    want = O.decode_incremental(P, ocfg, torch.from_numpy(z), torch.from_numpy(classes), torch.from_numpy(fed), attention).numpy()
+    # position 0 exactly as the training step builds decoder row 0
+    pos = O.positional_encodings(Dd, 1)[0].astype(np.float32)
+    init = z @ params["decoder.latent2hid.weight"].T + params["decoder.latent2hid.bias"] + params["decoder.class2hid.weight"][classes]
+    row0 = torch.from_numpy((np.sqrt(Dd) * init + pos).astype(np.float32)).to(torch.bfloat16).to(gpu)
+    plan = decode.DecodePlan(store, B, n + 1, attention=attention)
+    plan.start(row0)
+    got = []
+    for t in range(n):
+        got.append(plan.step(fed[:, t]).float().cpu().numpy())
+    got = np.stack(got, 1)
+    err = np.abs(got - want)
+    assert err.mean() <= 3e-3 and err.max() <= 6e-2, (err.mean(), err.max())
+    if kind == "token":
+        np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-3)
+    assert plan.t == n
+
+
+def test_query_axis_softmax_of_one_query_sums_the_cached_values(gpu):
+    """the reference's arithmetic on a decode step (transformer.py:96-102 with T_Q = 1): every weight is exactly 1"""
+    o = __import__("musicstyletransfer_amd.ops", fromlist=["ops"])
+    B, H, dh, n, t_max = 3, 2, 16, 7, 10
+    D = H * dh
+    g = torch.Generator().manual_seed(1)
+    cache = torch.randn(B, t_max, 3 * D, generator=g).to(torch.bfloat16).to(gpu)
+    out = torch.zeros(B, D, dtype=torch.bfloat16, device=gpu)
+    o.attn_decode(cache, n, H, dh, 0, D, 2 * D, out, mode=0)
+    torch.cuda.synchronize()
+    want = cache[:, :n, 2 * D:].float().sum(1)
+    assert torch.allclose(out.float(), want, rtol=1e-2, atol=1e-2)
+    o.attn_decode(cache, n, H, dh, 0, D, 2 * D, out, mode=1)
+    torch.cuda.synchronize()
+    K, V = cache[:, :n, :D].float().view(B, n, H, dh), cache[:, :n, 2 * D:].float().view(B, n, H, dh)
+    q = cache[:, n - 1, D:2 * D].float().view(B, H, dh)
+    p = torch.softmax(torch.einsum("bkhd,bhd->bhk", K, q) / np.sqrt(dh), -1)
+    want = torch.einsum("bhk,bkhd->bhd", p, V).reshape(B, D)
+    assert torch.allclose(out.float(), want, rtol=1e-2, atol=1e-2)
+
+
+def test_samplers_on_the_toy_model(gpu, tmp_path):
+    """Sampling and BeamSearchSampler through the reference's interface: get_sampler -> update_parameters -> process_batch
+    writes .mid files; beam search with one beam is greedy decoding, wider beams never score worse"""
+    from music_style_transfer.VarAutoEncoder import main, sampler as S
+    from music_style_transfer.VarAutoEncoder.data import ToyData
+    from music_style_transfer.MIDIUtil.defaults import EOS_ID, PAD_ID
+
+    class A:
+        verbose, beam_size = False, 3
+
+    t = main.main(["--toy", "--gpu", "--max-steps", "300", "--model-output", str(tmp_path)])
+    t.stream.synchronize()
+    batch = next(iter(ToyData()))
+    smp = S.get_sampler("sampling", None, None, None, A)
+    smp.update_parameters(t.model)
+    seqs = smp.sample(batch)
+    assert seqs.shape[0] == 3 and seqs.shape[1] >= 2 and (seqs[:, 0] == 1).all() and np.isfinite(smp.scores).all()
+    assert ((seqs >= 0) & (seqs < 10)).all()
+    # greedy reference through the same decode step
+    dec = t.model.decoder
+    st = dec.get_initial_state(*batch.data, t_max=12)
+    greedy = []
+    for _ in range(6):
+        p = dec.forward_inference(st).float().cpu().numpy()
+        nxt = p.argmax(-1)
+        greedy.append(nxt)
+        st.advance_state(nxt)
+    greedy = np.stack(greedy, 1)
+    b1 = S.BeamSearchSampler(beam_size=1)
+    b1.update_parameters(t.model)
+    one = b1.sample(batch)
+    for b in range(3):  # identical until the hypothesis ends
+        n_cmp = 0
+        for i in range(min(6, one.shape[1] - 1)):
+            if one[b, i + 1] in (EOS_ID, PAD_ID):
+                break
+            assert one[b, i + 1] == greedy[b, i]
+            n_cmp += 1
+    b3 = S.get_sampler("beam-search", None, None, None, A)
+    b3.update_parameters(t.model)
+    b3.sample(batch)
+    assert b3.hypotheses.shape[:2] == (3, 3)
+    assert (np.diff(b3.scores, axis=1) >= -1e-9).all()               # hypotheses come out best first
+    assert (b3.scores[:, 0] <= b1.scores[:, 0] + 1e-6).all()           # a wider beam never does worse than greedy
+    files = smp.process_batch(batch, str(tmp_path / "samples"), 3)
+    assert len(files) == 3 + 3 * 3 and all(os.path.getsize(f) > 0 for f in files)
+    with pytest.raises(ValueError):
+        S.get_sampler("nucleus", None, None, None, A)

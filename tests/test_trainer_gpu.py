@@ -174,24 +174,35 @@ def test_checkpoint_and_resume(gpu, tmp_path):
     assert steps == 21, f"Adam step counter {steps}: optimizer state was not restored"
 
 
-def test_reconstruction_sampler_writes_midi(gpu, tmp_path):
-    """the trainer's sampler hook writes the batch's reconstruction as .mid files (both ends)"""
-    from music_style_transfer.VarAutoEncoder import main
+def test_sampler_hook_writes_midi(gpu, tmp_path):
+    """trainer.py:149-153: every sampling_frequency steps the sampler writes .mid files — the reference's 'sampling' type
+    (originals + one ancestral sample per class) through main.py's wiring, and the reconstruction writer of SURVEY §8f
+    rank 3 when it is the trainer's sampler (both kinds of ends)"""
+    from music_style_transfer.VarAutoEncoder import main, sampler as S
     from music_style_transfer.MIDIUtil.midi_io import EventBasedMIDIReader
+    flags = [f for f in SCRIPT_FLAGS]
+    flags[flags.index("--sampling-frequency") + 1] = "3"
+    flags[flags.index("--latent-dim") + 1] = "64"
+    flags[flags.index("--max-seq-len") + 1] = "16"  # (sampling runs 2 x the batch length decode steps)
+    out = tmp_path / "token"
+    t = main.main(flags + ["--data", MIDI, "--model-output", str(out / "m"), "--out-samples", str(out / "s"), "--max-steps", "4"])
+    found = []
+    for root, _, files in os.walk(str(out)):
+        found += [os.path.join(root, f) for f in files if f.endswith(".mid")]
+    assert any(".class-0.mid" in f for f in found) and any(".class-1.mid" in f for f in found) and any(".original.mid" in f for f in found), found
+    assert isinstance(EventBasedMIDIReader().read_file([f for f in found if ".original." in f][0]), list)
     for extra, kind in ((["--pianoroll"], "pianoroll"), ([], "token")):
-        flags = [f for f in SCRIPT_FLAGS]
-        flags[flags.index("--sampling-frequency") + 1] = "3"
-        flags[flags.index("--latent-dim") + 1] = "64"
-        out = tmp_path / kind
-        t = main.main(flags + extra + ["--data", MIDI, "--model-output", str(out / "m"), "--out-samples", str(out / "s"),
-                                       "--max-steps", "4"])
+        out = tmp_path / ("rec_" + kind)
+        flags2 = [f for f in flags]
+        flags2[flags2.index("--sampling-frequency") + 1] = "0"
+        t = main.main(flags2 + extra + ["--data", MIDI, "--model-output", str(out / "m"), "--out-samples", str(out / "s"), "--max-steps", "2"])
         assert t.model.engine_config.kind == kind
-        found = []
-        for root, _, files in os.walk(str(out)):
-            found += [os.path.join(root, f) for f in files if f.startswith("reconstruction_") and f.endswith(".mid")]
-        assert found, "the sampler hook wrote no reconstruction"
-        melodies = EventBasedMIDIReader().read_file(found[0])  # parses as a standard MIDI file
-        assert isinstance(melodies, list)
+        rec = S.get_sampler("reconstruction", None, None, None, None)
+        rec.update_parameters(t.model)
+        with torch.cuda.stream(t.stream):
+            files = rec.process_batch(next(iter(t._last_dataset)), str(out / "rec"), 2)
+        assert files and all(os.path.getsize(f) > 0 for f in files)
+        assert isinstance(EventBasedMIDIReader().read_file(files[0]), list)
 
 
 def test_device_token_metrics_equal_the_host_metric_classes(gpu, tmp_path):
