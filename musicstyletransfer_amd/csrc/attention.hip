@@ -715,6 +715,32 @@ __device__ __forceinline__ void stage_all(T* lds, const T* __restrict__ g, int64
   }
 }
 
+// Two tensors at once: every global load of both is issued before the first LDS store (stage_all twice is two exposed
+// round trips: the second tensor's loads wait behind the first one's stores)
+template <typename T, int DH>
+__device__ __forceinline__ void stage_pair(T* ldsA, const T* __restrict__ gA, int64_t ldA, int64_t rowsA, T* ldsB,
+                                           const T* __restrict__ gB, int64_t ldB, int64_t rowsB, int SP, int tid, int nthr) {
+  constexpr int CPR = DH / 8, BATCH = 4;
+  for (int c0 = tid; c0 < SP * CPR; c0 += nthr * BATCH) {
+    u32x4 va[BATCH], vb[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int c = c0 + i * nthr, row = c / CPR, ch = c % CPR;
+      va[i] = u32x4{0u, 0u, 0u, 0u}; vb[i] = va[i];
+      if (c < SP * CPR && row < rowsA) va[i] = *reinterpret_cast<const u32x4*>(gA + (int64_t)row * ldA + ch * 8);
+      if (c < SP * CPR && row < rowsB) vb[i] = *reinterpret_cast<const u32x4*>(gB + (int64_t)row * ldB + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int c = c0 + i * nthr, row = c / CPR, ch = c % CPR;
+      if (c < SP * CPR) {
+        *reinterpret_cast<u32x4*>(ldsA + row * LdsLd<DH>::V + ch * 8) = va[i];
+        *reinterpret_cast<u32x4*>(ldsB + row * LdsLd<DH>::V + ch * 8) = vb[i];
+      }
+    }
+  }
+}
+
 // (batch*head) of a 1-D grid; batch elements are dealt to the XCDs so that the heads of one element share an L2
 __device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
   const int64_t lin = blockIdx.x;
@@ -815,8 +841,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
   // tile of dK / dQ is the LIGHT form. Same arithmetic as the dense path on the zero rows, about 45 % of its work.
   constexpr bool sparse = SPARSE;  // host: 0 < q_limit <= 32 (a separate instantiation keeps the dense kernel's registers)
   const int64_t do_rows = sparse ? a.q_limit : S;  // rows of dO that are read; the staged tile is zero beyond them
-  stage_all<T, DH>(bufA, Qg, a.ld_qkv, S, SP, tid, nthr);
-  stage_all<T, DH>(bufB, dOg, a.ld_dout, do_rows, SP, tid, nthr);
+  // the first owned key block's K / V fragments are requested before the staging loads: one exposed round trip, not two
+  typename Act<T>::vec8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, wave * 32 + (lane & 31), S, s, lane);
+    vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, wave * 32 + (lane & 31), S, s, lane);
+  }
+  stage_pair<T, DH>(bufA, Qg, a.ld_qkv, S, bufB, dOg, a.ld_dout, do_rows, SP, tid, nthr);
   __syncthreads();
   const int nq0 = sparse ? 1 : NB;  // query tiles that contribute to pass 0
 
@@ -824,11 +856,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
   int padded = 0;
   for (int ob = wave; ob < NB; ob += NW) {
     const int64_t k_lane = ob * 32 + (lane & 31);
-    typename Act<T>::vec8 kf[KS], vf[KS];
+    if (ob != wave) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
-      vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
+      for (int s = 0; s < KS; ++s) {
+        kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, k_lane, S, s, lane);
+        vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, k_lane, S, s, lane);
+      }
     }
     const bool in = k_lane < S;
     const bool vk = in && a.keymask[b * S + k_lane];
@@ -869,19 +902,26 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
       sNd[k_lane] = in ? neg_delta : 0.f;
     }
   }
+  // phase B's first Q / dO fragments: requested before the barrier and the K / V staging
+  typename Act<T>::vec8 qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, wave * 32 + (lane & 31), S, s, lane);
+    dof[s] = glb_row_frag<T>(dOg, a.ld_dout, wave * 32 + (lane & 31), do_rows, s, lane);
+  }
   __syncthreads();  // every wave is done with the staged Q and dO
-  stage_all<T, DH>(bufA, Kg, a.ld_qkv, S, SP, tid, nthr);
-  stage_all<T, DH>(bufB, Vg, a.ld_qkv, S, SP, tid, nthr);
+  stage_pair<T, DH>(bufA, Kg, a.ld_qkv, S, bufB, Vg, a.ld_qkv, S, SP, tid, nthr);
   const bool exact = __syncthreads_or(padded);
 
   // ---- phase B: dQ for the owned queries (attn_bwd_q_kernel's tiles)
   for (int ob = wave; ob < NB; ob += NW) {
     const int64_t q_lane = ob * 32 + (lane & 31);
-    typename Act<T>::vec8 qf[KS], dof[KS];
+    if (ob != wave) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
-      dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, do_rows, s, lane);
+      for (int s = 0; s < KS; ++s) {
+        qf[s] = glb_row_frag<T>(Qg, a.ld_qkv, q_lane, S, s, lane);
+        dof[s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, do_rows, s, lane);
+      }
     }
     f32x16 acc[DB];
 #pragma unroll

@@ -734,7 +734,12 @@ static int launch_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q, hipStr
 // reads of `a`), which is also the pass that stores the chunk for the weight-gradient launch.
 // LEAD (backward only): the block's input tile is not loaded but COMPUTED — the layer's leading LayerNorm backward on the
 // workgroup's 64 rows (mst_ffn_ln_bwd_lead), one launch and one 8 + 8 MB round trip less.
-template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD>
+// FULL: M is a multiple of 64 (no row guards). The guards, like every other conditional load in the stage loop, are not
+// free: hipcc cannot count outstanding loads across a branch and falls back to s_waitcnt vmcnt(0), which drains the
+// weight ring — the launch is bound by a single workgroup's serial latency (35 us for ONE workgroup, 42 for 256), so
+// every such drain is a full L2 round trip on the critical path. Hence also: bias of the first GEMM read from LDS
+// (it was a global load + vmcnt(0) inside the chunk epilogue), prefetches issued unconditionally (clamped).
+template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD, bool FULL>
 __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln, mst_ln_bwd_in lead) {
   constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
@@ -750,11 +755,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   u32x4* sB = reinterpret_cast<u32x4*>(smem);
   T* sH = reinterpret_cast<T*>(smem + (size_t)2 * BN * BK * 2);
   T* sX = sH + BM * LDA;
+  float* sBias1 = reinterpret_cast<float*>(sX + BM * LDA);  // [F] the first GEMM's bias (zeros without one)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t F = g1.N;
+  const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
+  for (int i = tid * 4; i < (int)F; i += NT * 4)
+    *reinterpret_cast<f32x4*>(sBias1 + i) = g1.bias ? *reinterpret_cast<const f32x4*>(g1.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
   const int n_chunks = (int)(F / BN);
+  // Chunk order rotated per workgroup: every workgroup streams BOTH weight matrices in full, and 256 of them walking the
+  // same lines in lockstep hit the same L2 channels at the same time. Workgroup i of an XCD starts at hidden chunk
+  // i mod n_chunks; the second GEMM's sum over the chunks then runs in rotated order (fp32, a different rounding order
+  // than the three-launch form; `a` itself is unchanged).
+#ifndef MST_FFN_ROT
+#define MST_FFN_ROT 1
+#endif
+  const int rot = MST_FFN_ROT ? (int)((blockIdx.x / 8) % (unsigned)n_chunks) : 0;
+  auto phys = [&](int c) { const int pc = c + rot; return pc >= n_chunks ? pc - n_chunks : pc; };
+  // ... and the K stages inside each GEMM of a chunk start at a per-workgroup offset too (KST is a power of two)
+#ifndef MST_FFN_ROTK
+#define MST_FFN_ROTK 0  /* measured: no effect (43.9 vs 43.6 us); off keeps `a` bit-identical to the three-launch form */
+#endif
+  static_assert((KST & (KST - 1)) == 0, "stage rotation masks with KST - 1");
+  const int rotk = MST_FFN_ROTK ? (int)((blockIdx.x / 8 / (unsigned)n_chunks) & (KST - 1)) : 0;
+  auto kstage = [&](int s) { return (s + rotk) & (KST - 1); };  // stage s of a GEMM reads K slice kstage(s)
   const T* __restrict__ W1 = reinterpret_cast<const T*>(g1.B);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(g2.B);
 
@@ -778,11 +803,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   u32x4 ring[RING][B_CH];
   auto load_stage = [&](int c, int s, u32x4 (&rb)[B_CH]) {  // (c, s) uniform
     if (s < KST) {
-      const T* base = W1 + (int64_t)c * BN * g1.ldb + s * BK;
+      const T* base = W1 + (int64_t)phys(c) * BN * g1.ldb + kstage(s) * BK;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off1[i]);
     } else {
-      const T* base = W2 + (int64_t)c * BN + (s - KST) * BK;
+      const T* base = W2 + (int64_t)phys(c) * BN + kstage(s - KST) * BK;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off2[i]);
     }
@@ -817,7 +842,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     for (int it = 0; it < ITERS; ++it) {
       const int64_t m = m0 + row0 + it * RSTEP;
       dyv[it] = u32x4{0u, 0u, 0u, 0u}; xv[it] = dyv[it]; mean_r[it] = 0.f; rstd_r[it] = 0.f;
-      if (m < g1.M) {
+      if (m < Mg) {
         dyv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(lead.dy) + m * lead.ld_dy + nc);
         xv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(lead.x) + m * lead.ld_x + nc);
         mean_r[it] = lead.mean[m];
@@ -856,11 +881,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         ob.h[e] = f32_to_bits<T>(o);
         mb.h[e] = f32_to_bits<T>(o * k);
       }
-      if (m < g1.M) {
+      if (m < Mg) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(lead.dx) + m * lead.ld_dx + nc) = ob.u;
         if (lead.mask_mode == 1) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(lead.dx_masked) + m * lead.ld_dxm + nc) = mb.u;
       }
-      *reinterpret_cast<u32x4*>(sX + row * LDA + nc) = (m < g1.M) ? (lead.mask_mode == 1 ? mb.u : ob.u) : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(sX + row * LDA + nc) = (m < Mg) ? (lead.mask_mode == 1 ? mb.u : ob.u) : u32x4{0u, 0u, 0u, 0u};
     }
     // dgamma / dbeta: the RSTEP row groups summed through LDS (the weight-stage region is not in use yet)
     float* red = reinterpret_cast<float*>(smem);  // [2][RSTEP][BN]
@@ -888,7 +913,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     for (int i = 0; i < BM * CPR / NT; ++i) {
       const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m0 + row < g1.M) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
+      if (m0 + row < Mg) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
       *reinterpret_cast<u32x4*>(sX + row * LDA + ch * 8) = v;
     }
   }
@@ -930,6 +955,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   store_stage(0, ring[0]);
   __syncthreads();  // (also publishes the x tile)
   for (int c = 0; c < n_chunks; ++c) {
+    const int pc = phys(c);  // the hidden chunk this iteration computes
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -943,7 +969,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
       for (int i = 0; i < OUT_CH; ++i) {
         const int cc = tid + i * NT, row = cc / (BN / 8), ch = cc % (BN / 8);
         gv[i] = u32x4{0u, 0u, 0u, 0u};
-        if (m0 + row < g1.M) gv[i] = *reinterpret_cast<const u32x4*>(G + (m0 + row) * g1.ldg + (int64_t)c * BN + ch * 8);
+        if (m0 + row < Mg) gv[i] = *reinterpret_cast<const u32x4*>(G + (m0 + row) * g1.ldg + (int64_t)pc * BN + ch * 8);
       }
     }
     auto stage = [&](auto sc) {
@@ -951,20 +977,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
       if constexpr (s < SPC) {
         {  // request stage s + AHEAD of the stream (it may belong to the next chunk)
           constexpr int t = s + AHEAD;
-          const int tc = t < SPC ? c : c + 1;
-          if (tc < n_chunks) load_stage(tc, t % SPC, ring[t % RING]);
+          // (unconditional: past the last chunk the clamped load fetches a stage nobody stores)
+          const int tc = t < SPC ? c : (c + 1 < n_chunks ? c + 1 : c);
+          load_stage(tc, t % SPC, ring[t % RING]);
         }
-        if constexpr (s < KST) mma_stage(acc1, sX, s * BK, s & 1);
-        else mma_stage(acc2, sH, (s - KST) * BK, s & 1);
+#ifndef MST_FFN_EARLY_STORE
+#define MST_FFN_EARLY_STORE 0  /* measured 43.9 vs 42.6 us at width 256: slower, kept as a switch */
+#endif
+        if (MST_FFN_EARLY_STORE) {
+          // Experiment (off): the next stage's weights go to the OTHER LDS buffer ahead of this stage's MFMAs (legal: that
+          // buffer was last read in the previous stage, which ended with a barrier) instead of after them.
+          if (s + 1 < SPC || c + 1 < n_chunks) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (s < KST) mma_stage(acc1, sX, kstage(s) * BK, s & 1);
+        else mma_stage(acc2, sH, kstage(s - KST) * BK, s & 1);
         if constexpr (s == KST - 1) {
           // ---- chunk epilogue of GEMM 1, in registers: bias, ReLU, dropout, rounding (the order of gemm_epilogue) -> sH.
           // (The previous chunk's GEMM-2 stages, which read sH, ended with a barrier.)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int n = wn * WTN + j * 16 + fq * 4;   // column within the chunk
-            const int64_t col = (int64_t)c * BN + n;     // hidden unit
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (g1.bias) b4 = *reinterpret_cast<const f32x4*>(g1.bias + col);
+            const int64_t col = (int64_t)pc * BN + n;    // hidden unit
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias1 + col);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               const int row = wm * WTM + i * 16 + frow;
@@ -984,7 +1019,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
           }
         }
         // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
-        if (s + 1 < SPC || c + 1 < n_chunks) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+        if (!MST_FFN_EARLY_STORE && (s + 1 < SPC || c + 1 < n_chunks)) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
         __syncthreads();
         if constexpr (s == KST - 1) {
           // the finished chunk goes out to `a` (the backward pass needs it) as whole 16-byte pieces of rows, while the
@@ -1003,7 +1038,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
               v = pv.u;
               *reinterpret_cast<u32x4*>(sH + row * LDA + ch * 8) = v;
             }
-            if (m0 + row < g1.M) *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)c * BN + ch * 8) = v;
+            if (m0 + row < Mg) *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)pc * BN + ch * 8) = v;
           }
           if constexpr (MODE == 2) __syncthreads();  // the gated chunk is what the second GEMM reads
         }
@@ -1024,18 +1059,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 template <typename T, int BN>
 static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, const mst_ln_bwd_in* lead, hipStream_t s) {
   constexpr int BM = 64;
-  const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
+  const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2 + (size_t)g1.N * 4, lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  const int mi = lead ? 2 : (ln.mode == 2 ? 1 : 0);
+  const int full = g1.M % BM == 0 ? 1 : 0;
+  const int mi = (lead ? 2 : (ln.mode == 2 ? 1 : 0)) * 2 + full;
   typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args, mst_ln_bwd_in);
-  const kern_t fns[3] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true>};
-  if (lds > 64 * 1024) {
-    static bool opted[3] = {false, false, false};
-    if (!opted[mi]) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
-      opted[mi] = true;
-    }
+  const kern_t fns[6] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true>,
+                         &ffn_ln_kernel<T, BN, 2, 4, 2, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true>,
+                         &ffn_ln_kernel<T, BN, 2, 4, 2, true, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true>};
+  static size_t opted[6] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // LDS each kernel is opted in for
+  if (lds > opted[mi]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+    opted[mi] = lds;
   }
   mst_ln_bwd_in none = {};
   hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln, lead ? *lead : none);

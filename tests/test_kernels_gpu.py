@@ -281,8 +281,9 @@ def test_gemm_ln_backward_equals_gemm_then_layernorm_bwd(gpu, M, N, K, mode, rem
 @pytest.mark.parametrize("M,D,F,p,self_resid", [(16384, 256, 1024, 0.2, False), (16448, 128, 512, 0.2, True), (200, 256, 512, 0.0, False),
                                                   (77, 128, 128, 0.1, False)])
 def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
-    """mst_ffn_ln_fwd == gemm_nt(ff1) + gemm_nt(ff2) + layernorm_fwd: the hidden activation and the pre-norm tensor bit for
-    bit (same MFMA order, same epilogues), the LayerNorm output within an ulp (statistics summed in another order)"""
+    """mst_ffn_ln_fwd == gemm_nt(ff1) + gemm_nt(ff2) + layernorm_fwd: the hidden activation bit for bit (same MFMA order, same
+    epilogue); the pre-norm tensor sums the hidden chunks in a per-workgroup rotated order (fp32), so it agrees to one
+    rounding of the activation type on a small fraction of elements, and the LayerNorm output likewise"""
     o = ops()
     x = rnd((M, D), gpu, seed=400)
     W1, W2 = rnd((F, D), gpu, seed=401, scale=0.06), rnd((D, F), gpu, seed=402, scale=0.03)
@@ -307,11 +308,12 @@ def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
     o.ffn_ln_fwd(x, W1, a1, W2, h1, gam, bet, y1, m1, r1, ff1=ff1, ff2=ff2)
     torch.cuda.synchronize()
     assert torch.equal(a1, a0), "hidden activation"
-    assert torch.equal(h1, h0), "pre-norm tensor"
-    close(m1, m0, 1e-5, 1e-5, "mean")
-    close(r1, r0, 1e-5, 1e-5, "rstd")
-    assert (y1.float() - y0.float()).abs().max().item() <= 2 ** -6  # at most one bf16 ulp at |y| < 4
-    assert ((y1 != y0).float().mean().item()) < 1e-2
+    dh = (h1.float() - h0.float()).abs()
+    assert (dh <= 2 ** -7 * h0.float().abs().clamp(min=1.0)).all() and (h1 != h0).float().mean().item() < 2e-2, "pre-norm tensor"
+    close(m1, m0, 1e-3, 5e-4, "mean")  # (statistics of rows in which an element of the pre-norm tensor rounded the other way)
+    close(r1, r0, 2e-3, 1e-4, "rstd")
+    assert (y1.float() - y0.float()).abs().max().item() <= 2 ** -5  # a bf16 ulp or two at |y| < 4
+    assert ((y1 != y0).float().mean().item()) < 5e-2
 
 
 @pytest.mark.parametrize("M,D,F,mode,with_resid", [(16384, 256, 1024, 1, True), (16448, 128, 512, 2, False), (200, 256, 512, 0, True),
