@@ -377,6 +377,35 @@ int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma
                        const float* dz, float kl_weight, float* dmu, float* dsigma, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * The position-0 tail of the top encoder layer in one launch (the model reads the encoder at position 0 only, model.py:97):
+ *   h1 = resid + dropout(att Wp^T + bp);  x1 = LN1(h1);  a = dropout(relu(x1 W1^T + b1));  h2 = x1 + dropout(a W2^T + b2);
+ *   x2 = LN2(h2)                                            (transformer.py:42-46,154-158 on B rows, B <= 64, D = 128 | 256)
+ * = mst_gemm_nt (+resid) · mst_layernorm_fwd · mst_gemm_nt (ReLU) · mst_gemm_nt (+resid) · mst_layernorm_fwd on those rows,
+ * same rounding points and dropout counters (sites site0, site0+1, site0+2; counter row = row * phys_stride), as D / 16
+ * workgroups that own output-column slices and meet at three grid barriers. Row r of every tensor sits at element offset
+ * r * (its row stride); statistics at index r * stat_stride. `sync`: one zeroed device word (mst_step_begin's zero list).
+ * ------------------------------------------------------------------------ */
+typedef struct mst_row_tail_args {
+  int32_t dtype;
+  int64_t B, D;
+  const void* att; int64_t rs_att;
+  const void* resid; int64_t rs_res;
+  const void* Wp; int64_t ldwp; const float* bp;
+  const float* g1; const float* be1;
+  const void* W1; int64_t ldw1; const float* b1;
+  const void* W2; int64_t ldw2; const float* b2;
+  const float* g2; const float* be2;
+  void* h1; void* x1; void* h2; void* x2; int64_t rs_d;
+  void* a; int64_t rs_a;
+  float* mean1; float* rstd1; float* mean2; float* rstd2; int64_t stat_stride;
+  float eps;
+  float dropout_p; uint64_t dropout_seed; const uint64_t* dropout_seed_ptr; uint32_t site0;
+  int64_t phys_stride;
+  uint32_t* sync;
+} mst_row_tail_args;
+int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Incremental decode (inference; model.py:259-272, transformer.py:70-77,242-249): the new position's query against the
  * K | Q | V rows cached so far. cache: act dtype [B, t_max, ld] with the training layout (k_off / q_off / v_off, head h at
  * columns h*dh); the new row is row n_keys - 1 and is already cached. out: act dtype [B, ld_out].

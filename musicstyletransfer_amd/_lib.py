@@ -47,6 +47,19 @@ class BceArgs(C.Structure):
                 ("probs", vp), ("ldp", c_i64), ("logits", vp), ("ldl", c_i64), ("gscale", c_f32)]
 
 
+class RowTailArgs(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("B", c_i64), ("D", c_i64),
+        ("att", vp), ("rs_att", c_i64), ("resid", vp), ("rs_res", c_i64),
+        ("Wp", vp), ("ldwp", c_i64), ("bp", vp), ("g1", vp), ("be1", vp),
+        ("W1", vp), ("ldw1", c_i64), ("b1", vp), ("W2", vp), ("ldw2", c_i64), ("b2", vp), ("g2", vp), ("be2", vp),
+        ("h1", vp), ("x1", vp), ("h2", vp), ("x2", vp), ("rs_d", c_i64), ("a", vp), ("rs_a", c_i64),
+        ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp), ("stat_stride", c_i64),
+        ("eps", c_f32), ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_seed_ptr", vp), ("site0", c_u32),
+        ("phys_stride", c_i64), ("sync", vp),
+    ]
+
+
 class LnArgs(C.Structure):
     _fields_ = [
         ("mode", c_i32),
@@ -115,6 +128,7 @@ SIGNATURES = {
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
+    "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),

@@ -1,0 +1,341 @@
+// row_tail.hip — the position-0 tail of the top encoder layer in ONE launch.
+//
+// The model reads the encoder at position 0 only (VarAutoEncoder/model.py:97), so after the attention mix the top layer's
+//     h1 = x_in + dropout(att W_proj^T + b)        x1 = LN1(h1)                         (transformer.py:154-155)
+//     a  = dropout(relu(x1 W1^T + b1))             h2 = x1 + dropout(a W2^T + b2)       (transformer.py:42-46,157)
+//     x2 = LN2(h2)                                                                        (transformer.py:158)
+// run on B rows (one per sample): microseconds of arithmetic that used to be five launches of ~9 us each, every one a
+// dependent launch boundary plus a cold fetch of its weights. Here the chain is one launch of G = D / 16 workgroups that
+// each own a slice of every GEMM's OUTPUT columns (so every workgroup streams 1/G of every weight matrix, once) and meet
+// at three grid-wide barriers where the chain needs whole rows: after W_proj (LayerNorm 1 needs the row), after FFN1 (FFN2
+// contracts over the whole hidden row), after FFN2 (LayerNorm 2). Rows travel between the stages through HBM/L2 (they
+// are the tensors the backward pass reads anyway); the LayerNorms are computed where they are consumed. 64 x 256 x
+// (256 + 1024 + 1024) MACs spread over 16 CUs is ~1 us of MFMA; the launch is three barrier latencies plus four L2 round
+// trips. Arithmetic, rounding points and dropout counters are those of mst_gemm_nt / mst_layernorm_fwd on the same rows
+// (counter = physical row * N + column), so the backward pass regenerates the same masks.
+//
+// Inter-workgroup visibility WITHOUT fences (a release is a write-back of the XCD's L2, an acquire an invalidate of the CU's
+// L1: the fenced form of this kernel spent ~8 us per barrier, 38 us in all — the five launches took 43): every byte
+// that crosses a barrier (h1, a, h2) is stored write-through (`sc1`: relaxed agent-scope atomic stores of 8 bytes) and
+// loaded with `sc1` loads (relaxed agent-scope atomic loads), which bypass the non-coherent levels; every storing wave
+// drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then ONE lane adds to the counter and polls it with
+// relaxed agent loads (bounded), and the workgroup barriers again before anyone loads. Weights, att and the residual come
+// from earlier launches and are read with plain loads. The G workgroups are co-resident by construction (G <= 16 << 256).
+#include <math.h>
+#include "common.hpp"
+
+namespace mst {
+
+__device__ __forceinline__ void grid_sync(uint32_t* ctr, uint32_t target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) break;  // never in a correct launch; a bound instead of a hung GPU
+    }
+  }
+  __syncthreads();
+}
+
+// write-through 8-byte store / L2-served loads of the bytes that cross a grid barrier (relaxed, agent scope -> sc1)
+__device__ __forceinline__ void store8_sc1(void* p, u32x2 v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)v[0] | ((uint64_t)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32x2 load8_sc1(const void* p) {
+  const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
+}
+__device__ __forceinline__ uint32_t load4_sc1(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Act<T>::vec8 frag16(const T* p, bool ok) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (ok) v = *reinterpret_cast<const u32x4*>(p);
+  return __builtin_bit_cast(typename Act<T>::vec8, v);
+}
+
+// wave_sum of N independent values at once: the six cross-lane steps of all of them interleaved. One after the other
+// (16 rows x 2 sums x 6 dependent permutes, alone on its SIMD) the LayerNorm of 16 rows took 8.7 us.
+template <int N>
+__device__ __forceinline__ void wave_sum_batch(float (&v)[N]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += t[i];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (ok) { const u32x2 lo = load8_sc1(p), hi = load8_sc1(p + 4); v = u32x4{lo[0], lo[1], hi[0], hi[1]}; }
+  return __builtin_bit_cast(typename Act<T>::vec8, v);
+}
+
+// LayerNorm of one row held as 4 elements per lane (D = 256) or 2 (D = 128): layernorm_fwd_kernel's arithmetic
+template <typename T, int D>
+__device__ __forceinline__ void ln_row(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       int lane, float (&y)[D / 64], float& mean, float& rstd) {
+  constexpr int E = D / 64;
+  float v[E];
+  float s = 0.f;
+  if constexpr (E == 4) {
+    const u32x2 r = load8_sc1(x + lane * 4);
+    v[0] = bits_to_f32<T>((uint16_t)(r[0] & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r[0] >> 16));
+    v[2] = bits_to_f32<T>((uint16_t)(r[1] & 0xffff)); v[3] = bits_to_f32<T>((uint16_t)(r[1] >> 16));
+  } else {
+    const uint32_t r = load4_sc1(x + lane * 2);
+    v[0] = bits_to_f32<T>((uint16_t)(r & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r >> 16));
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += v[e];
+  mean = wave_sum(s) * (1.f / (float)D);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) { const float d = v[e] - mean; ss += d * d; }
+  rstd = 1.f / sqrtf(wave_sum(ss) * (1.f / (float)D) + eps);
+#pragma unroll
+  for (int e = 0; e < E; ++e) y[e] = (v[e] - mean) * rstd * gamma[lane * E + e] + beta[lane * E + e];
+}
+
+// diagnostic build only (-DMST_TAIL_STAMPS): workgroup 0 leaves s_memrealtime stamps (100 MHz) in sync[8 + i]
+#ifdef MST_TAIL_STAMPS
+#define TAIL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) q.sync[8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_STAMP(i) do { } while (0)
+#endif
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) {
+  constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64;
+  __shared__ __attribute__((aligned(16))) T sX1[64 * LDX];  // LayerNorm-1 output of every row (FFN1's operand, FFN2's residual)
+  typedef typename Act<T>::vec8 vec8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x;
+  const int li = lane & 15, lq = lane >> 4;
+  const int B = (int)q.B;
+  const int m = wave * 16 + li;  // the row this lane's accumulator column belongs to
+  const bool m_ok = m < B;
+  const int64_t pm = (int64_t)m * q.phys_stride;  // physical row in the [B * S, N] tensors: the dropout counter's row
+  const float p = q.dropout_p;
+  const bool drop = p > 0.f;
+  const uint64_t dseed = q.dropout_seed ^ ((drop && q.dropout_seed_ptr) ? q.dropout_seed_ptr[0] : 0ull);
+  const uint32_t thr = dropout_thr(p);
+  const float inv_keep = dropout_inv_keep(p);
+  const T* att = reinterpret_cast<const T*>(q.att);
+  const T* xin = reinterpret_cast<const T*>(q.resid);
+  T* h1 = reinterpret_cast<T*>(q.h1); T* x1 = reinterpret_cast<T*>(q.x1); T* a = reinterpret_cast<T*>(q.a);
+  T* h2 = reinterpret_cast<T*>(q.h2); T* x2 = reinterpret_cast<T*>(q.x2);
+
+  auto finish4 = [&](const f32x4& acc, const float* bias, int n, uint32_t site, int64_t N, bool relu, const T* res /* row ptr or null */,
+                     T* dst /* row ptr */) {
+    // one lane's four consecutive output columns n..n+3 of row m: bias, ReLU, dropout, residual, rounding — gemm_epilogue's order
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n);
+    uint32_t keep = 0xFu;
+    if (drop) keep = dropout_keep4k(dropout_key(dseed, site), (uint64_t)(pm * N + n) >> 2, thr);
+    float r4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {
+      const u32x2 rv = *reinterpret_cast<const u32x2*>(res + n);
+      r4[0] = bits_to_f32<T>((uint16_t)(rv[0] & 0xffff)); r4[1] = bits_to_f32<T>((uint16_t)(rv[0] >> 16));
+      r4[2] = bits_to_f32<T>((uint16_t)(rv[1] & 0xffff)); r4[3] = bits_to_f32<T>((uint16_t)(rv[1] >> 16));
+    }
+    uint16_t hb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[e] + b4[e];
+      if (relu) t = fmaxf(t, 0.f);
+      if (drop) t = ((keep >> e) & 1u) ? t * inv_keep : 0.f;
+      hb[e] = f32_to_bits<T>(t + r4[e]);
+    }
+    store8_sc1(dst + n, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+  };
+
+  TAIL_STAMP(0);
+  // ---------------- stage 1: h1[:, 16 g .. 16 g + 15] = x_in + dropout(att W_proj^T + b)
+  {
+    const int n0 = g * 16;
+    const T* Wp = reinterpret_cast<const T*>(q.Wp) + (int64_t)(n0 + li) * q.ldwp + 8 * lq;
+    const T* Ar = att + (int64_t)m * q.rs_att + 8 * lq;
+    vec8 wf[D / 32], xf[D / 32];
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) { wf[ks] = frag16<T>(Wp + 32 * ks, true); xf[ks] = frag16<T>(Ar + 32 * ks, m_ok); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) acc = Act<T>::mfma16(wf[ks], xf[ks], acc);
+    if (m_ok) finish4(acc, q.bp, n0 + 4 * lq, q.site0, D, false, xin + (int64_t)m * q.rs_res, h1 + (int64_t)m * q.rs_d);
+  }
+  // (memory-level parallelism is the whole game here: every stage is a few dependent L2 / fabric round trips, so the
+  // next stage's weight fragments are requested BEFORE the barrier they do not depend on, and rows are loaded in batches)
+  const int n1 = g * 64;
+  const T* W1p = reinterpret_cast<const T*>(q.W1) + (int64_t)(n1 + li) * q.ldw1 + 8 * lq;
+  vec8 w1f[D / 32][4];  // ALL of this workgroup's FFN1 weights (one wave per SIMD: the whole register file is ours)
+#pragma unroll
+  for (int ks = 0; ks < D / 32; ++ks)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w1f[ks][j] = frag16<T>(W1p + (int64_t)16 * j * q.ldw1 + 32 * ks, true);
+  TAIL_STAMP(1);
+  grid_sync(q.sync, G);
+  TAIL_STAMP(2);
+
+  // ---------------- stage 2: x1 = LN1(h1) for every row (each workgroup, into LDS; the rows' owner also to HBM), then
+  //                  a[:, 64 g .. 64 g + 63] = dropout(relu(x1 W1^T + b1))
+  {
+    constexpr int RPW = 16;  // rows per wave: rows wave, wave + 4, ...
+    float v[RPW][E];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + 4 * i;
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[i][e] = 0.f;
+      if (r < B) {
+        if constexpr (E == 4) {
+          const u32x2 t = load8_sc1(h1 + (int64_t)r * q.rs_d + lane * 4);
+          v[i][0] = bits_to_f32<T>((uint16_t)(t[0] & 0xffff)); v[i][1] = bits_to_f32<T>((uint16_t)(t[0] >> 16));
+          v[i][2] = bits_to_f32<T>((uint16_t)(t[1] & 0xffff)); v[i][3] = bits_to_f32<T>((uint16_t)(t[1] >> 16));
+        } else {
+          const uint32_t t = load4_sc1(h1 + (int64_t)r * q.rs_d + lane * 2);
+          v[i][0] = bits_to_f32<T>((uint16_t)(t & 0xffff)); v[i][1] = bits_to_f32<T>((uint16_t)(t >> 16));
+        }
+      }
+    }
+    float gm[E], bt[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { gm[e] = q.g1[lane * E + e]; bt[e] = q.be1[lane * E + e]; }
+#ifdef MST_TAIL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TAIL_STAMP(8);
+#endif
+    float mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      mean[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) mean[i] += v[i][e];
+    }
+    wave_sum_batch<RPW>(mean);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      mean[i] *= (1.f / (float)D);
+      rstd[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const float d = v[i][e] - mean[i]; rstd[i] += d * d; }
+    }
+    wave_sum_batch<RPW>(rstd);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + 4 * i;
+      rstd[i] = 1.f / sqrtf(rstd[i] * (1.f / (float)D) + q.eps);
+      uint16_t yb[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) yb[e] = (r < B) ? f32_to_bits<T>((v[i][e] - mean[i]) * rstd[i] * gm[e] + bt[e]) : (uint16_t)0;  // rows past the batch: zeros
+      if constexpr (E == 4) {
+        const u32x2 o = {(uint32_t)yb[0] | ((uint32_t)yb[1] << 16), (uint32_t)yb[2] | ((uint32_t)yb[3] << 16)};
+        *reinterpret_cast<u32x2*>(sX1 + r * LDX + lane * 4) = o;
+        if (r < B && r % G == g) *reinterpret_cast<u32x2*>(x1 + (int64_t)r * q.rs_d + lane * 4) = o;
+      } else {
+        const uint32_t o = (uint32_t)yb[0] | ((uint32_t)yb[1] << 16);
+        *reinterpret_cast<uint32_t*>(sX1 + r * LDX + lane * 2) = o;
+        if (r < B && r % G == g) *reinterpret_cast<uint32_t*>(x1 + (int64_t)r * q.rs_d + lane * 2) = o;
+      }
+      if (r < B && r % G == g && lane == 0) { q.mean1[(int64_t)r * q.stat_stride] = mean[i]; q.rstd1[(int64_t)r * q.stat_stride] = rstd[i]; }
+    }
+  }
+  TAIL_STAMP(9);
+  __syncthreads();
+  TAIL_STAMP(10);
+  const int n2 = g * 16;
+  const T* W2p = reinterpret_cast<const T*>(q.W2) + (int64_t)(n2 + li) * q.ldw2 + 8 * lq;
+  constexpr int KB = F / 64;  // k-steps per batch of FFN2: two batches cover K = 4 D
+  vec8 w2f[2][KB];     // FFN2 weight fragments: both batches in flight
+  {
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+      const vec8 xf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sX1 + m * LDX + 32 * ks + 8 * lq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = Act<T>::mfma16(w1f[ks][j], xf, acc[j]);
+    }
+    TAIL_STAMP(11);
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) w2f[0][ks] = frag16<T>(W2p + 32 * ks, true);  // FFN2's first weights: before the barrier
+    if (m_ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) finish4(acc[j], q.b1, n1 + 16 * j + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) w2f[1][ks] = frag16<T>(W2p + (KB + ks) * 32, true);
+  }
+  TAIL_STAMP(3);
+  grid_sync(q.sync, 2 * G);
+  TAIL_STAMP(4);
+
+  // ---------------- stage 3: h2[:, 16 g ..] = x1 + dropout(a W2^T + b2)        (K = 4 D: the whole hidden row)
+  {
+    const T* Ar = a + (int64_t)m * q.rs_a + 8 * lq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    vec8 xf[2][KB];  // the hidden row's fragments: every load in flight at once (two dependent fabric round trips were 5 us)
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks) xf[bt][ks] = frag16_sc1<T>(Ar + (bt * KB + ks) * 32, m_ok);
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks) acc = Act<T>::mfma16(w2f[bt][ks], xf[bt][ks], acc);
+    if (m_ok) finish4(acc, q.b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
+  }
+  TAIL_STAMP(5);
+  grid_sync(q.sync, 3 * G);
+  TAIL_STAMP(6);
+
+  // ---------------- stage 4: x2 = LN2(h2), rows dealt to the workgroups
+  for (int r = g + G * wave; r < B; r += 4 * G) {
+    float y[E], mean, rstd;
+    ln_row<T, D>(h2 + (int64_t)r * q.rs_d, q.g2, q.be2, q.eps, lane, y, mean, rstd);
+    uint16_t yb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) yb[e] = f32_to_bits<T>(y[e]);
+    if constexpr (E == 4) *reinterpret_cast<u32x2*>(x2 + (int64_t)r * q.rs_d + lane * 4) =
+        u32x2{(uint32_t)yb[0] | ((uint32_t)yb[1] << 16), (uint32_t)yb[2] | ((uint32_t)yb[3] << 16)};
+    else *reinterpret_cast<uint32_t*>(x2 + (int64_t)r * q.rs_d + lane * 2) = (uint32_t)yb[0] | ((uint32_t)yb[1] << 16);
+    if (lane == 0) { q.mean2[(int64_t)r * q.stat_stride] = mean; q.rstd2[(int64_t)r * q.stat_stride] = rstd; }
+  }
+  TAIL_STAMP(7);
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr, "mst_row_tail_fwd: null args");
+  const mst_row_tail_args& q = *args;
+  MST_CHECK_ARG(q.B > 0 && q.B <= 64, "mst_row_tail_fwd: 1..64 rows (got %lld)", (long long)q.B);
+  MST_CHECK_ARG(q.D == 128 || q.D == 256, "mst_row_tail_fwd: width must be 128 or 256 (got %lld)", (long long)q.D);
+  MST_CHECK_ARG(q.att && q.resid && q.Wp && q.bp && q.g1 && q.be1 && q.W1 && q.b1 && q.W2 && q.b2 && q.g2 && q.be2 && q.h1 && q.x1 && q.a &&
+                q.h2 && q.x2 && q.mean1 && q.rstd1 && q.mean2 && q.rstd2 && q.sync, "mst_row_tail_fwd: null pointer");
+  MST_CHECK_ARG(q.rs_att % 8 == 0 && q.rs_res % 8 == 0 && q.rs_d % 8 == 0 && q.rs_a % 8 == 0 && q.ldwp % 8 == 0 && q.ldw1 % 8 == 0 &&
+                q.ldw2 % 8 == 0, "mst_row_tail_fwd: strides must be multiples of 8 elements");
+  MST_CHECK_ARG((((uintptr_t)q.att | (uintptr_t)q.resid | (uintptr_t)q.Wp | (uintptr_t)q.W1 | (uintptr_t)q.W2 | (uintptr_t)q.h1 | (uintptr_t)q.x1 |
+                  (uintptr_t)q.a | (uintptr_t)q.h2 | (uintptr_t)q.x2 | (uintptr_t)q.bp | (uintptr_t)q.b1 | (uintptr_t)q.b2) % 16) == 0,
+                "mst_row_tail_fwd: operands must be 16-byte aligned");
+  MST_CHECK_ARG(q.dropout_p >= 0.f && q.dropout_p < 1.f && q.phys_stride > 0 && q.stat_stride > 0, "mst_row_tail_fwd: bad dropout / strides");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(q.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8), dim3(256), 0, s, q);
+    MST_CHECK_LAUNCH("row_tail_fwd_kernel");
+    return MST_OK;
+  });
+}

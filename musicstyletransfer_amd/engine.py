@@ -372,9 +372,12 @@ class StepPlan:
         self.dec = layers(cfg.d_layers, self.Md, Dd, cfg.d_heads, Sd)
         self.mu, self.sigma, self.z = torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32), torch.zeros(B, Z, **f32)
         self.kl, self.total = torch.zeros(B, **f32), torch.zeros(B, **f32)
-        # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B)
-        self._recon_buf = torch.zeros((B + 3) // 4 * 4, **f32)
+        # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B);
+        # the same zero list clears the grid-barrier words of the one-launch position-0 tails (mst_row_tail_*)
+        nb4 = (B + 3) // 4 * 4
+        self._recon_buf = torch.zeros(nb4 + 4, **f32)
         self.recon = self._recon_buf[:B]
+        self.sync_words = self._recon_buf[nb4:].view(torch.int32)
         self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
         self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
         # output layer + BCE in one launch when a tile can hold whole rows of pitches of one sample (configs[1]: P 128, T 256)
@@ -542,6 +545,14 @@ class StepPlan:
 
         o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
         o.attn_fwd(L.qkv, self.keymask_e, L.lse, L.att, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
+        if o.can_row_tail(B, D):  # W_proj, LN1, FFN1, FFN2, LN2 on the B position-0 rows in one launch (mst_row_tail_fwd)
+            o.row_tail_fwd(row0(L.att), row0(x_in), st.h(f"{pre}.att.W_proj.weight"), st.p(f"{pre}.att.W_proj.bias"),
+                           st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), st.h(f"{pre}.ff1.weight"), st.p(f"{pre}.ff1.bias"),
+                           st.h(f"{pre}.ff2.weight"), st.p(f"{pre}.ff2.bias"), st.p(f"{pre}.ln2.gamma"), st.p(f"{pre}.ln2.beta"),
+                           row0(L.h1), row0(L.x1), row0(L.a), row0(L.h2), row0(L.x2), L.mean1, L.rstd1, L.mean2, L.rstd2,
+                           self.sync_words[0:1], stat_stride=S, phys_stride=S, dropout_p=p,
+                           dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
+            return L.x2
         rows = (1, S, 0)  # output row b -> physical row b*S
         o.gemm_nt(row0(L.att), st.h(f"{pre}.att.W_proj.weight"), L.h1, M=B, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
                   resid=row0(x_in), c_remap=rows, **self._drop(p, site0))

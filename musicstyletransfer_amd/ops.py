@@ -84,6 +84,28 @@ def gemm_nt(A, B, C_out, **kw):
     call("mst_gemm_nt", C.byref(_gemm_args(A, B, C_out, **kw)), stream())
 
 
+def can_row_tail(B, D):
+    """shapes the one-launch position-0 tail of the top encoder layer exists for (mst_row_tail_fwd)"""
+    return D in (128, 256) and 0 < B <= 64
+
+
+def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a, h2, x2, mean1, rstd1, mean2, rstd2, sync, stat_stride,
+                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0):
+    """att / resid / h1 / x1 / a / h2 / x2: [B, width] row views (stride(0) = the row stride in elements) of the layer's
+    buffers; sync: one zeroed int32 device word"""
+    q = _lib.RowTailArgs()
+    q.dtype, q.B, q.D = dt(att), att.shape[0], Wp.shape[0]
+    q.att, q.rs_att, q.resid, q.rs_res = ptr(att), att.stride(0), ptr(resid), resid.stride(0)
+    q.Wp, q.ldwp, q.bp, q.g1, q.be1 = ptr(Wp), ld(Wp), ptr(bp), ptr(g1), ptr(be1)
+    q.W1, q.ldw1, q.b1, q.W2, q.ldw2, q.b2, q.g2, q.be2 = ptr(W1), ld(W1), ptr(b1), ptr(W2), ld(W2), ptr(b2), ptr(g2), ptr(be2)
+    assert h1.stride(0) == x1.stride(0) == h2.stride(0) == x2.stride(0)
+    q.h1, q.x1, q.h2, q.x2, q.rs_d, q.a, q.rs_a = ptr(h1), ptr(x1), ptr(h2), ptr(x2), h1.stride(0), ptr(a), a.stride(0)
+    q.mean1, q.rstd1, q.mean2, q.rstd2, q.stat_stride = ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2), stat_stride
+    q.eps, q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = eps, dropout_p, 0, ptr(dropout_seed_ptr), site0
+    q.phys_stride, q.sync = phys_stride, ptr(sync)
+    call("mst_row_tail_fwd", C.byref(q), stream())
+
+
 def can_fuse_bce(P, T):
     """shapes the output-layer GEMM + BCE launch exists for (mst_gemm_sigmoid_bce)"""
     return P in (128, 256) and T % 64 == 0

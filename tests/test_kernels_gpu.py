@@ -30,6 +30,55 @@ def close(a, b, rtol, atol, what=""):
     assert bad == 0, f"{what}: {bad}/{a.numel()} out of tolerance, max err {err.max().item():.4g}, ref max {b.abs().max().item():.4g}"
 
 
+# ------------------------------------------------------------------------------------------ position-0 tail
+@pytest.mark.parametrize("B,S,D,p,dtype", [(64, 8, 256, 0.2, BF), (5, 3, 128, 0.0, BF), (33, 4, 256, 0.2, torch.float16), (16, 2, 128, 0.2, BF)])
+def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
+    """mst_row_tail_fwd (W_proj + LN1 + FFN1 + FFN2 + LN2 on the B position-0 rows, one launch with three grid barriers)
+    against the five launches it replaces on the same strided rows: same MFMA order per element and the same dropout
+    counters, so h1 / a are bit-identical; the LayerNorms sum a row in another order (an ulp here and there)"""
+    o = ops()
+    F = 4 * D
+    g = torch.Generator().manual_seed(7)
+    r = lambda *sh, sc=1.0, dt=dtype: (torch.randn(*sh, generator=g) * sc).to(dt).to(gpu)
+    att, xin = r(B * S, D), r(B * S, D)
+    Wp, W1, W2 = r(D, D, sc=0.06), r(F, D, sc=0.06), r(D, F, sc=0.03)
+    bp, b1, b2 = r(D, sc=0.1, dt=torch.float32), r(F, sc=0.1, dt=torch.float32), r(D, sc=0.1, dt=torch.float32)
+    g1, be1, g2, be2 = (1 + r(D, sc=0.1, dt=torch.float32)), r(D, sc=0.1, dt=torch.float32), (1 + r(D, sc=0.1, dt=torch.float32)), r(D, sc=0.1, dt=torch.float32)
+    seedp = torch.tensor([99, 0, 0, 0], dtype=torch.int64, device=gpu)
+    row0 = lambda t: t.view(B, S, -1)[:, 0, :]
+
+    def bufs():
+        z = lambda w: torch.zeros(B * S, w, dtype=dtype, device=gpu)
+        return dict(h1=z(D), x1=z(D), a=z(F), h2=z(D), x2=z(D), m1=torch.zeros(B * S, device=gpu), r1=torch.zeros(B * S, device=gpu),
+                    m2=torch.zeros(B * S, device=gpu), r2=torch.zeros(B * S, device=gpu))
+
+    dk = lambda site: dict(dropout_p=p, dropout_seed_ptr=seedp, dropout_site=site) if p > 0 else {}
+    u, rows = bufs(), (1, S, 0)
+    o.gemm_nt(row0(att), Wp, u["h1"], M=B, N=D, K=D, bias=bp, resid=row0(xin), c_remap=rows, **dk(6))
+    o.layernorm_fwd(row0(u["h1"]), g1, be1, row0(u["x1"]), u["m1"], u["r1"], D=D, M=B, row_id_stride=S)
+    o.gemm_nt(row0(u["x1"]), W1, u["a"], M=B, K=D, bias=b1, act=o.ACT_RELU, c_remap=rows, **dk(7))
+    o.gemm_nt(row0(u["a"]), W2, u["h2"], M=B, K=F, bias=b2, resid=row0(u["x1"]), c_remap=rows, **dk(8))
+    o.layernorm_fwd(row0(u["h2"]), g2, be2, row0(u["x2"]), u["m2"], u["r2"], D=D, M=B, row_id_stride=S)
+    f = bufs()
+    sync = torch.zeros(4, dtype=torch.int32, device=gpu)
+    o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(f["h1"]), row0(f["x1"]), row0(f["a"]), row0(f["h2"]),
+                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:1], stat_stride=S, phys_stride=S, dropout_p=p,
+                   dropout_seed_ptr=seedp if p > 0 else None, site0=6)
+    torch.cuda.synchronize()
+    assert int(sync[0].item()) == 3 * (D // 16)  # three barriers, every workgroup arrived at each
+    assert torch.equal(row0(f["h1"]), row0(u["h1"])), "h1"
+    ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
+    for k in ("x1", "a", "h2", "x2"):
+        d = (row0(f[k]).float() - row0(u[k]).float()).abs()
+        ref = row0(u[k]).float().abs().clamp(min=1.0)
+        assert (d <= 2 * ulp * ref).all(), (k, d.max().item())
+        assert (row0(f[k]) != row0(u[k])).float().mean().item() < 0.05, k
+    for k in ("m1", "r1", "m2", "r2"):
+        close(f[k][::S], u[k][::S], 2e-3, 2e-4, k)
+    # rows other than position 0 are never touched
+    assert (f["h1"].view(B, S, -1)[:, 1:] == 0).all() and (f["a"].view(B, S, -1)[:, 1:] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------ layout
 def test_selftest_layout_maps(gpu):
     flags = ops().selftest()
