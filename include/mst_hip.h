@@ -194,6 +194,19 @@ typedef struct mst_ln_bwd_in {
 } mst_ln_bwd_in;
 int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
                         const mst_ln_args* ln, mst_stream_t stream);
+/* The attention output projection joins the block (MultiHeadDotAttention's W_proj Dense, transformer.py:65-68,105-106, and the
+ * residual LayerNorm behind it, transformer.py:154-156 / 191-193):
+ * forward, in FRONT of mst_ffn_ln_fwd —
+ *     mst_gemm_nt_ln(proj, ln1) mode 1     h1 = epi(att Wp^T + bp) (+ dropout, + residual), x1 = LayerNorm(h1), mean1, rstd1
+ * with x1 (= ln1->out, which must be ff1->A) handed to the block on chip and stored, with h1 and the statistics, for backward;
+ * backward, BEHIND mst_ffn_ln_bwd / mst_ffn_ln_bwd_lead (lead may be NULL) —
+ *     mst_gemm_nt(proj_dgrad)              datt = d(h1)[masked] Wp          (a plain product: no bias, residual or scale)
+ * proj_dgrad->A must be the LayerNorm backward's masked result (ln->out, mask_mode 1) or its plain one (ff1_dgrad->C).
+ * The projection is width x width (N = K = the model width) on the same M rows. Same results as the separate launches. */
+int mst_proj_ffn_ln_fwd(const mst_gemm_args* proj, const mst_ln_args* ln1, const mst_gemm_args* ff1, const mst_gemm_args* ff2,
+                        const mst_ln_args* ln2, mst_stream_t stream);
+int mst_ffn_ln_bwd_tail(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
+                        const mst_ln_args* ln, const mst_gemm_args* proj_dgrad, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order

@@ -132,6 +132,8 @@ SIGNATURES = {
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
+    "mst_proj_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
+    "mst_ffn_ln_bwd_tail": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), C.POINTER(GemmArgs), vp]),
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln_parts": (c_i64, [c_i64]),
     "mst_partial_sums": (C.c_int, [C.POINTER(PartialSum), C.c_int, vp]),

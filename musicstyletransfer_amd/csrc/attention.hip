@@ -741,6 +741,13 @@ __device__ __forceinline__ void stage_pair(T* ldsA, const T* __restrict__ gA, in
   }
 }
 
+// waves per SIMD the head-size-16 resident kernels are compiled for (5 = 96 VGPRs, two 9-wave workgroups per CU, measured no faster forward and spills backward: the kernels are VALU-bound, not occupancy-bound)
+#ifndef MST_ATT16_WAVES_FWD
+#define MST_ATT16_WAVES_FWD 4
+#endif
+#ifndef MST_ATT16_WAVES_BWD
+#define MST_ATT16_WAVES_BWD 4
+#endif
 // (batch*head) of a 1-D grid; batch elements are dealt to the XCDs so that the heads of one element share an L2
 __device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
   const int64_t lin = blockIdx.x;
@@ -750,7 +757,7 @@ __device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
 }
 
 template <typename T, int DH>
-__global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_FWD : 4))) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
   const int64_t S = a.S;
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(AttnArgs a) {
 }
 
 template <typename T, int DH, bool SPARSE>
-__global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_BWD : 4))) void attn_bwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
   const int64_t S = a.S;
@@ -939,8 +946,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(AttnArgs a) {
 }
 
 // Waves per workgroup for the resident kernels, or 0 when the sequence does not fit: maximise (resident waves per CU)
-// x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU.
-static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes) {
+// x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU,
+// the 96 of the head-size-16 instantiations 20 (two 9-wave workgroups of a 257-row sequence: the decoder of configs[1]).
+static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_cu = 16) {
   const char* force = getenv("MST_ATTN_PATH");  // "stream" / "resident": pin the path (tests cover both)
   if (force && force[0] == 's') return 0;
   const size_t LDS_CU = 160 * 1024;
@@ -950,7 +958,7 @@ static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes) {
   int best = 0;
   double best_score = 0.0;
   for (int nw = 1; nw <= 16 && nw <= NB; ++nw) {
-    int wgs = 16 / nw;
+    int wgs = waves_cu / nw;
     if ((size_t)wgs * lds_bytes > LDS_CU) wgs = (int)(LDS_CU / lds_bytes);
     if (wgs > by_grid) wgs = by_grid;
     if (wgs < 1) continue;
@@ -974,7 +982,7 @@ static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, i
 template <typename T, int DH>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_fwd<DH>(a.S);
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds)) {
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_FWD : 16)) {
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
     if (lds > attr_lds) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH>),
@@ -997,7 +1005,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <typename T, int DH>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_bwd<DH>(a.S);
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds)) {
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_BWD : 16)) {
     const bool sparse = a.q_limit > 0 && a.q_limit <= 32;
     static size_t attr_lds[2] = {64 * 1024, 64 * 1024};  // dynamic LDS above 64 KB has to be opted into, per kernel
     if (lds > attr_lds[sparse]) {

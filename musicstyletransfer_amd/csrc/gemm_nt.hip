@@ -40,6 +40,60 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int frow = lane & 15, fq = lane >> 4;
+  if constexpr (PATH == 3) {
+    // Direct form (interior tiles, 16-bit output, only bias / alpha / ReLU / residual / gate): finished in accumulator
+    // layout — a quad is 4 consecutive columns of one row, so every access is 8 bytes and the four column blocks of a
+    // wave complete 32-byte sectors of the same lines back to back. No LDS round trip and no barrier: a wave leaves as
+    // soon as its own MFMAs are done (the staged form costs a workgroup ~3.5 us of its ~10 us life at K = 256).
+    // Off by default: it measured slower at step level (launch_gemm).
+    const T* resid = reinterpret_cast<const T*>(a.resid);
+    const T* gate = reinterpret_cast<const T*>(a.gate);
+    const int64_t mrow = m0 + wm * WTM + frow;
+    const int ncol = (int)n0 + wn * WTN + fq * 4;
+    u32x2 rv[TN][TM], gv[TN][TM];
+    if (resid) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rv[j][i] = *reinterpret_cast<const u32x2*>(resid + (mrow + i * 16) * a.ldr + ncol + j * 16);
+    }
+    if (gate) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) gv[j][i] = *reinterpret_cast<const u32x2*>(gate + (mrow + i * 16) * a.ldg + ncol + j * 16);
+    }
+    const bool relu = a.act == MST_ACT_RELU;
+    const float alpha = a.alpha;
+    T* cbase = reinterpret_cast<T*>(a.C) + mrow * a.ldc + ncol;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ncol + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          t[e] = (acc[j][i][e] + b4[e]) * alpha;
+          if (relu) t[e] = fmaxf(t[e], 0.f);
+        }
+        if (resid) {
+          t[0] += bits_to_f32<T>((uint16_t)(rv[j][i][0] & 0xFFFFu)); t[1] += bits_to_f32<T>((uint16_t)(rv[j][i][0] >> 16));
+          t[2] += bits_to_f32<T>((uint16_t)(rv[j][i][1] & 0xFFFFu)); t[3] += bits_to_f32<T>((uint16_t)(rv[j][i][1] >> 16));
+        }
+        if (gate) {
+          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][0] & 0xFFFFu)) > 0.f)) t[0] = 0.f;
+          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][0] >> 16)) > 0.f)) t[1] = 0.f;
+          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][1] & 0xFFFFu)) > 0.f)) t[2] = 0.f;
+          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][1] >> 16)) > 0.f)) t[3] = 0.f;
+        }
+        *reinterpret_cast<u32x2*>(cbase + (int64_t)i * 16 * a.ldc + j * 16) =
+            u32x2{(uint32_t)f32_to_bits<T>(t[0]) | ((uint32_t)f32_to_bits<T>(t[1]) << 16),
+                  (uint32_t)f32_to_bits<T>(t[2]) | ((uint32_t)f32_to_bits<T>(t[3]) << 16)};
+      }
+    }
+    return;
+  }
   // ------------------------------------------------------------------ epilogue
   // The accumulators go to LDS as fp32 (one wave-row group of the tile per pass) and every thread then finishes
   // 8 consecutive columns of a row at a time: bias / residual / gate / output move as 16-byte, row-contiguous
@@ -434,9 +488,12 @@ __device__ __forceinline__ float row_sum(float v) {
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
                                                  f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0,
-                                                 const T* lds_resid = nullptr, int lds_resid_ld = 0) {
+                                                 const T* lds_resid = nullptr, int lds_resid_ld = 0,
+                                                 T* lds_out = nullptr, int lds_out_ld = 0) {
   // lds_resid: the workgroup's BM residual rows already sit in LDS (row stride lds_resid_ld elements, outside the staging
   // tile): they are read from there instead of from a.resid
+  // lds_out: the result rows ALSO go to this LDS tile (outside the staging tile; rows past M as zeros): the LayerNorm output
+  // (mode 1) or the input gradient — its masked copy when there is one — (mode 2), for a GEMM that follows in the same launch
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -538,6 +595,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
 #pragma unroll
         for (int e = 0; e < 8; ++e) yb.h[e] = f32_to_bits<T>(t[e] * rstd * gam8[e] + bet8[e]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(l.out) + pm * l.ld_out + nc) = yb.u;
+        if (lds_out) *reinterpret_cast<u32x4*>(lds_out + row * lds_out_ld + nc) = yb.u;
         if (ch == 0) { l.mean[pm] = mean; l.rstd[pm] = rstd; }
       } else {
         const int64_t rid = pm;  // x, the statistics and the forward's dropout counter live at the PHYSICAL row of C
@@ -574,7 +632,10 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
         }
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + pm * a.ldc + nc) = ob.u;
         if (l.mask_mode == 1) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(l.out) + m * l.ld_out + nc) = mb.u;
+        if (lds_out) *reinterpret_cast<u32x4*>(lds_out + row * lds_out_ld + nc) = l.mask_mode == 1 ? mb.u : ob.u;
       }
+    } else if (lds_out) {
+      *reinterpret_cast<u32x4*>(lds_out + row * lds_out_ld + nc) = u32x4{0u, 0u, 0u, 0u};
     }
   }
   if (MODE == 2) {
@@ -739,12 +800,31 @@ static int launch_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q, hipStr
 // weight ring — the launch is bound by a single workgroup's serial latency (35 us for ONE workgroup, 42 for 256), so
 // every such drain is a full L2 round trip on the critical path. Hence also: bias of the first GEMM read from LDS
 // (it was a global load + vmcnt(0) inside the chunk epilogue), prefetches issued unconditionally (clamped).
-template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD, bool FULL>
-__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln, mst_ln_bwd_in lead) {
+// DW ("direct weights", WGM = 1): a wave owns ALL 64 rows and BN / WGN columns of both GEMMs, so every weight fragment has
+// exactly one consumer — the wave loads it from global memory straight into the MFMA operand registers (a ring of RING
+// stages per wave), the weight stages in LDS, their ds_writes and the barrier per stage disappear: the waves free-run
+// between the two barriers of a chunk (hidden chunk produced / double-buffered, so none before it is overwritten), LDS
+// carries only the activation fragments (64 x k x 2 B per wave and k step instead of (32 + 64) x k x 2 plus the stage
+// writes). Same MFMA order per output element as the staged form.
+// Measured (tools/experiments/ab_ffn_dw.sh, width 256 forward, staged form 42.5 us): reading the weights where they lie —
+// 16 rows x 64 B per load instruction — 52.9 us; reading them from a fragment-ordered copy (1 KB contiguous per
+// instruction; timing experiment MST_FFN_DW_FAKE, wrong numbers) 37.7 us with a 4-stage ring, 59 us with 8 stages (spills),
+// 43 us with 16 waves of 16 columns. Not enabled (MST_FFN_DW=1 selects it): the 5 us need a third weight shadow layout.
+// EXTRA: one more width x width GEMM on the workgroup's rows in the same launch (gx; its weights are extra stages of the
+// same stream). Forward (mst_proj_ffn_ln_fwd): the attention output projection + residual + LayerNorm in FRONT — the input
+// tile is the attention output, the block's input x1 = LayerNorm(h1) is computed by mst_gemm_nt_ln's forward epilogue
+// (gx, lnx) into the x tile (and stored, with h1 and the statistics, for the backward pass). Backward (mst_ffn_ln_bwd_tail):
+// the projection's dgrad BEHIND the LayerNorm-1 backward — its (masked) result tile is the extra GEMM's A operand.
+template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD, bool FULL, bool DW = false, bool EXTRA = false>
+__global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln, mst_ln_bwd_in lead,
+                                                                mst_gemm_args gx, mst_ln_args lnx) {
+  constexpr bool HEAD = EXTRA && MODE == 1, TAIL = EXTRA && MODE == 2;
+  static_assert(!(EXTRA && DW), "the extra GEMM rides on the staged weight stream");
   constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
-  constexpr int B_CH = BN * CHUNKS / NT;       // 16-byte pieces of a weight stage per thread
+  static_assert(!DW || WGM == 1, "direct weights: a wave must own every row of its columns");
+  constexpr int B_CH = DW ? TN * (BK / 32) : BN * CHUNKS / NT;  // 16-byte pieces of a weight stage per thread
   constexpr int LDA = BN + 8;                  // row stride (elements) of the two activation tiles: conflict-free b128 reads
   constexpr int KST = BN / BK;                 // K stages of one GEMM of a chunk (K = BN for both)
   static_assert(BN * CHUNKS % NT == 0 && (BM * BN / 8) % NT == 0, "tile/threads mismatch");
@@ -752,9 +832,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [weight stages 2 x BN x 64][hidden chunk 64 x LDA][x tile 64 x LDA]; the LayerNorm epilogue's fp32 staging tile reuses
   // the first two regions (both dead by then)
+  // (DW: [hidden chunk, two buffers][x tile])
   u32x4* sB = reinterpret_cast<u32x4*>(smem);
-  T* sH = reinterpret_cast<T*>(smem + (size_t)2 * BN * BK * 2);
-  T* sX = sH + BM * LDA;
+  T* sH = reinterpret_cast<T*>(smem + (DW ? (size_t)0 : (size_t)2 * BN * BK * 2));
+  T* sX = sH + (DW ? 2 : 1) * BM * LDA;
   float* sBias1 = reinterpret_cast<float*>(sX + BM * LDA);  // [F] the first GEMM's bias (zeros without one)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
@@ -782,27 +863,46 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   auto kstage = [&](int s) { return (s + rotk) & (KST - 1); };  // stage s of a GEMM reads K slice kstage(s)
   const T* __restrict__ W1 = reinterpret_cast<const T*>(g1.B);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(g2.B);
+  const T* __restrict__ WX = reinterpret_cast<const T*>(gx.B);  // EXTRA: chunk -1 (head) / chunk n_chunks (tail) of the stream
 
   // ---- weight stream: stage s of chunk c is GEMM 1 (s < KST: W1 rows c*BN.., columns s*64..) or GEMM 2 (W2 rows 0..BN-1,
   // columns c*BN + (s-KST)*64..). Per-thread element offsets are constants; the uniform base moves.
-  uint32_t off1[B_CH], off2[B_CH];
+  uint32_t off1[B_CH], off2[B_CH], offx[B_CH];
   int b_lds[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
-    const int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
+    // (DW: piece i = fragment (j, ks) of the wave's own columns, in the MFMA operand's lane order)
+    const int c = tid + i * NT;
+    const int row = DW ? wn * WTN + (i / (BK / 32)) * 16 + frow : c / CHUNKS, ch = DW ? (i % (BK / 32)) * 4 + fq : c % CHUNKS;
     off1[i] = (uint32_t)row * (uint32_t)g1.ldb + (uint32_t)ch * 8u;
     off2[i] = (uint32_t)row * (uint32_t)g2.ldb + (uint32_t)ch * 8u;
+    offx[i] = EXTRA ? (uint32_t)row * (uint32_t)gx.ldb + (uint32_t)ch * 8u : 0u;
     b_lds[i] = row * CHUNKS + (ch ^ (row & 7));
   }
   // The stream runs AHEAD stages in front of the MFMAs, in a register ring: with one 8-wave workgroup per CU (BN = 256:
   // 133 KB of LDS) nothing else hides a weight load's ~1.5 us, and a single stage of lookahead (gemm_mainloop's scheme,
   // which relies on 2-5 co-resident workgroups) made every stage as long as that latency: 52 us for the launch.
   constexpr int SPC = 2 * KST;                 // stages per chunk (a multiple of the ring: slots are compile-time)
-  constexpr int RING = BN >= 256 ? 4 : 2, AHEAD = RING - 1;
+#ifndef MST_FFN_DW_RING
+#define MST_FFN_DW_RING 8
+#endif
+  constexpr int RING = DW ? (BN >= 256 ? MST_FFN_DW_RING : 4) : (BN >= 256 ? 4 : 2), AHEAD = RING - 1;
   static_assert(SPC % RING == 0, "ring slots must repeat per chunk");
   u32x4 ring[RING][B_CH];
   auto load_stage = [&](int c, int s, u32x4 (&rb)[B_CH]) {  // (c, s) uniform
-    if (s < KST) {
+#ifdef MST_FFN_DW_FAKE  /* timing experiment only (wrong numbers): what a fragment-ordered weight copy would cost to read */
+    if constexpr (DW) {
+      const T* base = (s < KST ? W1 : W2) + (int64_t)phys(c) * BN * BN + (int64_t)((kstage(s < KST ? s : s - KST) * WGN + wn) * B_CH) * 512 + lane * 8;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + i * 512);
+      return;
+    }
+#endif
+    if (EXTRA && (HEAD ? c < 0 : c >= n_chunks)) {  // the extra GEMM's K stage s
+      const T* base = WX + kstage(s) * BK;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + offx[i]);
+    } else if (s < KST) {
       const T* base = W1 + (int64_t)phys(c) * BN * g1.ldb + kstage(s) * BK;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off1[i]);
@@ -820,9 +920,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   {
     auto pro = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if (j < AHEAD && (j < SPC || n_chunks > 1)) load_stage(j / SPC, j % SPC, ring[j % RING]);
+      if constexpr (HEAD) {
+        static_assert(!HEAD || AHEAD <= KST, "the head GEMM's stages cover the prologue");
+        if (j < AHEAD) load_stage(-1, j, ring[j % RING]);
+      } else {
+        if (j < AHEAD && (j < SPC || n_chunks > 1)) load_stage(j / SPC, j % SPC, ring[j % RING]);
+      }
     };
     pro(std::integral_constant<int, 0>()); pro(std::integral_constant<int, 1>()); pro(std::integral_constant<int, 2>());
+    pro(std::integral_constant<int, 3>()); pro(std::integral_constant<int, 4>()); pro(std::integral_constant<int, 5>());
+    pro(std::integral_constant<int, 6>());
+    static_assert(AHEAD <= 7, "the prologue list covers seven stages");
   }
   if constexpr (LEAD) {
     // ---- the input tile = LayerNorm backward of the incoming gradient (the arithmetic of gemm_epilogue_ln's mode 2 on dy)
@@ -889,7 +997,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     }
     // dgamma / dbeta: the RSTEP row groups summed through LDS (the weight-stage region is not in use yet)
     float* red = reinterpret_cast<float*>(smem);  // [2][RSTEP][BN]
-    static_assert((size_t)2 * RSTEP * BN * 4 <= (size_t)2 * BN * BK * 2, "reduction scratch must fit the weight stages");
+    static_assert((size_t)2 * RSTEP * BN * 4 <= (DW ? (size_t)2 * BM * LDA * 2 : (size_t)2 * BN * BK * 2), "reduction scratch must fit the weight stages");
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[row0 * BN + nc + e] = dg8[e];
@@ -907,18 +1015,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   } else
   // ---- the x tile (rows past M read as zero)
   {
-    const T* X = reinterpret_cast<const T*>(g1.A);
+    // (HEAD: the attention output tile, the extra GEMM's A operand; the block's own input is computed from it below)
+    const T* X = reinterpret_cast<const T*>(HEAD ? gx.A : g1.A);
+    const int64_t ldx = HEAD ? gx.lda : g1.lda;
     constexpr int CPR = BN / 8;
 #pragma unroll
     for (int i = 0; i < BM * CPR / NT; ++i) {
       const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m0 + row < Mg) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * g1.lda + ch * 8);
+      if (m0 + row < Mg) v = *reinterpret_cast<const u32x4*>(X + (m0 + row) * ldx + ch * 8);
       *reinterpret_cast<u32x4*>(sX + row * LDA + ch * 8) = v;
     }
   }
   // one 64-deep K stage: acc += A[64, 64] (LDS tile `sA`, columns k0..) x stage `buf`
-  auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf) {
+  auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf, const u32x4 (&rb)[B_CH]) {
     const u32x4* cB = sB + buf * BN * CHUNKS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
@@ -930,7 +1040,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 16 + frow;
-        wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
+        if constexpr (DW) wf[j] = __builtin_bit_cast(vec8, rb[j * (BK / 32) + ks]);
+        else wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -952,10 +1063,41 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const bool relu1 = g1.act == MST_ACT_RELU;
   T* Aout = reinterpret_cast<T*>(g1.C);
 
-  store_stage(0, ring[0]);
+  // the KST stages of the extra GEMM (stream position `cx`: -1 in front of the chunks, n_chunks behind them) into acc1
+  auto extra_gemm = [&](int cx) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc1[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    store_stage(0, ring[0]);
+    __syncthreads();
+    auto xstage = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < KST) {
+        constexpr int t = s + AHEAD;
+        if constexpr (t < KST) load_stage(cx, t, ring[t % RING]);
+        else if constexpr (HEAD) load_stage(0, t - KST, ring[t % RING]);  // the first chunk's stages follow (KST % RING == 0)
+        mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING]);
+        if constexpr (s + 1 < KST) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+        __syncthreads();
+      }
+    };
+    static_assert(!EXTRA || (KST <= 4 && KST % RING == 0), "the extra GEMM stage list / ring slots");
+    xstage(std::integral_constant<int, 0>()); xstage(std::integral_constant<int, 1>());
+    xstage(std::integral_constant<int, 2>()); xstage(std::integral_constant<int, 3>());
+  };
+  if constexpr (HEAD) {
+    // h1 = epi(att Wp^T) (+ x), x1 = LayerNorm(h1): mst_gemm_nt_ln's forward epilogue; x1 also lands in the x tile
+    extra_gemm(-1);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA);
+    __syncthreads();  // the staging tile (over the weight stages) is dead, the x tile complete
+  }
+  if constexpr (!DW) store_stage(0, ring[0]);
   __syncthreads();  // (also publishes the x tile)
+  T* const sH0 = sH;
   for (int c = 0; c < n_chunks; ++c) {
     const int pc = phys(c);  // the hidden chunk this iteration computes
+    if constexpr (DW) sH = sH0 + (c & 1) * BM * LDA;  // double-buffered: chunk c - 1's readers may still be in their second GEMM
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -978,7 +1120,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         {  // request stage s + AHEAD of the stream (it may belong to the next chunk)
           constexpr int t = s + AHEAD;
           // (unconditional: past the last chunk the clamped load fetches a stage nobody stores)
-          const int tc = t < SPC ? c : (c + 1 < n_chunks ? c + 1 : c);
+          // (TAIL: past the last chunk come the extra GEMM's stages)
+          const int tc = t < SPC ? c : (TAIL || c + 1 < n_chunks ? c + 1 : c);
           load_stage(tc, t % SPC, ring[t % RING]);
         }
 #ifndef MST_FFN_EARLY_STORE
@@ -990,8 +1133,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
           if (s + 1 < SPC || c + 1 < n_chunks) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (s < KST) mma_stage(acc1, sX, kstage(s) * BK, s & 1);
-        else mma_stage(acc2, sH, kstage(s - KST) * BK, s & 1);
+        if constexpr (s < KST) mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING]);
+        else mma_stage(acc2, sH, kstage(s - KST) * BK, s & 1, ring[s % RING]);
         if constexpr (s == KST - 1) {
           // ---- chunk epilogue of GEMM 1, in registers: bias, ReLU, dropout, rounding (the order of gemm_epilogue) -> sH.
           // (The previous chunk's GEMM-2 stages, which read sH, ended with a barrier.)
@@ -1019,8 +1162,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
           }
         }
         // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
-        if (!MST_FFN_EARLY_STORE && (s + 1 < SPC || c + 1 < n_chunks)) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
-        __syncthreads();
+        if constexpr (!DW) {
+          if (!MST_FFN_EARLY_STORE && (s + 1 < SPC || c + 1 < n_chunks)) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+          __syncthreads();
+        } else if constexpr (s == KST - 1) {
+          __syncthreads();  // the chunk is complete in LDS
+        }
         if constexpr (s == KST - 1) {
           // the finished chunk goes out to `a` (the backward pass needs it) as whole 16-byte pieces of rows, while the
           // second GEMM's stages run
@@ -1053,28 +1200,74 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   // ---- the second GEMM's epilogue + LayerNorm: exactly mst_gemm_nt_ln's (staging tile over the dead weight / hidden regions)
   // (a residual that IS the block's input — the encoder's x1 + dropout(ff) — is taken from the x tile in LDS)
   const bool resid_is_x = g2.resid == g1.A && g2.ldr == g1.lda;
-  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA);
+  if constexpr (DW) __syncthreads();  // the staging tile overlays the hidden chunks other waves may still be reading
+  if constexpr (!TAIL) {
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA);
+  } else {
+    // the LayerNorm-1 backward result (masked copy, if any) -> x tile (dead: the residual is read from global memory here),
+    // then datt = that tile x Wp (the transposed shadow, [BN, BN] K-contiguous), stored as 16-bit rows
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA);
+    __syncthreads();  // the reduction scratch (over the weight stages) is dead, the tile complete
+    extra_gemm(n_chunks);
+    constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
+    float* sF = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc1[j][i];
+    __syncthreads();
+    const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = row0 + it * RSTEP;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
+      Pack8 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ob.h[e] = f32_to_bits<T>(v0[e]); ob.h[4 + e] = f32_to_bits<T>(v1[e]); }
+      if (m0 + row < Mg) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(gx.C) + (m0 + row) * gx.ldc + nc) = ob.u;
+    }
+  }
 }
 
 template <typename T, int BN>
-static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, const mst_ln_bwd_in* lead, hipStream_t s) {
+static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, const mst_ln_bwd_in* lead, hipStream_t s,
+                         const mst_gemm_args* gx = nullptr, const mst_ln_args* lnx = nullptr) {
   constexpr int BM = 64;
-  const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2 + (size_t)g1.N * 4, lds_epi = (size_t)BM * (BN + 4) * 4;
+#ifndef MST_FFN_DW_WGN256
+#define MST_FFN_DW_WGN256 8
+#endif
+  constexpr int DWN = BN >= 256 ? MST_FFN_DW_WGN256 : 8;  // waves of the direct-weight form
+  static const int dw_env = getenv("MST_FFN_DW") ? 1 : 0;  // experiment, off: see the DW note above ffn_ln_kernel
+  const int dw = gx ? 0 : dw_env, ex = gx ? 1 : 0;
+  const size_t lds_loop = (dw ? (size_t)3 * BM * (BN + 8) * 2 : (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2) + (size_t)g1.N * 4;
+  const size_t lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   const int full = g1.M % BM == 0 ? 1 : 0;
-  const int mi = (lead ? 2 : (ln.mode == 2 ? 1 : 0)) * 2 + full;
-  typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args, mst_ln_bwd_in);
-  const kern_t fns[6] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true>,
-                         &ffn_ln_kernel<T, BN, 2, 4, 2, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true>,
-                         &ffn_ln_kernel<T, BN, 2, 4, 2, true, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true>};
-  static size_t opted[6] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // LDS each kernel is opted in for
+  const int mi = (dw + 2 * ex) * 6 + (lead ? 2 : (ln.mode == 2 ? 1 : 0)) * 2 + full;
+  typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args, mst_ln_bwd_in, mst_gemm_args, mst_ln_args);
+  const kern_t fns[18] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true>,
+                          &ffn_ln_kernel<T, BN, 2, 4, 2, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true>,
+                          &ffn_ln_kernel<T, BN, 2, 4, 2, true, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true>,
+                          &ffn_ln_kernel<T, BN, 1, DWN, 1, false, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 1, false, true, true>,
+                          &ffn_ln_kernel<T, BN, 1, DWN, 2, false, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 2, false, true, true>,
+                          &ffn_ln_kernel<T, BN, 1, DWN, 2, true, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 2, true, true, true>,
+                          &ffn_ln_kernel<T, BN, 2, 4, 1, false, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true, false, true>,
+                          &ffn_ln_kernel<T, BN, 2, 4, 2, false, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true, false, true>,
+                          &ffn_ln_kernel<T, BN, 2, 4, 2, true, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true, false, true>};
+  static size_t opted[18] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024,
+                             64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // LDS each kernel is opted in for
   if (lds > opted[mi]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
     opted[mi] = lds;
   }
-  mst_ln_bwd_in none = {};
-  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln, lead ? *lead : none);
+  const mst_ln_bwd_in none = {};
+  const mst_gemm_args no_gemm = {};
+  const mst_ln_args no_ln = {};
+  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(dw ? DWN * 64 : 512), lds, s, g1, g2, ln, lead ? *lead : none,
+                     gx ? *gx : no_gemm, lnx ? *lnx : no_ln);
   MST_CHECK_LAUNCH("ffn_ln_kernel");
   return MST_OK;
 }
@@ -1121,16 +1314,23 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
                                  (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
   const bool drop = a.dropout_p > 0.f || a.self_resid;
   // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
-  const int variant = a.a_u8 ? (fast ? 8 : 9) : (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
+  // (measured, in-call A/B at configs[1]: 0.787 ms per step with the direct form on its 8 eligible launches against 0.783
+  // with the staged one — 8-byte accesses in accumulator layout lose to 16-byte row-contiguous ones by more than the LDS
+  // round trip costs; kept behind MST_GEMM_DIRECT=1)
+  static const bool direct_ok = getenv("MST_GEMM_DIRECT") && getenv("MST_GEMM_DIRECT")[0] == '1';
+  const bool direct = direct_ok && fast && !drop && !rowops && !a.a_u8 && (!a.bias || (uintptr_t)a.bias % 16 == 0);
+  const int variant = direct ? 10 : a.a_u8 ? (fast ? 8 : 9) : (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
   typedef void (*kern_t)(mst_gemm_args);
   // [8], [9]: uint8 A operand (the piano-roll embedding GEMMs: row ops, 16-bit C, no dropout), fast / general
-  const kern_t fns[10] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
+  // [10]: the direct epilogue (no LDS staging)
+  const kern_t fns[11] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2, true>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, false, true>};
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, false, true>,
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 3, false>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[10] = {false, false, false, false, false, false, false, false, false, false};
+    static bool opted[11] = {false, false, false, false, false, false, false, false, false, false, false};
     if (!opted[variant]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
@@ -1162,7 +1362,8 @@ static int check_gemm_common(const mst_gemm_args& a) {
 extern "C" int64_t mst_gemm_nt_ln_parts(int64_t M) { return M > 0 ? cdiv(M, 64) : 0; }  // launch_gemm_ln's 64-row tiles
 
 static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_gemm_args* second, const mst_ln_args* ln, int mode,
-                       mst_stream_t stream, const mst_ln_bwd_in* lead = nullptr) {
+                       mst_stream_t stream, const mst_ln_bwd_in* lead = nullptr, const mst_gemm_args* extra = nullptr,
+                       const mst_ln_args* extra_ln = nullptr) {
   MST_CHECK_ARG(first != nullptr && second != nullptr && ln != nullptr, "%s: null args", who);
   const mst_gemm_args& a = *first;
   const mst_gemm_args& b = *second;
@@ -1211,12 +1412,44 @@ static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_ge
     const int64_t tile_ld = q.mask_mode == 1 ? q.ld_dxm : q.ld_dx;
     MST_CHECK_ARG(a.A == tile && a.lda == tile_ld, "%s: the first GEMM's A operand must be the leading LayerNorm's (masked) output", who);
   }
+  if (extra) {
+    const mst_gemm_args& x = *extra;
+    rc = check_gemm_common(x);
+    if (rc) return rc;
+    MST_CHECK_ARG(x.dtype == a.dtype && x.M == a.M && x.N == b.N && x.K == b.N, "%s: the extra GEMM is width x width on the same rows", who);
+    MST_CHECK_ARG(!x.c_f32 && !x.gate && !x.rowadd && !x.grpadd && x.act == MST_ACT_NONE && x.a_rows_per_group <= 0 && x.c_rows_per_group <= 0 &&
+                  x.ldc % 8 == 0 && x.ldc >= x.N && (uint64_t)x.N * (uint64_t)x.ldb < (1ull << 32),
+                  "%s: the extra GEMM takes no gate, activation, row-indexed add or row remap", who);
+    if (mode == 1) {
+      MST_CHECK_ARG(extra_ln != nullptr, "%s: the projection needs its LayerNorm", who);
+      const mst_ln_args& q = *extra_ln;
+      MST_CHECK_ARG(q.mode == 1 && q.gamma && q.beta && q.mean && q.rstd && q.out == a.A && q.ld_out == a.lda,
+                    "%s: the leading LayerNorm's output must be the first GEMM's A operand", who);
+      MST_CHECK_ARG(!x.resid || (x.ldr % 8 == 0 && x.ldr >= x.N && (uintptr_t)x.resid % 16 == 0), "%s: bad residual layout", who);
+    } else {
+      const void* tile = l.mask_mode == 1 ? l.out : b.C;
+      const int64_t tile_ld = l.mask_mode == 1 ? l.ld_out : b.ldc;
+      MST_CHECK_ARG(x.A == tile && x.lda == tile_ld, "%s: the trailing GEMM's A operand must be the LayerNorm backward's (masked) result", who);
+      MST_CHECK_ARG(!x.bias && !x.resid && !x.self_resid && x.dropout_p == 0.f && x.alpha == 1.f, "%s: the trailing GEMM is a plain product", who);
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, lead, s);
-    return launch_ffn_ln<T, 128>(a, b, l, lead, s);
+    if (b.N == 256) return launch_ffn_ln<T, 256>(a, b, l, lead, s, extra, extra_ln);
+    return launch_ffn_ln<T, 128>(a, b, l, lead, s, extra, extra_ln);
   });
+}
+
+extern "C" int mst_proj_ffn_ln_fwd(const mst_gemm_args* proj, const mst_ln_args* ln1, const mst_gemm_args* ff1, const mst_gemm_args* ff2,
+                                   const mst_ln_args* ln2, mst_stream_t stream) {
+  MST_CHECK_ARG(proj != nullptr && ln1 != nullptr, "mst_proj_ffn_ln_fwd: null args");
+  return ffn_ln_impl("mst_proj_ffn_ln_fwd", ff1, ff2, ln2, 1, stream, nullptr, proj, ln1);
+}
+extern "C" int mst_ffn_ln_bwd_tail(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
+                                   const mst_ln_args* ln, const mst_gemm_args* proj_dgrad, mst_stream_t stream) {
+  MST_CHECK_ARG(proj_dgrad != nullptr, "mst_ffn_ln_bwd_tail: null args");
+  return ffn_ln_impl("mst_ffn_ln_bwd_tail", ff2_dgrad, ff1_dgrad, ln, 2, stream, lead, proj_dgrad);
 }
 
 extern "C" int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,

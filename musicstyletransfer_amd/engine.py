@@ -16,6 +16,7 @@ There is no torch autograd, no torch operator and no CPU fallback on this path: 
 out by hand below, mirroring the forward line by line.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -382,6 +383,11 @@ class StepPlan:
         self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
         # output layer + BCE in one launch when a tile can hold whole rows of pitches of one sample (configs[1]: P 128, T 256)
         self.fuse_bce = cfg.kind == "pianoroll" and o.can_fuse_bce(cfg.out_dim, T)
+        # the attention output projection inside the feed-forward launches: "head" = W_proj + LayerNorm-1 in front of the
+        # forward block (two launches less per layer at equal time), "all" = also its dgrad behind the backward block
+        # (measured slower: +14 us on a launch that is already one latency-bound workgroup per CU), "0" = neither
+        fp = os.environ.get("MST_FUSE_PROJ", "head")
+        self.fuse_proj, self.fuse_proj_bwd = fp != "0", fp == "all"
         self.logits = None if self.fuse_bce else act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
         if cfg.kind == "token":
@@ -578,17 +584,23 @@ class StepPlan:
         # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
         # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM
         # as much. The backward forms, where the LayerNorm launch is 16 us, do pay: _layer_bwd.)
-        o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
-                  resid=x_in, **self._drop(p, site0))
-        o.layernorm_fwd(L.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), L.x1, L.mean1, L.rstd1, D=D)
+        proj = dict(N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"), resid=x_in, **self._drop(p, site0))
+        fused = o.ffn_fusion_pays(D, 4 * D)
+        if not (fused and self.fuse_proj):
+            o.gemm_nt(L.att, st.h(f"{pre}.att.W_proj.weight"), L.h1, **proj)
+            o.layernorm_fwd(L.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), L.x1, L.mean1, L.rstd1, D=D)
         ff1 = dict(K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **self._drop(p, site0 + 1))
         # encoder: LN2(x1 + dropout(ff)); decoder (transformer.py:199-200): LN3(ff + dropout(ff))
         ln = "ln2" if side == "encoder" else "ln3"
         ff2 = dict(K=4 * D, bias=st.p(f"{pre}.ff2.bias"), **self._drop(p, site0 + 2))
         ff2.update(dict(resid=L.x1) if side == "encoder" else dict(self_resid=True))
-        if o.ffn_fusion_pays(D, 4 * D):  # the whole feed-forward block + LayerNorm in one launch (same results, bit for bit in a / h2)
+        if fused:  # the whole feed-forward block + LayerNorm in one launch (same results, bit for bit in a / h2)
+            head = None
+            if self.fuse_proj:  # ... and the attention output projection + LayerNorm-1 in front of it (mst_proj_ffn_ln_fwd)
+                head = dict(att=L.att, W=st.h(f"{pre}.att.W_proj.weight"), h1=L.h1, gamma=st.p(f"{pre}.ln1.gamma"),
+                            beta=st.p(f"{pre}.ln1.beta"), mean=L.mean1, rstd=L.rstd1, **proj)
             o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.{ln}.gamma"),
-                         st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, ff1=ff1, ff2=ff2)
+                         st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, ff1=ff1, ff2=ff2, proj=head)
             return L.x2
         o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, **ff1)
         o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, **ff2)
@@ -743,10 +755,14 @@ class StepPlan:
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
         ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
+        proj_done = False
         if ffn_fused:  # both dgrads of the block + LayerNorm-1 backward in one launch (mst_ffn_ln_bwd)
+            # ... and the attention output projection's dgrad behind them (mst_ffn_ln_bwd_tail)
+            tail = (st.t(f"{pre}.att.W_proj.weight"), t.datt) if self.fuse_proj_bwd else None
+            proj_done = tail is not None
             o.ffn_ln_bwd(dff, st.t(f"{pre}.ff2.weight"), t.dpre, L.a, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"),
                          L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), alpha=inv_keep, resid=resid_ff,
-                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), lead=lead, **ln1)
+                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), lead=lead, tail=tail, **ln1)
         else:
             o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
             if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
@@ -759,7 +775,8 @@ class StepPlan:
                                 st.grad(f"{pre}.ln1.beta"), D=D, partials=self._ln_partials(f"{pre}.ln1", o.layernorm_bwd_parts(M, D)),
                                 **ln1)
         dproj = t.dh1m if p > 0 else t.dh1
-        o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
+        if not proj_done:
+            o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
         if next_ln is not None:  # the layer below starts its backward pass with a LayerNorm backward: run it here
             kw, t_below = next_ln

@@ -160,25 +160,39 @@ def ffn_fusion_pays(D, F):
     return can_fuse_ffn(D, F)
 
 
-def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5, ff1=None, ff2=None):
+def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5, ff1=None, ff2=None, proj=None):
     """a_out = epilogue1(x @ W1^T), h_out = epilogue2(a_out @ W2^T), y_out = LayerNorm(h_out) in one launch
-    (mst_ffn_ln_fwd); ff1 / ff2: the keyword arguments gemm_nt would get for the two GEMMs"""
+    (mst_ffn_ln_fwd); ff1 / ff2: the keyword arguments gemm_nt would get for the two GEMMs.
+    proj: dict(att, W, h1, gamma, beta, mean, rstd, **gemm_nt keywords) -> the attention output projection and its
+    LayerNorm run in front, in the same launch (mst_proj_ffn_ln_fwd): h1 = epilogue(att @ W^T), x = LayerNorm(h1) (x is then
+    an OUTPUT as well as the block's input)"""
     g1 = _gemm_args(x, W1, a_out, **(ff1 or {}))
     g2 = _gemm_args(a_out, W2, h_out, **(ff2 or {}))
     l = LnArgs()
     l.mode, l.gamma, l.beta, l.eps = 1, ptr(gamma), ptr(beta), eps
     l.out, l.ld_out = ptr(y_out), ld(y_out)
     l.mean, l.rstd = ptr(mean), ptr(rstd)
-    call("mst_ffn_ln_fwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+    if proj is None:
+        call("mst_ffn_ln_fwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+        return
+    kw = {k: v for k, v in proj.items() if k not in ("att", "W", "h1", "gamma", "beta", "mean", "rstd")}
+    g0 = _gemm_args(proj["att"], proj["W"], proj["h1"], **kw)
+    l0 = LnArgs()
+    l0.mode, l0.gamma, l0.beta, l0.eps = 1, ptr(proj["gamma"]), ptr(proj["beta"]), eps
+    l0.out, l0.ld_out = ptr(x), ld(x)
+    l0.mean, l0.rstd = ptr(proj["mean"]), ptr(proj["rstd"])
+    call("mst_proj_ffn_ln_fwd", C.byref(g0), C.byref(l0), C.byref(g1), C.byref(g2), C.byref(l), stream())
 
 
 def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgamma, dbeta, alpha=1.0, dx_masked=None, mask_mode=0,
-               partials=None, lead=None, **kw):
+               partials=None, lead=None, tail=None, **kw):
     """dpre_out = ((dff @ W2t^T) * alpha) gated by gate > 0; dx_out = LayerNorm-backward(dpre_out @ W1t^T + resid; x, mean, rstd,
     gamma) in one launch (mst_ffn_ln_bwd). W2t / W1t: the transposed 16-bit weights ([F, D] and [D, F]); **kw: resid and the
     dropout fields of the LayerNorm-backward mask, as for gemm_nt_ln_bwd.
     lead: dict(dy, x, gamma, mean, rstd, dx, [dx_masked, dropout_*], [dgamma, dbeta | partials]) -> the layer's leading
-    LayerNorm backward runs in the prologue (mst_ffn_ln_bwd_lead); dff must then be lead's dx_masked (or dx)"""
+    LayerNorm backward runs in the prologue (mst_ffn_ln_bwd_lead); dff must then be lead's dx_masked (or dx).
+    tail: (Wt, datt_out) -> datt_out = (dx_masked if mask_mode == 1 else dx_out) @ Wt^T, the attention output projection's
+    dgrad, in the same launch (mst_ffn_ln_bwd_tail)"""
     g1 = _gemm_args(dff, W2t, dpre_out, gate=gate, alpha=alpha)
     g2 = _gemm_args(dpre_out, W1t, dx_out, **kw)
     l = LnArgs()
@@ -191,8 +205,15 @@ def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgam
     l.partials = ptr(partials)
     if partials is not None:
         assert partials.shape[0] >= gemm_nt_ln_parts(g1.M) and partials.shape[1] == 2 * g2.N and partials.is_contiguous()
+    gt = None
+    if tail is not None:
+        src = dx_masked if mask_mode == 1 else dx_out
+        gt = _gemm_args(src, tail[0], tail[1], N=g2.N, K=g2.N)
     if lead is None:
-        call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+        if gt is not None:
+            call("mst_ffn_ln_bwd_tail", None, C.byref(g1), C.byref(g2), C.byref(l), C.byref(gt), stream())
+        else:
+            call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
         return
     q = LnBwdIn()
     q.dy, q.ld_dy = ptr(lead["dy"]), ld(lead["dy"])
@@ -207,7 +228,10 @@ def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgam
     q.dropout_seed_ptr, q.dropout_site = ptr(lead.get("dropout_seed_ptr")), lead.get("dropout_site", 0)
     if lead.get("partials") is not None:
         assert lead["partials"].shape[0] >= gemm_nt_ln_parts(g1.M) and lead["partials"].shape[1] == 2 * g2.N
-    call("mst_ffn_ln_bwd_lead", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), stream())
+    if gt is not None:
+        call("mst_ffn_ln_bwd_tail", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), C.byref(gt), stream())
+    else:
+        call("mst_ffn_ln_bwd_lead", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), stream())
 
 
 def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):

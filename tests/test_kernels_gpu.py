@@ -365,6 +365,85 @@ def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
     assert ((y1 != y0).float().mean().item()) < 5e-2
 
 
+@pytest.mark.parametrize("M,D,F,p", [(16384, 256, 1024, 0.2), (16448, 128, 512, 0.2), (200, 256, 512, 0.0), (77, 128, 128, 0.1)])
+def test_proj_ffn_ln_fwd_equals_projection_then_block(gpu, M, D, F, p):
+    """mst_proj_ffn_ln_fwd == mst_gemm_nt_ln(proj, ln1) + mst_ffn_ln_fwd, bit for bit in every output (h1, x1 and its
+    statistics, hidden activation, pre-norm tensor, block output): the same epilogue code, the same MFMA order"""
+    o = ops()
+    att, xin = rnd((M, D), gpu, seed=420), rnd((M, D), gpu, seed=421)
+    Wp = rnd((D, D), gpu, seed=422, scale=0.06)
+    W1, W2 = rnd((F, D), gpu, seed=401, scale=0.06), rnd((D, F), gpu, seed=402, scale=0.03)
+    bp = rnd((D,), gpu, dtype=torch.float32, seed=423, scale=0.1)
+    b1, b2 = rnd((F,), gpu, dtype=torch.float32, seed=403, scale=0.1), rnd((D,), gpu, dtype=torch.float32, seed=404, scale=0.1)
+    g1, be1 = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=424), rnd((D,), gpu, dtype=torch.float32, seed=425, scale=0.1)
+    g2, be2 = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=405), rnd((D,), gpu, dtype=torch.float32, seed=406, scale=0.1)
+    seedp = torch.tensor([55, 0, 0, 0], dtype=torch.int64, device=gpu)
+    dk = lambda site: dict(dropout_p=p, dropout_seed_ptr=seedp, dropout_site=site) if p > 0 else {}
+    proj = dict(N=D, K=D, bias=bp, resid=xin, **dk(3))
+    ff1 = dict(K=D, bias=b1, act=o.ACT_RELU, **dk(4))
+    res = []
+    for fused in (False, True):
+        h1, x1 = torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+        a, h2, y = torch.zeros(M, F, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+        m1, r1, m2, r2 = (torch.zeros(M, device=gpu) for _ in range(4))
+        ff2 = dict(K=F, bias=b2, resid=x1, **dk(5))
+        if fused:
+            o.ffn_ln_fwd(x1, W1, a, W2, h2, g2, be2, y, m2, r2, ff1=ff1, ff2=ff2,
+                         proj=dict(att=att, W=Wp, h1=h1, gamma=g1, beta=be1, mean=m1, rstd=r1, **proj))
+        else:
+            o.gemm_nt_ln_fwd(att, Wp, h1, g1, be1, x1, m1, r1, **proj)
+            o.ffn_ln_fwd(x1, W1, a, W2, h2, g2, be2, y, m2, r2, ff1=ff1, ff2=ff2)
+        torch.cuda.synchronize()
+        res.append((h1, x1, m1, r1, a, h2, y, m2, r2))
+    for name, u, v in zip(("h1", "x1", "mean1", "rstd1", "a", "h2", "y", "mean2", "rstd2"), res[0], res[1]):
+        assert torch.equal(u, v), name
+    # ... and the unfused projection GEMM gives the same h1
+    h1u = torch.zeros(M, D, dtype=BF, device=gpu)
+    o.gemm_nt(att, Wp, h1u, **proj)
+    torch.cuda.synchronize()
+    assert torch.equal(h1u, res[1][0])
+
+
+@pytest.mark.parametrize("M,D,F,mode,lead", [(16384, 256, 1024, 1, True), (16448, 128, 512, 1, False), (200, 256, 512, 0, False),
+                                               (77, 128, 128, 1, True)])
+def test_ffn_ln_bwd_tail_equals_block_then_projection_dgrad(gpu, M, D, F, mode, lead):
+    """mst_ffn_ln_bwd_tail == mst_ffn_ln_bwd(_lead) + mst_gemm_nt(datt = d(h1)[masked] Wp): every output bit for bit"""
+    o = ops()
+    dff, gate = rnd((M, D), gpu, seed=500, scale=0.5), rnd((M, F), gpu, seed=501)
+    W2t, W1t, Wpt = rnd((F, D), gpu, seed=502, scale=0.05), rnd((D, F), gpu, seed=503, scale=0.05), rnd((D, D), gpu, seed=520, scale=0.06)
+    x = rnd((M, D), gpu, seed=505)
+    gam = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=506)
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    seedp = torch.tensor([91, 0, 0, 0], dtype=torch.int64, device=gpu)
+    drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2) if mode else {}
+    dyin, xin = rnd((M, D), gpu, seed=507), rnd((M, D), gpu, seed=508, scale=1.5)
+    gin = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=509)
+    mean_in, rstd_in = xin.float().mean(1), 1.0 / torch.sqrt(xin.float().var(1, unbiased=False) + 1e-5)
+    parts = o.gemm_nt_ln_parts(M)
+    res = []
+    for fused in (False, True):
+        dh, dhm = torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+        dpre, dx, dxm = torch.zeros(M, F, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
+        datt = torch.zeros(M, D, dtype=BF, device=gpu)
+        dg, db = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+        part, pin = torch.zeros(parts, 2 * D, device=gpu), torch.zeros(parts, 2 * D, device=gpu)
+        kw = dict(alpha=1.25, dx_masked=dxm if mode == 1 else None, mask_mode=mode, partials=part, **drop)
+        if lead:
+            kw.update(resid=dh, lead=dict(dy=dyin, x=xin, gamma=gin, mean=mean_in, rstd=rstd_in, dx=dh, dx_masked=dhm, partials=pin,
+                                          dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=7))
+        a_op = dhm if lead else dff
+        if fused:
+            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, tail=(Wpt, datt), **kw)
+        else:
+            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, **kw)
+            o.gemm_nt(dxm if mode == 1 else dx, Wpt, datt, N=D, K=D)
+        torch.cuda.synchronize()
+        res.append((dpre, dx, dxm, datt, part, pin, dh, dhm))
+    for name, u, v in zip(("dpre", "dx", "dx masked", "datt", "partials", "lead partials", "lead dx", "lead dx masked"), res[0], res[1]):
+        assert torch.equal(u, v), name
+    assert res[1][3].float().abs().max().item() > 0
+
+
 @pytest.mark.parametrize("M,D,F,mode,with_resid", [(16384, 256, 1024, 1, True), (16448, 128, 512, 2, False), (200, 256, 512, 0, True),
                                                      (77, 128, 128, 1, True)])
 def test_ffn_ln_bwd_equals_the_separate_launches(gpu, M, D, F, mode, with_resid):
