@@ -42,6 +42,21 @@ __device__ __forceinline__ i16x4 tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(uintptr_t)p);
 }
 
+// (Direct global -> LDS staging — global_load_lds_dwordx4 into an image of 1-KiB slots + 32 B of pad, two buffers, one stage
+// ahead — was built and measured: stamps of one workgroup showed the MFMA phase of a stage going from 0.95 to 1.85 us while
+// the LDS-DMA writes of the next stage land, 3.1 us per stage against 2.65 for the register-staged loop. Removed; what did
+// pay is the interleaved register staging in wgrad_body.)
+// diagnostic build only (-DMST_WGRAD_STAMPS): one workgroup leaves s_memtime stamps per stage (tools/bench_wgrad_stamps.py)
+#ifdef MST_WGRAD_STAMPS
+#ifndef MST_WGRAD_STAMP_WG
+#define MST_WGRAD_STAMP_WG 64
+#endif
+__device__ uint64_t g_wgrad_stamps[4 + 64 * 4];
+#define WG_STAMP(slot) do { if (blockIdx.x == MST_WGRAD_STAMP_WG && threadIdx.x == 0 && (slot) < 4 + 64 * 4) g_wgrad_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STAMP(slot) do { } while (0)
+#endif
+
 // AU8: this problem's A operand is uint8 (mst_wgrad_args.a_u8). A template switch on purpose: the 256x256 form sits at
 // exactly 256 VGPRs, and a run-time branch in the stage loop (an extra register array, or partial-register updates)
 // cost EVERY problem of the launch (92 -> 160 us for the step's batch); as two bodies in one kernel the 16-bit problems
@@ -213,15 +228,138 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
   // a second register set, 256 VGPRs — measured the same 58 us on the 128x128 tiles: the stage time, ~2.2 us for 0.25 us
   // of MFMA work per wave, is not a latency that more loads in flight would hide; what did move it was fewer operand
   // bytes per FLOP — the 256x128 and 256x256 tiles of launch_wgrad.)
+  // ---- interleaved register staging (slabs of whole 64-row stages; row remaps in groups of >= 64 rows).
+  // Stamps of one workgroup of the whole-step launch (tools/bench_wgrad_stamps.py) showed the stage as a SUM of phases:
+  // 0.89 us issuing the 8 loads of the next stage (the wave stalls on the memory pipeline's back-pressure while the MFMA
+  // pipe idles — both waves of a SIMD do the same thing at the same time), 0.95 us of MFMAs, 0.41 us waiting for the loads
+  // and writing them to LDS, 0.19 us barrier. Here the staging is cut into 8 pieces — { ds_write chunk p of stage t+1 (in
+  // registers since the previous stage), reload the register with chunk p of stage t+2 } — placed between the 8 MFMA groups
+  // of stage t: a stalled load issue of one wave overlaps the other wave's MFMAs, the loads get a whole stage to arrive, and
+  // nothing but the barrier separates the last MFMA of a stage from the first of the next.
+#ifndef MST_WGRAD_IL
+#define MST_WGRAD_IL 1
+#endif
+  bool done_il = false;
+  if constexpr (MST_WGRAD_IL && TN * (BMR / 32) == A_CH + B_CH) {
+    if ((m_end - m_begin) % BMR == 0 && !div_a && !div_b) {
+      done_il = true;
+      // every load is unconditional: a chunk beyond N / K reads the tile's first column instead and is zeroed when it is
+      // written to LDS; past the last stage the loads repeat the last one (a conditional load costs a vmcnt(0) drain)
+      const int a_cc = a_ok ? a_c : 0, b_cc = b_ok ? b_c : 0;
+      int64_t pa = pa0, oa = oa0, pb = pb0, ob = ob0;  // remapped operands: physical row / offset in its group of the thread's first chunk
+      int64_t mb_next = m_begin, loaded = 0;           // the stage the next loads fetch
+      auto ld = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < A_CH) {
+          constexpr int r = p * A_RSTEP;
+          const int64_t pm = remap_a ? pa + r + ((oa + r >= a.a_rows_per_group) ? a.a_group_stride - a.a_rows_per_group : 0) : mb_next + a_r0 + r;
+          ra[p] = *reinterpret_cast<const RA*>(A + pm * a.lda + n0 + a_cc);
+        } else {
+          constexpr int r = (p - A_CH) * B_RSTEP;
+          const int64_t pm = remap_b ? pb + r + ((ob + r >= a.b_rows_per_group) ? a.b_group_stride - a.b_rows_per_group : 0) : mb_next + b_r0 + r;
+          rb[p - A_CH] = *reinterpret_cast<const u32x4*>(B + pm * a.ldb + k0 + b_cc);
+        }
+      };
+      auto advance = [&]() {  // (uniform)
+        if (loaded + 1 < nsteps) {
+          ++loaded; mb_next += BMR;
+          if (remap_a) { oa += BMR; pa += BMR; if (oa >= a.a_rows_per_group) { oa -= a.a_rows_per_group; pa += a.a_group_stride - a.a_rows_per_group; } }
+          if (remap_b) { ob += BMR; pb += BMR; if (ob >= a.b_rows_per_group) { ob -= a.b_rows_per_group; pb += a.b_group_stride - a.b_rows_per_group; } }
+        }
+      };
+      auto st = [&](auto pc, int buf) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < A_CH) {
+          u32x4 v;
+          if constexpr (AU8) v = expand_u8x8<T>(ra[p]); else v = ra[p];
+          *reinterpret_cast<u32x4*>(wA + buf * BMR * LDA_S + p * A_RSTEP * LDA_S) = a_ok ? v : zero4;
+        } else {
+          *reinterpret_cast<u32x4*>(wB + buf * BMR * LDB_S + (p - A_CH) * B_RSTEP * LDB_S) = b_ok ? rb[p - A_CH] : zero4;
+        }
+      };
+      auto all_pieces = [&](auto&& f) {
+        f(std::integral_constant<int, 0>()); f(std::integral_constant<int, 1>()); f(std::integral_constant<int, 2>()); f(std::integral_constant<int, 3>());
+        if constexpr (A_CH + B_CH > 4) {
+          f(std::integral_constant<int, 4>()); f(std::integral_constant<int, 5>()); f(std::integral_constant<int, 6>()); f(std::integral_constant<int, 7>());
+        }
+      };
+      static_assert(A_CH + B_CH == 4 || A_CH + B_CH == 8, "piece list");
+      WG_STAMP(0);
+      all_pieces([&](auto pc) { ld(pc); });
+      advance();
+      all_pieces([&](auto pc) { st(pc, 0); });
+      all_pieces([&](auto pc) { ld(pc); });
+      advance();
+      __syncthreads();
+      WG_STAMP(1);
+      for (int64_t t = 0; t < nsteps; ++t) {
+        const int cur = (int)(t & 1);
+        const T* cA = fA + cur * BMR * LDA_S;
+        const T* cB = fB + cur * BMR * LDB_S;
+        WG_STAMP(4 + (int)t * 4);
+        auto half = [&](auto msc) {
+          constexpr int ms = decltype(msc)::value;
+          vec8 af[TN], bf[TK];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const i16x4 lo = tr_read(cA + (ms * 32) * LDA_S + j * 16);
+            const i16x4 hi = tr_read(cA + (ms * 32 + 16) * LDA_S + j * 16);
+            const i16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            af[j] = __builtin_bit_cast(vec8, w);
+          }
+#pragma unroll
+          for (int i = 0; i < TK; ++i) {
+            const i16x4 lo = tr_read(cB + (ms * 32) * LDB_S + i * 16);
+            const i16x4 hi = tr_read(cB + (ms * 32 + 16) * LDB_S + i * 16);
+            const i16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf[i] = __builtin_bit_cast(vec8, w);
+          }
+          auto group = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < TN) {
+#pragma unroll
+              for (int i = 0; i < TK; ++i) acc[j][i] = Act<T>::mfma16(af[j], bf[i], acc[j][i]);
+              if (bias_wave) acc_b[j] = Act<T>::mfma16(af[j], ones, acc_b[j]);
+              __builtin_amdgcn_sched_barrier(0);
+              st(std::integral_constant<int, ms * TN + j>(), cur ^ 1);
+              ld(std::integral_constant<int, ms * TN + j>());
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          static_assert(TN <= 4, "the group list covers four rows of MFMAs");
+          group(std::integral_constant<int, 0>()); group(std::integral_constant<int, 1>());
+          group(std::integral_constant<int, 2>()); group(std::integral_constant<int, 3>());
+        };
+        static_assert(BMR / 32 == 2, "two k-steps per stage");
+        half(std::integral_constant<int, 0>());
+        half(std::integral_constant<int, 1>());
+        advance();
+        WG_STAMP(4 + (int)t * 4 + 1);
+        WG_STAMP(4 + (int)t * 4 + 2);
+        __syncthreads();
+        WG_STAMP(4 + (int)t * 4 + 3);
+      }
+      WG_STAMP(2);
+    }
+  }
+  if (!done_il) {
+  WG_STAMP(0);
   load_tile(m_begin);
   store_tile(0);
   __syncthreads();
+  WG_STAMP(1);
   for (int64_t t = 0; t < nsteps; ++t) {
     const int cur = (int)(t & 1);
     if (t + 1 < nsteps) load_tile(m_begin + (t + 1) * BMR);
+    WG_STAMP(4 + (int)t * 4);
     compute(cur);
+    WG_STAMP(4 + (int)t * 4 + 1);
     if (t + 1 < nsteps) store_tile(cur ^ 1);
+    WG_STAMP(4 + (int)t * 4 + 2);
     __syncthreads();
+    WG_STAMP(4 + (int)t * 4 + 3);
+  }
+  WG_STAMP(2);
   }
 
   // D[row = n (4*(lane>>4)+r)][col = k (lane&15)].
@@ -276,6 +414,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
         if (n < a.N) atomicAdd(a.db + n, acc_b[j][r] * a.scale);
       }
   }
+  WG_STAMP(3);
 }
 
 template <typename T, int BN, int BKO, int WGN, int WGK>
@@ -496,3 +635,9 @@ extern "C" int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr, "mst_gemm_wgrad: null args");
   return mst_gemm_wgrad_batch(args, 1, stream);
 }
+
+#ifdef MST_WGRAD_STAMPS
+extern "C" int mst_debug_wgrad_stamps(uint64_t* host_out) {  // diagnostic builds only
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_wgrad_stamps), sizeof(uint64_t) * (4 + 64 * 4)) == hipSuccess ? 0 : -1;
+}
+#endif
