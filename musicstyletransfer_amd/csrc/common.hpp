@@ -96,16 +96,38 @@ template <typename T> __device__ __forceinline__ u32x4 expand_u8x8(u32x2 raw) {
   return p.u;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions over aligned groups of LANES lanes; every lane ends with the group's value. Levels 1..8 are DPP
+// operands of the add itself (quad_perm, then row_half_mirror / row_mirror, which pair up the already-uniform quads / octets),
+// level 16 is one ds_swizzle, level 32 one ds_bpermute. (As __shfl_xor butterflies every level was a ds_bpermute_b32 with
+// its address arithmetic and LDS-crossbar latency: the LayerNorm epilogue of ffn_ln_kernel spent 7.5 of its 9.5 us in
+// ten dependent ones per row.)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_xor16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // swizzle(SWAP, 16)
+}
+template <int LANES> __device__ __forceinline__ float group_sum(float v) {
+  static_assert(LANES == 4 || LANES == 8 || LANES == 16 || LANES == 32 || LANES == 64, "group size");
+  v += dpp_mov<0xB1>(v);                              // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);                              // quad_perm [2,3,0,1]
+  if constexpr (LANES >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if constexpr (LANES >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+  if constexpr (LANES >= 32) v += lane_xor16(v);
+  if constexpr (LANES >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int LANES> __device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  if constexpr (LANES >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if constexpr (LANES >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  if constexpr (LANES >= 32) v = fmaxf(v, lane_xor16(v));
+  if constexpr (LANES >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
 // logical → physical row remap (see mst_gemm_args)
 __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t rpg, int64_t stride, int64_t off) {

@@ -478,12 +478,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
 // Supported epilogue features: bias, alpha, dropout / self_resid, residual, C row remap (the others are rejected on the
 // host). One thread finishes 8 columns of a row; the N/8 threads of a row are consecutive lanes, so row sums are
 // xor-shuffles inside a 32- or 16-lane group.
+// diagnostic build only (-DMST_FFN_STAMPS): one workgroup leaves s_memtime stamps per stage (tools/bench_ffn_stamps.py)
+#ifdef MST_FFN_STAMPS
+__device__ uint64_t g_ffn_stamps[8 + 48 * 4];  // [0..3] kernel phases, [5..7] LayerNorm epilogue, [8 + 4k..] stage k, [190, 191] realtime
+#define FFN_STAMP(slot) do { if (blockIdx.x == 64 && threadIdx.x == 0 && (slot) < 8 + 48 * 4) g_ffn_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FFN_RT(slot) do { if (blockIdx.x == 64 && threadIdx.x == 0) g_ffn_stamps[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FFN_STAMP(slot) do { } while (0)
+#define FFN_RT(slot) do { } while (0)
+#endif
 template <int LANES>
-__device__ __forceinline__ float row_sum(float v) {
-#pragma unroll
-  for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float row_sum(float v) { return group_sum<LANES>(v); }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
@@ -510,6 +515,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
     for (int j = 0; j < TN; ++j)
       *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
   __syncthreads();
+  FFN_STAMP(5);
 
   const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
   const float inv_n = 1.f / (float)BN;
@@ -548,6 +554,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
       }
     }
   }
+  FFN_STAMP(6);
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int row = row0 + it * RSTEP;
@@ -638,6 +645,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
       *reinterpret_cast<u32x4*>(lds_out + row * lds_out_ld + nc) = u32x4{0u, 0u, 0u, 0u};
     }
   }
+  FFN_STAMP(7);
   if (MODE == 2) {
     // dgamma / dbeta: sum the RSTEP row groups through LDS (the staged tile is dead), one atomic per column per workgroup
     __syncthreads();
@@ -841,6 +849,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t F = g1.N;
+  FFN_STAMP(0); FFN_RT(190);
   const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
   for (int i = tid * 4; i < (int)F; i += NT * 4)
     *reinterpret_cast<f32x4*>(sBias1 + i) = g1.bias ? *reinterpret_cast<const f32x4*>(g1.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -851,6 +860,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   // than the three-launch form; `a` itself is unchanged).
 #ifndef MST_FFN_ROT
 #define MST_FFN_ROT 1
+#endif
+#ifndef MST_FFN_EARLY_STORE
+#define MST_FFN_EARLY_STORE 0  /* measured 43.9 vs 42.6 us at width 256: slower, kept as a switch */
 #endif
   const int rot = MST_FFN_ROT ? (int)((blockIdx.x / 8) % (unsigned)n_chunks) : 0;
   auto phys = [&](int c) { const int pc = c + rot; return pc >= n_chunks ? pc - n_chunks : pc; };
@@ -911,6 +923,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + off2[i]);
     }
+  };
+  auto load_piece = [&](int c, int s, u32x4 (&rb)[B_CH], auto ic) {  // one 16-byte piece of load_stage
+    constexpr int i = decltype(ic)::value;
+    const T* base;
+    uint32_t off;
+    if (EXTRA && (HEAD ? c < 0 : c >= n_chunks)) { base = WX + kstage(s) * BK; off = offx[i]; }
+    else if (s < KST) { base = W1 + (int64_t)phys(c) * BN * g1.ldb + kstage(s) * BK; off = off1[i]; }
+    else { base = W2 + (int64_t)phys(c) * BN + kstage(s - KST) * BK; off = off2[i]; }
+    rb[i] = *reinterpret_cast<const u32x4*>(base + off);
   };
   auto store_stage = [&](int buf, const u32x4 (&rb)[B_CH]) {
 #pragma unroll
@@ -1028,7 +1049,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     }
   }
   // one 64-deep K stage: acc += A[64, 64] (LDS tile `sA`, columns k0..) x stage `buf`
-  auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf, const u32x4 (&rb)[B_CH]) {
+  // hook(k), k < 2 * TN: called behind the k-th row of MFMAs of the stage — the staged form hangs the weight staging
+  // there (MST_FFN_IL), piece by piece, instead of issuing it in front of / behind the whole stage
+  auto mma_stage = [&](f32x4 (&acc)[TN][TM], const T* sA, int k0, int buf, const u32x4 (&rb)[B_CH], auto&& hook) {
     const u32x4* cB = sB + buf * BN * CHUNKS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
@@ -1043,12 +1066,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         if constexpr (DW) wf[j] = __builtin_bit_cast(vec8, rb[j * (BK / 32) + ks]);
         else wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
       }
+      auto row = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < TN) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf[j], xf[i], acc[j][i]);
+          for (int i = 0; i < TM; ++i) acc[j][i] = Act<T>::mfma16(wf[j], xf[i], acc[j][i]);
+          if (ks == 0) hook(std::integral_constant<int, j>()); else hook(std::integral_constant<int, TN + j>());
+        }
+      };
+      static_assert(TN <= 4, "row list");
+      row(std::integral_constant<int, 0>()); row(std::integral_constant<int, 1>());
+      row(std::integral_constant<int, 2>()); row(std::integral_constant<int, 3>());
     }
   };
+  auto no_hook = [](auto) {};
 
   f32x4 acc1[TN][TM], acc2[TN][TM];
 #pragma unroll
@@ -1077,7 +1108,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         constexpr int t = s + AHEAD;
         if constexpr (t < KST) load_stage(cx, t, ring[t % RING]);
         else if constexpr (HEAD) load_stage(0, t - KST, ring[t % RING]);  // the first chunk's stages follow (KST % RING == 0)
-        mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING]);
+        mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING], no_hook);
         if constexpr (s + 1 < KST) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
         __syncthreads();
       }
@@ -1094,6 +1125,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   }
   if constexpr (!DW) store_stage(0, ring[0]);
   __syncthreads();  // (also publishes the x tile)
+  FFN_STAMP(1);
   T* const sH0 = sH;
   for (int c = 0; c < n_chunks; ++c) {
     const int pc = phys(c);  // the hidden chunk this iteration computes
@@ -1117,24 +1149,37 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     auto stage = [&](auto sc) {
       constexpr int s = decltype(sc)::value;      // stage within the chunk: ring slot s % RING, LDS buffer s % 2
       if constexpr (s < SPC) {
-        {  // request stage s + AHEAD of the stream (it may belong to the next chunk)
-          constexpr int t = s + AHEAD;
-          // (unconditional: past the last chunk the clamped load fetches a stage nobody stores)
-          // (TAIL: past the last chunk come the extra GEMM's stages)
-          const int tc = t < SPC ? c : (TAIL || c + 1 < n_chunks ? c + 1 : c);
-          load_stage(tc, t % SPC, ring[t % RING]);
-        }
-#ifndef MST_FFN_EARLY_STORE
-#define MST_FFN_EARLY_STORE 0  /* measured 43.9 vs 42.6 us at width 256: slower, kept as a switch */
+#ifndef MST_FFN_IL
+#define MST_FFN_IL 1
 #endif
+        constexpr bool IL = MST_FFN_IL && BN >= 256 && !DW && !MST_FFN_EARLY_STORE && B_CH <= 2 * TN;  // (width 128, two workgroups per CU: measured 1 us slower)
+        // request stage s + AHEAD of the stream (it may belong to the next chunk)
+        constexpr int t = s + AHEAD;
+        // (unconditional: past the last chunk the clamped load fetches a stage nobody stores)
+        // (TAIL: past the last chunk come the extra GEMM's stages)
+        const int tc = t < SPC ? c : (TAIL || c + 1 < n_chunks ? c + 1 : c);
+        const bool more = s + 1 < SPC || c + 1 < n_chunks;  // a next stage exists: its weights go to the other LDS buffer
+        // interleaved form: piece k of { load of stage s + AHEAD, LDS store of stage s + 1 } behind the k-th row of MFMAs
+        auto piece = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (IL && k < B_CH) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_piece(tc, t % SPC, ring[t % RING], kc);
+            if (more) sB[((s + 1) & 1) * BN * CHUNKS + b_lds[k]] = ring[(s + 1) % RING][k];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        if constexpr (!IL) load_stage(tc, t % SPC, ring[t % RING]);
+        FFN_STAMP(8 + (c * SPC + s) * 4);
         if (MST_FFN_EARLY_STORE) {
           // Experiment (off): the next stage's weights go to the OTHER LDS buffer ahead of this stage's MFMAs (legal: that
           // buffer was last read in the previous stage, which ended with a barrier) instead of after them.
           if (s + 1 < SPC || c + 1 < n_chunks) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (s < KST) mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING]);
-        else mma_stage(acc2, sH, kstage(s - KST) * BK, s & 1, ring[s % RING]);
+        if constexpr (s < KST) mma_stage(acc1, sX, kstage(s) * BK, s & 1, ring[s % RING], piece);
+        else mma_stage(acc2, sH, kstage(s - KST) * BK, s & 1, ring[s % RING], piece);
+        FFN_STAMP(8 + (c * SPC + s) * 4 + 1);
         if constexpr (s == KST - 1) {
           // ---- chunk epilogue of GEMM 1, in registers: bias, ReLU, dropout, rounding (the order of gemm_epilogue) -> sH.
           // (The previous chunk's GEMM-2 stages, which read sH, ended with a barrier.)
@@ -1163,8 +1208,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         }
         // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
         if constexpr (!DW) {
-          if (!MST_FFN_EARLY_STORE && (s + 1 < SPC || c + 1 < n_chunks)) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+          if (!IL && !MST_FFN_EARLY_STORE && more) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+          FFN_STAMP(8 + (c * SPC + s) * 4 + 2);
           __syncthreads();
+          FFN_STAMP(8 + (c * SPC + s) * 4 + 3);
         } else if constexpr (s == KST - 1) {
           __syncthreads();  // the chunk is complete in LDS
         }
@@ -1200,6 +1247,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   // ---- the second GEMM's epilogue + LayerNorm: exactly mst_gemm_nt_ln's (staging tile over the dead weight / hidden regions)
   // (a residual that IS the block's input — the encoder's x1 + dropout(ff) — is taken from the x tile in LDS)
   const bool resid_is_x = g2.resid == g1.A && g2.ldr == g1.lda;
+  FFN_STAMP(2);
   if constexpr (DW) __syncthreads();  // the staging tile overlays the hidden chunks other waves may still be reading
   if constexpr (!TAIL) {
     gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA);
@@ -1229,6 +1277,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
       if (m0 + row < Mg) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(gx.C) + (m0 + row) * gx.ldc + nc) = ob.u;
     }
   }
+  FFN_STAMP(3); FFN_RT(191);
 }
 
 template <typename T, int BN>
@@ -1563,3 +1612,9 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
 }
+
+#ifdef MST_FFN_STAMPS
+extern "C" int mst_debug_ffn_stamps(uint64_t* host_out) {  // diagnostic builds only
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_ffn_stamps), sizeof(uint64_t) * (8 + 48 * 4)) == hipSuccess ? 0 : -1;
+}
+#endif

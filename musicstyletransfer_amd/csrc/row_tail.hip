@@ -63,14 +63,24 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16(const T* p, bool ok) {
 // (16 rows x 2 sums x 6 dependent permutes, alone on its SIMD) the LayerNorm of 16 rows took 8.7 us.
 template <int N>
 __device__ __forceinline__ void wave_sum_batch(float (&v)[N]) {
+  // level by level over all N values (DPP adds, one swizzle, one permute each: common.hpp group_sum), so that the N chains overlap
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float t[N];
+  for (int i = 0; i < N; ++i) v[i] += dpp_mov<0xB1>(v[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], o, 64);
+  for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x4E>(v[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += t[i];
-  }
+  for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x141>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x140>(v[i]);
+  float t[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = lane_xor16(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], 32, 64);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += t[i];
 }
 
 template <typename T>
