@@ -278,12 +278,25 @@ __device__ __forceinline__ void stats_tile_fast(const T* sQ, int r0, int64_t q_b
   l = l * fast_exp2(m2 - m_new) + sum;
   m2 = m_new;
 }
+// THIN tile: only the tile's first partner row exists (the lone row of a 32 n + 1 sequence, lone_row_shape): accumulator
+// element 0 of the lower lane half; one exponential instead of sixteen.
+template <typename T, int DH>
+__device__ __forceinline__ void stats_tile_thin(const T* sQ, int r0, float c, const typename Act<T>::vec8 (&kf)[DH / 16], float& m2, float& l,
+                                                int lane) {
+  f32x16 x = zero16<DH>();
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s) x = Act<T>::mfma32(lds_row_frag<T, DH>(sQ, r0, s, lane), kf[s], x);
+  const float x0 = (lane < 32) ? x[0] : -INFINITY;
+  const float m_new = fmaxf(m2, x0 * c);
+  l = l * fast_exp2(m2 - m_new) + fast_exp2(fmaf(x0, c, -m_new));
+  m2 = m_new;
+}
 // Full statistics of the 32 keys on this wave's lanes over the query tiles [0, n_tiles) staged at sQ (tile t at rows
 // 32 t, global query index q0 + 32 t): updates the running (max, sum) pair, natural-log domain on entry and exit.
 constexpr float LN2 = 0.6931471805599453f;
 template <typename T, int DH>
 __device__ __forceinline__ void stats_sweep(const T* sQ, int n_tiles, int64_t q0, int64_t S, float scale, float madd, bool exact_w,
-                                            const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane) {
+                                            const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane, bool thin_tail = false) {
   if (exact_w) {
     for (int t = 0; t < n_tiles; ++t) stats_tile_exact<T, DH>(sQ, t * 32, q0 + t * 32, S, scale, madd, kf, m, l, lane);
     return;
@@ -292,6 +305,7 @@ __device__ __forceinline__ void stats_sweep(const T* sQ, int n_tiles, int64_t q0
   float m2 = (m > NEG_BIG) ? m * LOG2E : NEG_BIG;
   for (int t = 0; t < n_tiles; ++t) {
     if (q0 + t * 32 + 32 <= S) stats_tile_fast<T, DH, false>(sQ, t * 32, q0 + t * 32, S, c, kf, m2, l, lane);
+    else if (thin_tail) stats_tile_thin<T, DH>(sQ, t * 32, c, kf, m2, l, lane);
     else stats_tile_fast<T, DH, true>(sQ, t * 32, q0 + t * 32, S, c, kf, m2, l, lane);
   }
   m = (m2 > NEG_BIG) ? m2 * LN2 : NEG_BIG;
@@ -345,7 +359,8 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
 
 // One 32-key x 32-query tile of the query-owner kernels. Straight-line on purpose: EXACT is a template parameter (the
 // callers branch once per tile), so the compiler is free to issue the per-key constant reads ahead of the exps.
-template <typename T, int DH, bool EXACT>
+// (THIN: only the tile's first key exists — accumulator element 0; the other fifteen probabilities are zero)
+template <typename T, int DH, bool EXACT, bool THIN = false>
 __device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
                                              const float* sMax, const float* sLogl, int blk, float scale,
                                              const typename Act<T>::vec8 (&qf)[DH / 16], f32x16 (&o)[(DH + 31) / 32], int lane) {
@@ -361,6 +376,16 @@ __device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const flo
   f32x16 x = zero16<DH>();
 #pragma unroll
   for (int s = 0; s < KS; ++s) x = Act<T>::mfma32(kfr[s], qf[s], x);
+  if constexpr (THIN) {
+    const int kr = blk * 32 + 4 * (lane >> 5);  // (upper lane half: a key beyond the sequence, its constants give p = 0)
+    const float p0 = EXACT ? exact_prob(x[0], scale, sMadd[kr], sMax[kr], sLogl[kr]) : fast_exp2(fmaf(x[0], sSk[kr], sCk[kr]));
+    x = zero16<DH>();
+    x[0] = p0;
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, 0);  // (keys 8.. of the tile: all zero, no second product)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[d] = Act<T>::mfma32(vfr[0][d], pf, o[d]);
+    return;
+  }
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {  // accumulator rows 4g..4g+3 are 4 consecutive keys: one 16-byte read per constant
     const int kr = blk * 32 + 8 * g4 + 4 * (lane >> 5);
@@ -384,7 +409,7 @@ __device__ __forceinline__ void fwd_out_tile(const T* sK, const T* sV, const flo
 // -delta[k] (sNd, one value per accumulator row), dL = P (dP - delta) scale is one multiply per element:
 //   x = exp2(S sk2 + ck2') * (dO.V - delta);  acc^T += K^T-fragment x   (rows d, query on the lane)
 // LIGHT: the owned queries' dO rows are zero (dP = 0): no V fragments, no dP MFMAs.
-template <typename T, int DH, bool EXACT, bool LIGHT = false>
+template <typename T, int DH, bool EXACT, bool LIGHT = false, bool THIN = false>
 __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float* sSk, const float* sCk, const float* sMadd,
                                            const float* sMax, const float* sLogl, const float* sNd, int blk, float scale,
                                            const typename Act<T>::vec8 (&qf)[DH / 16], const typename Act<T>::vec8 (&dof)[DH / 16],
@@ -412,6 +437,17 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
   for (int s = 0; s < KS; ++s) {
     x = Act<T>::mfma32(kfr[s], qf[s], x);
     if (!LIGHT) dp = Act<T>::mfma32(vfr[s], dof[s], dp);
+  }
+  if constexpr (THIN) {  // only the tile's first key exists (accumulator element 0)
+    const int kr = blk * 32 + 4 * (lane >> 5);
+    const float pr = EXACT ? exact_prob(x[0], scale, sMadd[kr], sMax[kr], sLogl[kr]) * scale : fast_exp2(fmaf(x[0], sSk[kr], sCk[kr]));
+    const float d0 = pr * dp[0];
+    x = zero16<DH>();
+    x[0] = d0;
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, 0);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(ktr[0][d], pf, acc[d]);
+    return;
   }
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
@@ -442,7 +478,7 @@ __device__ __forceinline__ void bwd_q_tile(const T* sK, const T* sV, const float
 // and need no guard).
 // LIGHT (PASS 1 only): the tile's dO rows are all zero, so dP = 0 and dL = -P * delta * s — no dO fragments, no dP MFMAs;
 // bit-identical to the full tile on zero dO rows (its accumulator stays at -delta).
-template <typename T, int DH, int PASS, bool EXACT, bool LIGHT = false>
+template <typename T, int DH, int PASS, bool EXACT, bool LIGHT = false, bool THIN = false>
 __device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, float scale, const typename Act<T>::vec8 (&kf)[DH / 16],
                                             const typename Act<T>::vec8 (&vf)[DH / 16], float sk2, float ck2x /* PASS 1: ck2s */, float madd,
                                             float rmax, float logl, float neg_delta, f32x16 (&acc)[(DH + 31) / 32], int lane) {
@@ -467,6 +503,16 @@ __device__ __forceinline__ void bwd_kv_tile(const T* sQ, const T* sdO, int qt, f
   for (int s = 0; s < KS; ++s) {
     x = Act<T>::mfma32(qfr[s], kf[s], x);
     if (NEED_DP) dp = Act<T>::mfma32(dofr[s], vf[s], dp);
+  }
+  if constexpr (THIN) {  // only the tile's first query exists (accumulator element 0; the upper lane half's row is a zero row of sQ / sdO)
+    float p0 = EXACT ? exact_prob(x[0], scale, madd, rmax, logl) : fast_exp2(fmaf(x[0], sk2, ck2x));
+    if (PASS == 1) p0 = (EXACT ? p0 * scale : p0) * dp[0];
+    x = zero16<DH>();
+    x[0] = p0;
+    const typename Act<T>::vec8 pf = acc_to_frag<T>(x, 0);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[d] = Act<T>::mfma32(trf[0][d], pf, acc[d]);
+    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -741,6 +787,46 @@ __device__ __forceinline__ void stage_pair(T* ldsA, const T* __restrict__ gA, in
   }
 }
 
+// ---- the LONE ROW of a sequence of 32 n + 1 rows (the decoder of configs[1]: 257 = the state row + 256 positions).
+// As a ninth 32-row owner block it costs a whole wave's sweep over all nine partner tiles for one useful lane — 81 tile
+// visits per sweep instead of 64, and nine waves per workgroup leave room for one workgroup per CU instead of two. As a
+// PARTNER the row is no problem (the ninth partner tile is an ordinary partial tile). As an OWNER it is handled here with
+// the roles turned over: the partner rows go on the lanes, each lane forms its row's dot products with the lone row
+// in-lane (rows are read straight from the staged LDS tiles), and what the MFMA form gets by summing down the register
+// axis becomes one cross-lane sum per output element at the end of the sweep — ~300 VALU operations per wave instead of
+// ~1200, and the owner blocks left are whole: eight waves, two workgroups per CU, one resident round.
+template <typename T, int DH>
+__device__ __forceinline__ void lds_row_load(const T* row, float (&v)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH / 8; ++c) {
+    Pack8 p; p.u = *reinterpret_cast<const u32x4*>(row + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[8 * c + e] = bits_to_f32<T>(p.h[e]);
+  }
+}
+template <typename T, int DH>
+__device__ __forceinline__ float lds_row_dot(const T* row, const float (&w)[DH]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH / 8; ++c) {
+    Pack8 p; p.u = *reinterpret_cast<const u32x4*>(row + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(bits_to_f32<T>(p.h[e]), w[8 * c + e], s);
+  }
+  return s;
+}
+template <typename T, int DH>
+__device__ __forceinline__ void lds_row_axpy(float alpha, const T* row, float (&acc)[DH]) {
+#pragma unroll
+  for (int c = 0; c < DH / 8; ++c) {
+    Pack8 p; p.u = *reinterpret_cast<const u32x4*>(row + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[8 * c + e] = fmaf(alpha, bits_to_f32<T>(p.h[e]), acc[8 * c + e]);
+  }
+}
+constexpr int LONE_RED = 16 * 32;  // floats of cross-wave reduction scratch behind the per-key arrays
+__host__ __device__ inline bool lone_row_shape(int64_t S, int dh) { return dh <= 16 && S > 32 && (S & 31) == 1; }  // (head size 32: the three fp32 rows spill the dense kernel)
+
 // waves per SIMD the head-size-16 resident kernels are compiled for (5 = 96 VGPRs, two 9-wave workgroups per CU, measured no faster forward and spills backward: the kernels are VALU-bound, not occupancy-bound)
 #ifndef MST_ATT16_WAVES_FWD
 #define MST_ATT16_WAVES_FWD 4
@@ -767,9 +853,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   T* sV = sK + SP * LD;
   float* sSk = reinterpret_cast<float*>(sV + SP * LD);
   float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP;
+  float* sRed = sLogl + SP;  // [LONE_RED]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
   const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
   const int64_t plane = a.B * a.H * S;
+  const bool lone = lone_row_shape(S, DH) && a.q_limit >= S;  // the last row is handled apart (above)
+  const int NBo = lone ? NB - 1 : NB;                            // owner blocks swept with MFMA tiles
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   stage_all<T, DH>(sQ, base + a.q_off, a.ld_qkv, S, SP, tid, nthr);
   stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
@@ -778,7 +867,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
 
   // ---- phase A: softmax statistics of every key row (the arithmetic of attn_fwd_stats_kernel)
   int padded = 0;
-  for (int ob = wave; ob < NB; ob += NW) {
+  for (int ob = wave; ob < NBo; ob += NW) {
     const int64_t k_lane = ob * 32 + (lane & 31);
     typename Act<T>::vec8 kf[KS];
 #pragma unroll
@@ -787,7 +876,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     const bool vk = in && a.keymask[b * S + k_lane];
     const float madd = vk ? 0.f : MASK_VALUE;
     float m = NEG_BIG, l = 0.f;
-    stats_sweep<T, DH>(sQ, NB, 0, S, a.scale, madd, __any(!vk), kf, m, l, lane);
+    stats_sweep<T, DH>(sQ, NB, 0, S, a.scale, madd, __any(!vk), kf, m, l, lane, lone);
     const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
     const float M = fmaxf(m, m2);
     const float logl = __logf(l * __expf(m - M) + l2 * __expf(m2 - M));
@@ -801,10 +890,42 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     }
     padded |= (in && !vk);
   }
+  if constexpr (DH <= 16) {
+    if (lone) {  // statistics of the lone key: queries on the lanes, the reference's operation order (stats_tile_exact)
+      const int64_t e = S - 1;
+      const bool vk = a.keymask[b * S + e];
+      const float madd = vk ? 0.f : MASK_VALUE;
+      float ke[DH];
+      lds_row_load<T, DH>(sK + e * LD, ke);
+      float m = NEG_BIG, l = 0.f;
+      for (int q = tid; q < S; q += nthr) {
+        const float t = fmaf(lds_row_dot<T, DH>(sQ + q * LD, ke), a.scale, madd);
+        const float m_new = fmaxf(m, t);
+        l = l * __expf(m - m_new) + __expf(t - m_new);
+        m = m_new;
+      }
+      const float mw = wave_max(m);
+      const float lw = wave_sum(l * __expf(m - mw));  // (a lane without a query: l = 0)
+      if (lane == 0) { sRed[wave] = mw; sRed[16 + wave] = lw; }
+      __syncthreads();
+      if (tid == 0) {
+        float M = NEG_BIG, L = 0.f;
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sRed[w]);
+        for (int w = 0; w < NW; ++w) L += sRed[16 + w] * __expf(sRed[w] - M);
+        const float logl = __logf(L);
+        a.lse[bh * S + e] = M;
+        a.lse[plane + bh * S + e] = logl;
+        key_consts(true, vk, M, logl, a.scale, sSk[e], sCk[e]);
+        sMadd[e] = madd; sMax[e] = M; sLogl[e] = logl;
+        for (int k = (int)S; k < SP; ++k) { key_consts(false, false, 0.f, 0.f, a.scale, sSk[k], sCk[k]); sMadd[k] = MASK_VALUE; sMax[k] = 0.f; sLogl[k] = INFINITY; }
+      }
+      padded |= !vk;
+    }
+  }
   const bool exact = __syncthreads_or(padded);  // does this sequence hold a padded key?
 
   // ---- phase B: O = P^T V for the owned queries (attn_fwd_out_kernel's tiles)
-  for (int ob = wave; ob < NB; ob += NW) {
+  for (int ob = wave; ob < NBo; ob += NW) {
     if ((int64_t)ob * 32 >= a.q_limit) break;
     typename Act<T>::vec8 qf[KS];
 #pragma unroll
@@ -813,13 +934,46 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
 #pragma unroll
     for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
     if (exact) {
-      for (int kt = 0; kt < NB; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+      for (int kt = 0; kt < NBo; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
     } else {
-      for (int kt = 0; kt < NB; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+      for (int kt = 0; kt < NBo; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+    }
+    if constexpr (DH <= 16) {
+      if (lone) {  // the ninth key tile holds the lone key only
+        if (exact) fwd_out_tile<T, DH, true, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, NB - 1, a.scale, qf, o, lane);
+        else fwd_out_tile<T, DH, false, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, NB - 1, a.scale, qf, o, lane);
+      }
     }
     T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
     const int64_t q_lane = ob * 32 + (lane & 31);
     owner_store<T, DH>((q_lane < S && q_lane < a.q_limit) ? og + q_lane * a.ld_out : nullptr, o, lane);
+  }
+  if constexpr (DH <= 16) {
+    if (lone) {  // O[e] = sum_k P[k,e] V[k]: keys on the lanes (P stays fp32 here; the MFMA form rounds it to the activation type)
+      const int64_t e = S - 1;
+      float qe[DH], acc[DH];
+      lds_row_load<T, DH>(sQ + e * LD, qe);
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = 0.f;
+      for (int k = tid; k < S; k += nthr) {
+        const float x = lds_row_dot<T, DH>(sK + k * LD, qe);
+        const float p = exact ? exact_prob(x, a.scale, sMadd[k], sMax[k], sLogl[k]) : fast_exp2(fmaf(x, sSk[k], sCk[k]));
+        lds_row_axpy<T, DH>(p, sV + k * LD, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = wave_sum(acc[f]);
+      if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) sRed[wave * DH + f] = acc[f];
+      }
+      __syncthreads();
+      if (tid < DH) {
+        float o_e = 0.f;
+        for (int w = 0; w < NW; ++w) o_e += sRed[w * DH + tid];
+        T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
+        og[e * a.ld_out + tid] = (T)o_e;
+      }
+    }
   }
 }
 
@@ -833,9 +987,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   T* bufB = bufA + SP * LD;                  // phase A: dO  phase B: V
   float* sSk = reinterpret_cast<float*>(bufB + SP * LD);
   float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sNd = sLogl + SP;
+  float* sRed = sNd + SP;  // [LONE_RED]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
   const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
   const int64_t plane = a.B * a.H * S;
+  const bool lone = !SPARSE && lone_row_shape(S, DH);  // the last row is handled apart (see lone_row_shape)
+  const int NBo = lone ? NB - 1 : NB;                    // owner blocks swept with MFMA tiles
   const float log2_scale = __log2f(a.scale);
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
@@ -857,11 +1014,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   }
   stage_pair<T, DH>(bufA, Qg, a.ld_qkv, S, bufB, dOg, a.ld_dout, do_rows, SP, tid, nthr);
   __syncthreads();
-  const int nq0 = sparse ? 1 : NB;  // query tiles that contribute to pass 0
+  const int nq0 = sparse ? 1 : NBo;  // (whole) query tiles that contribute to pass 0
 
   // ---- phase A: dV, delta, dK for the owned keys (attn_bwd_kv_kernel's two passes over the query tiles)
   int padded = 0;
-  for (int ob = wave; ob < NB; ob += NW) {
+  for (int ob = wave; ob < NBo; ob += NW) {
     const int64_t k_lane = ob * 32 + (lane & 31);
     if (ob != wave) {
 #pragma unroll
@@ -890,6 +1047,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
     if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
     else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 0, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+    if constexpr (DH <= 16 && !SPARSE) {
+      if (lone) {  // the ninth query tile holds the lone query only
+        if (exact_w) bwd_kv_tile<T, DH, 0, true, false, true>(bufA, bufB, NB - 1, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+        else bwd_kv_tile<T, DH, 0, false, false, true>(bufA, bufB, NB - 1, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+      }
+    }
     {
       const float delta = delta_from_dv<T, DH>(acc, vf, lane);
       if (lane < 32 && in) a.delta[bh * S + k_lane] = delta;
@@ -901,12 +1064,88 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
     if (exact_w) for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
     else for (int qt = 0; qt < nq0; ++qt) bwd_kv_tile<T, DH, 1, false>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
-    if (exact_w) for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
-    else for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    if (sparse) {
+      if (exact_w) for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, true, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+      else for (int qt = nq0; qt < NB; ++qt) bwd_kv_tile<T, DH, 1, false, true>(bufA, bufB, qt, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+    }
+    if constexpr (DH <= 16 && !SPARSE) {
+      if (lone) {
+        if (exact_w) bwd_kv_tile<T, DH, 1, true, false, true>(bufA, bufB, NB - 1, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+        else bwd_kv_tile<T, DH, 1, false, false, true>(bufA, bufB, NB - 1, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+      }
+    }
     owner_store<T, DH>(drow ? drow + a.k_off : nullptr, acc, lane);
     if (lane < 32) {
       sSk[k_lane] = sk2; sCk[k_lane] = ck2s; sMadd[k_lane] = madd; sMax[k_lane] = rmax; sLogl[k_lane] = logl;
       sNd[k_lane] = in ? neg_delta : 0.f;
+    }
+  }
+  if constexpr (DH <= 16 && !SPARSE) {
+    if (lone) {  // the lone key: queries on the lanes; dV, delta = V . dV, then dK (two sweeps, as the MFMA form)
+      const int64_t e = S - 1;
+      float ke[DH], ve[DH], acc[DH];
+#pragma unroll
+      for (int f = 0; f < DH; ++f) { ke[f] = to_f32(Kg[e * a.ld_qkv + f]); ve[f] = to_f32(Vg[e * a.ld_qkv + f]); }
+      const bool vk = a.keymask[b * S + e];
+      const float rmax = a.lse[bh * S + e], logl = a.lse[plane + bh * S + e], madd = vk ? 0.f : MASK_VALUE;
+      float sk2, ck2;
+      key_consts(true, vk, rmax, logl, a.scale, sk2, ck2);
+      const float ck2s = ck2 + log2_scale;
+      padded |= !vk;
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = 0.f;
+      for (int q = tid; q < S; q += nthr) {
+        const float x = lds_row_dot<T, DH>(bufA + q * LD, ke);
+        const float pr = vk ? fast_exp2(fmaf(x, sk2, ck2)) : exact_prob(x, a.scale, madd, rmax, logl);
+        lds_row_axpy<T, DH>(pr, bufB + q * LD, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = wave_sum(acc[f]);
+      if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) sRed[wave * DH + f] = acc[f];
+      }
+      __syncthreads();
+      if (tid < DH) {
+        float dv = 0.f;
+        for (int w = 0; w < NW; ++w) dv += sRed[w * DH + tid];
+        sRed[LONE_RED / 2 + tid] = dv;
+        dbase[e * a.ld_dqkv + a.v_off + tid] = (T)dv;
+      }
+      __syncthreads();
+      float delta = 0.f;
+#pragma unroll
+      for (int f = 0; f < DH; ++f) delta = fmaf(ve[f], sRed[LONE_RED / 2 + f], delta);
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = 0.f;
+      for (int q = tid; q < S; q += nthr) {
+        const float x = lds_row_dot<T, DH>(bufA + q * LD, ke);
+        const float ps = vk ? fast_exp2(fmaf(x, sk2, ck2s)) : exact_prob(x, a.scale, madd, rmax, logl) * a.scale;
+        const float dl = ps * (lds_row_dot<T, DH>(bufB + q * LD, ve) - delta);
+        lds_row_axpy<T, DH>(dl, bufA + q * LD, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = wave_sum(acc[f]);
+      __syncthreads();  // (the dV partials have been read)
+      if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) sRed[wave * DH + f] = acc[f];
+      }
+      __syncthreads();
+      if (tid < DH) {
+        float dk = 0.f;
+        for (int w = 0; w < NW; ++w) dk += sRed[w * DH + tid];
+        dbase[e * a.ld_dqkv + a.k_off + tid] = (T)dk;
+      }
+      if (tid == 0) {
+        a.delta[bh * S + e] = delta;
+        sSk[e] = sk2; sCk[e] = ck2s; sMadd[e] = madd; sMax[e] = rmax; sLogl[e] = logl; sNd[e] = -delta;
+        for (int k = (int)S; k < SP; ++k) {
+          float s0, c0;
+          key_consts(false, false, 0.f, 0.f, a.scale, s0, c0);
+          sSk[k] = s0; sCk[k] = c0 + log2_scale; sMadd[k] = MASK_VALUE; sMax[k] = 0.f; sLogl[k] = INFINITY; sNd[k] = 0.f;
+        }
+      }
     }
   }
   // phase B's first Q / dO fragments: requested before the barrier and the K / V staging
@@ -921,7 +1160,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   const bool exact = __syncthreads_or(padded);
 
   // ---- phase B: dQ for the owned queries (attn_bwd_q_kernel's tiles)
-  for (int ob = wave; ob < NB; ob += NW) {
+  for (int ob = wave; ob < NBo; ob += NW) {
     const int64_t q_lane = ob * 32 + (lane & 31);
     if (ob != wave) {
 #pragma unroll
@@ -937,23 +1176,55 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
       if (exact) for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
       else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else if (exact) {
-      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      for (int kt = 0; kt < NBo; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else {
-      for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      for (int kt = 0; kt < NBo; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+    }
+    if constexpr (DH <= 16 && !SPARSE) {
+      if (lone) {  // the ninth key tile holds the lone key only
+        if (exact) bwd_q_tile<T, DH, true, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, NB - 1, a.scale, qf, dof, acc, lane);
+        else bwd_q_tile<T, DH, false, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, NB - 1, a.scale, qf, dof, acc, lane);
+      }
     }
     owner_store<T, DH>(q_lane < S ? dbase + a.q_off + q_lane * a.ld_dqkv : nullptr, acc, lane);
+  }
+  if constexpr (DH <= 16 && !SPARSE) {
+    if (lone) {  // dQ of the lone query: keys on the lanes
+      const int64_t e = S - 1;
+      float qe[DH], doe[DH], acc[DH];
+#pragma unroll
+      for (int f = 0; f < DH; ++f) { qe[f] = to_f32(Qg[e * a.ld_qkv + f]); doe[f] = to_f32(dOg[e * a.ld_dout + f]); acc[f] = 0.f; }
+      for (int k = tid; k < S; k += nthr) {
+        const float x = lds_row_dot<T, DH>(bufA + k * LD, qe);
+        const float ps = exact ? exact_prob(x, a.scale, sMadd[k], sMax[k], sLogl[k]) * a.scale : fast_exp2(fmaf(x, sSk[k], sCk[k]));
+        const float dl = ps * (lds_row_dot<T, DH>(bufB + k * LD, doe) + sNd[k]);
+        lds_row_axpy<T, DH>(dl, bufA + k * LD, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < DH; ++f) acc[f] = wave_sum(acc[f]);
+      if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) sRed[wave * DH + f] = acc[f];
+      }
+      __syncthreads();
+      if (tid < DH) {
+        float dq = 0.f;
+        for (int w = 0; w < NW; ++w) dq += sRed[w * DH + tid];
+        dbase[e * a.ld_dqkv + a.q_off + tid] = (T)dq;
+      }
+    }
   }
 }
 
 // Waves per workgroup for the resident kernels, or 0 when the sequence does not fit: maximise (resident waves per CU)
 // x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU,
 // the 96 of the head-size-16 instantiations 20 (two 9-wave workgroups of a 257-row sequence: the decoder of configs[1]).
-static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_cu = 16) {
+static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_cu = 16, bool lone = false) {
   const char* force = getenv("MST_ATTN_PATH");  // "stream" / "resident": pin the path (tests cover both)
   if (force && force[0] == 's') return 0;
   const size_t LDS_CU = 160 * 1024;
   if (lds_bytes > LDS_CU - 1024) return 0;
-  const int NB = (int)cdiv(S, 32);
+  const int NB = (int)cdiv(S, 32) - (lone ? 1 : 0);  // owner blocks
   const int by_grid = (int)cdiv(n_wg, 256);
   int best = 0;
   double best_score = 0.0;
@@ -968,8 +1239,8 @@ static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_
   }
   return best;
 }
-template <int DH> static size_t res_lds_fwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 3 * SP * LdsLd<DH>::V * 2 + 5 * SP * 4; }
-template <int DH> static size_t res_lds_bwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 2 * SP * LdsLd<DH>::V * 2 + 6 * SP * 4; }
+template <int DH> static size_t res_lds_fwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 3 * SP * LdsLd<DH>::V * 2 + 5 * SP * 4 + LONE_RED * 4; }
+template <int DH> static size_t res_lds_bwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 2 * SP * LdsLd<DH>::V * 2 + 6 * SP * 4 + LONE_RED * 4; }
 
 static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off) {
   MST_CHECK_ARG(B > 0 && S > 0 && H > 0, "attention: B,S,H must be positive");
@@ -982,7 +1253,7 @@ static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, i
 template <typename T, int DH>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_fwd<DH>(a.S);
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_FWD : 16)) {
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_FWD : 16, lone_row_shape(a.S, DH) && a.q_limit >= a.S)) {
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
     if (lds > attr_lds) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH>),
@@ -1005,8 +1276,9 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <typename T, int DH>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_bwd<DH>(a.S);
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_BWD : 16)) {
-    const bool sparse = a.q_limit > 0 && a.q_limit <= 32;
+  const bool sparse_shape = a.q_limit > 0 && a.q_limit <= 32;
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_BWD : 16, lone_row_shape(a.S, DH) && !sparse_shape)) {
+    const bool sparse = sparse_shape;
     static size_t attr_lds[2] = {64 * 1024, 64 * 1024};  // dynamic LDS above 64 KB has to be opted into, per kernel
     if (lds > attr_lds[sparse]) {
       const void* fn = sparse ? reinterpret_cast<const void*>(&attn_bwd_res_kernel<T, DH, true>)
