@@ -51,6 +51,23 @@ __device__ __forceinline__ u32x2 load8_sc1(const void* p) {
 __device__ __forceinline__ uint32_t load4_sc1(const void* p) {
   return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same loads WITHOUT the wait hipcc puts behind every atomic load (sixteen rows read one after the other were sixteen
+// exposed L2 round trips: 4.8 us of stage 2): issue a batch with *_nowait, then sc1_wait_all on the destinations —
+// the values may be used only behind that wait (its "+v" operands make every use depend on it).
+__device__ __forceinline__ void load8_sc1_nowait(u32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void load4_sc1_nowait(uint32_t& dst, const void* p) {
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void sc1_wait_all(V (&r)[16]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                 "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+               :
+               : "memory");
+}
 
 template <typename T>
 __device__ __forceinline__ typename Act<T>::vec8 frag16(const T* p, bool ok) {
@@ -200,20 +217,25 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
   {
     constexpr int RPW = 16;  // rows per wave: rows wave, wave + 4, ...
     float v[RPW][E];
+    // all sixteen rows requested at once, unconditionally (a row past the batch re-reads the last one and is zeroed below)
+    typename std::conditional<E == 4, u32x2, uint32_t>::type raw[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;
+      const int r = wave + 4 * i, rc = r < B ? r : B - 1;
+      if constexpr (E == 4) load8_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 4);
+      else load4_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 2);
+    }
+    sc1_wait_all(raw);
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[i][e] = 0.f;
-      if (r < B) {
-        if constexpr (E == 4) {
-          const u32x2 t = load8_sc1(h1 + (int64_t)r * q.rs_d + lane * 4);
-          v[i][0] = bits_to_f32<T>((uint16_t)(t[0] & 0xffff)); v[i][1] = bits_to_f32<T>((uint16_t)(t[0] >> 16));
-          v[i][2] = bits_to_f32<T>((uint16_t)(t[1] & 0xffff)); v[i][3] = bits_to_f32<T>((uint16_t)(t[1] >> 16));
-        } else {
-          const uint32_t t = load4_sc1(h1 + (int64_t)r * q.rs_d + lane * 2);
-          v[i][0] = bits_to_f32<T>((uint16_t)(t & 0xffff)); v[i][1] = bits_to_f32<T>((uint16_t)(t >> 16));
-        }
+    for (int i = 0; i < RPW; ++i) {
+      const bool ok = wave + 4 * i < B;
+      if constexpr (E == 4) {
+        const u32x2 t = raw[i];
+        v[i][0] = ok ? bits_to_f32<T>((uint16_t)(t[0] & 0xffff)) : 0.f; v[i][1] = ok ? bits_to_f32<T>((uint16_t)(t[0] >> 16)) : 0.f;
+        v[i][2] = ok ? bits_to_f32<T>((uint16_t)(t[1] & 0xffff)) : 0.f; v[i][3] = ok ? bits_to_f32<T>((uint16_t)(t[1] >> 16)) : 0.f;
+      } else {
+        const uint32_t t = raw[i];
+        v[i][0] = ok ? bits_to_f32<T>((uint16_t)(t & 0xffff)) : 0.f; v[i][1] = ok ? bits_to_f32<T>((uint16_t)(t >> 16)) : 0.f;
       }
     }
     float gm[E], bt[E];
