@@ -417,6 +417,36 @@ typedef struct mst_row_tail_args {
   uint32_t* sync;
 } mst_row_tail_args;
 int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
+/* The same rows on the way back: autograd of mst_row_tail_fwd's chain for the gradient `dy` of the layer's output rows —
+ *     mst_layernorm_bwd (LayerNorm-2; dh, its dropout-masked copy dhm, dgamma2 / dbeta2 +=)
+ *  -> mst_gemm_nt(dhm, W2t, gate = a, alpha = 1 / (1 - p))   d(pre)                 [B, 4 D]
+ *  -> mst_gemm_nt(d(pre), W1t, resid = dh)                   dx1
+ *  -> mst_layernorm_bwd (LayerNorm-1; dh1 rows, masked copy dh1m, dgamma1 / dbeta1 +=)
+ *  -> mst_gemm_nt(dh1m, Wpt)                                 datt rows
+ * in one launch (same results to rounding of the LayerNorm sums). W2t [4 D, D], W1t [D, 4 D], Wpt [D, D]: the transposed
+ * 16-bit weights (K-contiguous dgrad operands). dh / dhm / dx1 / dh1m: compact [B, >= D] scratch rows (row stride rs_c);
+ * dh1 / datt: rows of the strided full-size buffers the following launches read. `sync`: one zeroed device word. */
+typedef struct mst_row_tail_bwd_args {
+  int32_t dtype;
+  int64_t B, D;
+  const void* dy; int64_t rs_dy;
+  const void* h2; const void* h1; int64_t rs_d;
+  const void* a; int64_t rs_a;
+  const float* mean1; const float* rstd1; const float* mean2; const float* rstd2; int64_t stat_stride;
+  const float* g1; const float* g2;
+  const void* W2t; int64_t ldw2t;
+  const void* W1t; int64_t ldw1t;
+  const void* Wpt; int64_t ldwpt;
+  void* dh; void* dhm; void* dx1; void* dh1m; int64_t rs_c;
+  void* dpre; int64_t rs_dpre;
+  void* dh1; int64_t rs_dh1;
+  void* datt; int64_t rs_datt;
+  float* dg1; float* db1; float* dg2; float* db2;
+  float dropout_p; uint64_t dropout_seed; const uint64_t* dropout_seed_ptr; uint32_t site0;
+  int64_t phys_stride;
+  uint32_t* sync;
+} mst_row_tail_bwd_args;
+int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Incremental decode (inference; model.py:259-272, transformer.py:70-77,242-249): the new position's query against the

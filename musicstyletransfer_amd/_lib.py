@@ -60,6 +60,20 @@ class RowTailArgs(C.Structure):
     ]
 
 
+class RowTailBwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("B", c_i64), ("D", c_i64),
+        ("dy", vp), ("rs_dy", c_i64), ("h2", vp), ("h1", vp), ("rs_d", c_i64), ("a", vp), ("rs_a", c_i64),
+        ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp), ("stat_stride", c_i64), ("g1", vp), ("g2", vp),
+        ("W2t", vp), ("ldw2t", c_i64), ("W1t", vp), ("ldw1t", c_i64), ("Wpt", vp), ("ldwpt", c_i64),
+        ("dh", vp), ("dhm", vp), ("dx1", vp), ("dh1m", vp), ("rs_c", c_i64), ("dpre", vp), ("rs_dpre", c_i64),
+        ("dh1", vp), ("rs_dh1", c_i64), ("datt", vp), ("rs_datt", c_i64),
+        ("dg1", vp), ("db1", vp), ("dg2", vp), ("db2", vp),
+        ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_seed_ptr", vp), ("site0", c_u32),
+        ("phys_stride", c_i64), ("sync", vp),
+    ]
+
+
 class LnArgs(C.Structure):
     _fields_ = [
         ("mode", c_i32),
@@ -129,6 +143,7 @@ SIGNATURES = {
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
+    "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),

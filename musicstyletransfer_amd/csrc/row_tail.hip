@@ -140,16 +140,46 @@ __device__ __forceinline__ void ln_row(const T* __restrict__ x, const float* __r
 #define TAIL_STAMP(i) do { } while (0)
 #endif
 
+// Sixteen waves per workgroup (four per SIMD): every stage is a chain of dependent L2 round trips, and with one wave per
+// SIMD nothing ran under them (four waves: forward 30 us, backward 43 us against 39 for its five launches). Wave (mi, wq):
+// row block mi = wave & 3 (rows 16 mi .. 16 mi + 15 in the MFMA stages), quarter wq = wave >> 2 — the 64-column slices are
+// split by 16-column block, the 16-column slices by quarter of K (partial accumulators meet in LDS); the LayerNorms take
+// four rows per wave.
+constexpr int TAIL_WAVES = 16;
+template <typename V>
+__device__ __forceinline__ void sc1_wait4(V (&r)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+}
+// partial 16-column accumulators of the four K quarters -> their sum on the waves of quarter 0 (sP: [4][64][16] floats)
+__device__ __forceinline__ f32x4 quarter_sum(float* sP, const f32x4& part, int wq, int m, int lq) {
+  *reinterpret_cast<f32x4*>(sP + (wq * 64 + m) * 16 + 4 * lq) = part;
+  __syncthreads();
+  f32x4 acc = part;
+  if (wq == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(sP + (w * 64 + m) * 16 + 4 * lq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += o[e];
+    }
+  }
+  return acc;
+}
+
 template <typename T, int D>
-__global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) {
+__global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q) {
   constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64;
+  constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;  // k-steps per K quarter of the two 16-column stages
   __shared__ __attribute__((aligned(16))) T sX1[64 * LDX];  // LayerNorm-1 output of every row (FFN1's operand, FFN2's residual)
+  __shared__ __attribute__((aligned(16))) float sP[4 * 64 * 16];
   typedef typename Act<T>::vec8 vec8;
+  typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave & 3, wq = wave >> 2;
   const int g = blockIdx.x;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
-  const int m = wave * 16 + li;  // the row this lane's accumulator column belongs to
+  const int m = mi * 16 + li;  // the row this lane's accumulator column belongs to
   const bool m_ok = m < B;
   const int64_t pm = (int64_t)m * q.phys_stride;  // physical row in the [B * S, N] tensors: the dropout counter's row
   const float p = q.dropout_p;
@@ -186,28 +216,27 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
   };
 
   TAIL_STAMP(0);
-  // ---------------- stage 1: h1[:, 16 g .. 16 g + 15] = x_in + dropout(att W_proj^T + b)
+  // ---------------- stage 1: h1[:, 16 g .. 16 g + 15] = x_in + dropout(att W_proj^T + b)     (K quarter wq per wave)
   {
     const int n0 = g * 16;
-    const T* Wp = reinterpret_cast<const T*>(q.Wp) + (int64_t)(n0 + li) * q.ldwp + 8 * lq;
-    const T* Ar = att + (int64_t)m * q.rs_att + 8 * lq;
-    vec8 wf[D / 32], xf[D / 32];
+    const T* Wp = reinterpret_cast<const T*>(q.Wp) + (int64_t)(n0 + li) * q.ldwp + 8 * lq + 32 * KQ1 * wq;
+    const T* Ar = att + (int64_t)m * q.rs_att + 8 * lq + 32 * KQ1 * wq;
+    vec8 wf[KQ1], xf[KQ1];
 #pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) { wf[ks] = frag16<T>(Wp + 32 * ks, true); xf[ks] = frag16<T>(Ar + 32 * ks, m_ok); }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KQ1; ++ks) { wf[ks] = frag16<T>(Wp + 32 * ks, true); xf[ks] = frag16<T>(Ar + 32 * ks, m_ok); }
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) acc = Act<T>::mfma16(wf[ks], xf[ks], acc);
-    if (m_ok) finish4(acc, q.bp, n0 + 4 * lq, q.site0, D, false, xin + (int64_t)m * q.rs_res, h1 + (int64_t)m * q.rs_d);
+    for (int ks = 0; ks < KQ1; ++ks) part = Act<T>::mfma16(wf[ks], xf[ks], part);
+    const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
+    if (wq == 0 && m_ok) finish4(acc, q.bp, n0 + 4 * lq, q.site0, D, false, xin + (int64_t)m * q.rs_res, h1 + (int64_t)m * q.rs_d);
   }
   // (memory-level parallelism is the whole game here: every stage is a few dependent L2 / fabric round trips, so the
   // next stage's weight fragments are requested BEFORE the barrier they do not depend on, and rows are loaded in batches)
-  const int n1 = g * 64;
+  const int n1 = g * 64 + 16 * wq;  // this wave's 16-column block of the FFN1 slice
   const T* W1p = reinterpret_cast<const T*>(q.W1) + (int64_t)(n1 + li) * q.ldw1 + 8 * lq;
-  vec8 w1f[D / 32][4];  // ALL of this workgroup's FFN1 weights (one wave per SIMD: the whole register file is ours)
+  vec8 w1f[D / 32];
 #pragma unroll
-  for (int ks = 0; ks < D / 32; ++ks)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w1f[ks][j] = frag16<T>(W1p + (int64_t)16 * j * q.ldw1 + 32 * ks, true);
+  for (int ks = 0; ks < D / 32; ++ks) w1f[ks] = frag16<T>(W1p + 32 * ks, true);
   TAIL_STAMP(1);
   grid_sync(q.sync, G);
   TAIL_STAMP(2);
@@ -215,20 +244,20 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
   // ---------------- stage 2: x1 = LN1(h1) for every row (each workgroup, into LDS; the rows' owner also to HBM), then
   //                  a[:, 64 g .. 64 g + 63] = dropout(relu(x1 W1^T + b1))
   {
-    constexpr int RPW = 16;  // rows per wave: rows wave, wave + 4, ...
+    constexpr int RPW = 4;  // rows per wave: rows wave, wave + 16, ...
     float v[RPW][E];
-    // all sixteen rows requested at once, unconditionally (a row past the batch re-reads the last one and is zeroed below)
-    typename std::conditional<E == 4, u32x2, uint32_t>::type raw[RPW];
+    // all rows requested at once, unconditionally (a row past the batch re-reads the last one and is zeroed below)
+    raw_t raw[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i, rc = r < B ? r : B - 1;
+      const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
       if constexpr (E == 4) load8_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 4);
       else load4_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 2);
     }
-    sc1_wait_all(raw);
+    sc1_wait4(raw);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const bool ok = wave + 4 * i < B;
+      const bool ok = wave + TAIL_WAVES * i < B;
       if constexpr (E == 4) {
         const u32x2 t = raw[i];
         v[i][0] = ok ? bits_to_f32<T>((uint16_t)(t[0] & 0xffff)) : 0.f; v[i][1] = ok ? bits_to_f32<T>((uint16_t)(t[0] >> 16)) : 0.f;
@@ -263,7 +292,7 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
     wave_sum_batch<RPW>(rstd);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;
+      const int r = wave + TAIL_WAVES * i;
       rstd[i] = 1.f / sqrtf(rstd[i] * (1.f / (float)D) + q.eps);
       uint16_t yb[E];
 #pragma unroll
@@ -284,54 +313,42 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
   __syncthreads();
   TAIL_STAMP(10);
   const int n2 = g * 16;
-  const T* W2p = reinterpret_cast<const T*>(q.W2) + (int64_t)(n2 + li) * q.ldw2 + 8 * lq;
-  constexpr int KB = F / 64;  // k-steps per batch of FFN2: two batches cover K = 4 D
-  vec8 w2f[2][KB];     // FFN2 weight fragments: both batches in flight
+  const T* W2p = reinterpret_cast<const T*>(q.W2) + (int64_t)(n2 + li) * q.ldw2 + 8 * lq + 32 * KQ2 * wq;
+  vec8 w2f[KQ2];  // this wave's quarter of the FFN2 weights: requested before the barrier
   {
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < D / 32; ++ks) {
       const vec8 xf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sX1 + m * LDX + 32 * ks + 8 * lq));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = Act<T>::mfma16(w1f[ks][j], xf, acc[j]);
+      acc = Act<T>::mfma16(w1f[ks], xf, acc);
     }
     TAIL_STAMP(11);
 #pragma unroll
-    for (int ks = 0; ks < KB; ++ks) w2f[0][ks] = frag16<T>(W2p + 32 * ks, true);  // FFN2's first weights: before the barrier
-    if (m_ok) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) finish4(acc[j], q.b1, n1 + 16 * j + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KB; ++ks) w2f[1][ks] = frag16<T>(W2p + (KB + ks) * 32, true);
+    for (int ks = 0; ks < KQ2; ++ks) w2f[ks] = frag16<T>(W2p + 32 * ks, true);
+    if (m_ok) finish4(acc, q.b1, n1 + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
   }
   TAIL_STAMP(3);
   grid_sync(q.sync, 2 * G);
   TAIL_STAMP(4);
 
-  // ---------------- stage 3: h2[:, 16 g ..] = x1 + dropout(a W2^T + b2)        (K = 4 D: the whole hidden row)
+  // ---------------- stage 3: h2[:, 16 g ..] = x1 + dropout(a W2^T + b2)        (K = 4 D: the whole hidden row, a quarter per wave)
   {
-    const T* Ar = a + (int64_t)m * q.rs_a + 8 * lq;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    vec8 xf[2][KB];  // the hidden row's fragments: every load in flight at once (two dependent fabric round trips were 5 us)
+    const T* Ar = a + (int64_t)m * q.rs_a + 8 * lq + 32 * KQ2 * wq;
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    vec8 xf[KQ2];  // the hidden row's fragments: every load in flight at once
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
+    for (int ks = 0; ks < KQ2; ++ks) xf[ks] = frag16_sc1<T>(Ar + ks * 32, m_ok);
 #pragma unroll
-      for (int ks = 0; ks < KB; ++ks) xf[bt][ks] = frag16_sc1<T>(Ar + (bt * KB + ks) * 32, m_ok);
-#pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-      for (int ks = 0; ks < KB; ++ks) acc = Act<T>::mfma16(w2f[bt][ks], xf[bt][ks], acc);
-    if (m_ok) finish4(acc, q.b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
+    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w2f[ks], xf[ks], part);
+    const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
+    if (wq == 0 && m_ok) finish4(acc, q.b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
   }
   TAIL_STAMP(5);
   grid_sync(q.sync, 3 * G);
   TAIL_STAMP(6);
 
   // ---------------- stage 4: x2 = LN2(h2), rows dealt to the workgroups
-  for (int r = g + G * wave; r < B; r += 4 * G) {
+  for (int r = g + G * wave; r < B; r += TAIL_WAVES * G) {
     float y[E], mean, rstd;
     ln_row<T, D>(h2 + (int64_t)r * q.rs_d, q.g2, q.be2, q.eps, lane, y, mean, rstd);
     uint16_t yb[E];
@@ -341,6 +358,244 @@ __global__ __launch_bounds__(256) void row_tail_fwd_kernel(mst_row_tail_args q) 
         u32x2{(uint32_t)yb[0] | ((uint32_t)yb[1] << 16), (uint32_t)yb[2] | ((uint32_t)yb[3] << 16)};
     else *reinterpret_cast<uint32_t*>(x2 + (int64_t)r * q.rs_d + lane * 2) = (uint32_t)yb[0] | ((uint32_t)yb[1] << 16);
     if (lane == 0) { q.mean2[(int64_t)r * q.stat_stride] = mean; q.rstd2[(int64_t)r * q.stat_stride] = rstd; }
+  }
+  TAIL_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same rows on the way back (mst_row_tail_bwd): LayerNorm-2 backward -> FFN2 dgrad (ReLU gate) -> FFN1 dgrad (+ the
+// residual branch) -> LayerNorm-1 backward -> W_proj dgrad, five launches of the step (two LayerNorm backward launches on B
+// rows and three GEMMs with M = B) as one, with the forward kernel's decomposition: D / 16 workgroups, each owning 64 hidden
+// columns of the FFN2 dgrad and 16 output columns of the FFN1 and W_proj dgrads; both LayerNorm backward passes are
+// recomputed by every workgroup on all rows (their results are the next GEMM's operand, kept in LDS), so only two results
+// cross a grid barrier: d(pre-activation) and the FFN1 dgrad's output. The workgroup's FFN2-dgrad weights wait in LDS.
+template <typename T, int D>
+__global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_args q) {
+  constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64, RPW = 4;
+  constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+  T* sA = reinterpret_cast<T*>(tail_smem);                     // [64][LDX] masked LayerNorm-backward rows: the GEMM operand
+  T* sW = sA + 64 * LDX;                                        // [64][LDX] W2t rows 64 g .. 64 g + 63
+  float* sRed = reinterpret_cast<float*>(sW + 64 * LDX);        // [16 waves][2][D]
+  float* sP = sRed + TAIL_WAVES * 2 * D;                        // [4][64][16]
+  typedef typename Act<T>::vec8 vec8;
+  typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave & 3, wq = wave >> 2;
+  const int g = blockIdx.x;
+  const int li = lane & 15, lq = lane >> 4;
+  const int B = (int)q.B;
+  const int m = mi * 16 + li;
+  const bool m_ok = m < B;
+  const float p = q.dropout_p;
+  const bool drop = p > 0.f;
+  const uint64_t dseed = q.dropout_seed ^ ((drop && q.dropout_seed_ptr) ? q.dropout_seed_ptr[0] : 0ull);
+  const uint32_t thr = dropout_thr(p);
+  const float inv_keep = dropout_inv_keep(p), inv_d = 1.f / (float)D;
+  const T* dy = reinterpret_cast<const T*>(q.dy);
+  const T* h2 = reinterpret_cast<const T*>(q.h2); const T* h1 = reinterpret_cast<const T*>(q.h1);
+  const T* a = reinterpret_cast<const T*>(q.a);
+  T* dh = reinterpret_cast<T*>(q.dh); T* dhm = reinterpret_cast<T*>(q.dhm); T* dx1 = reinterpret_cast<T*>(q.dx1);
+  T* dh1m = reinterpret_cast<T*>(q.dh1m); T* dpre = reinterpret_cast<T*>(q.dpre); T* dh1 = reinterpret_cast<T*>(q.dh1);
+  T* datt = reinterpret_cast<T*>(q.datt);
+  const int n1 = g * 64 + 16 * wq, n2 = g * 16;
+
+  auto unpack = [&](raw_t t, float (&v)[E]) {
+    if constexpr (E == 4) {
+      v[0] = bits_to_f32<T>((uint16_t)(t[0] & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(t[0] >> 16));
+      v[2] = bits_to_f32<T>((uint16_t)(t[1] & 0xffff)); v[3] = bits_to_f32<T>((uint16_t)(t[1] >> 16));
+    } else {
+      v[0] = bits_to_f32<T>((uint16_t)(t & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(t >> 16));
+    }
+  };
+  auto pack = [&](const float (&v)[E]) -> raw_t {
+    if constexpr (E == 4) return u32x2{(uint32_t)f32_to_bits<T>(v[0]) | ((uint32_t)f32_to_bits<T>(v[1]) << 16),
+                                       (uint32_t)f32_to_bits<T>(v[2]) | ((uint32_t)f32_to_bits<T>(v[3]) << 16)};
+    else return (uint32_t)f32_to_bits<T>(v[0]) | ((uint32_t)f32_to_bits<T>(v[1]) << 16);
+  };
+  auto store_row = [&](T* dst, raw_t v, bool through) {  // `through`: another workgroup reads it behind a grid barrier
+    if constexpr (E == 4) { if (through) store8_sc1(dst, v); else *reinterpret_cast<u32x2*>(dst) = v; }
+    else { if (through) __hip_atomic_store(reinterpret_cast<uint32_t*>(dst), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+           else *reinterpret_cast<uint32_t*>(dst) = v; }
+  };
+
+  // LayerNorm backward of every row (rows wave, wave + 16, ... of this wave; columns E * lane ..): layernorm_bwd_kernel's
+  // arithmetic. raw_dy / raw_x: the rows' dy and pre-norm x; the masked result goes to sA, the rows this workgroup owns
+  // (r % G == g) to dx_out / dxm_out; dgamma / dbeta are added by workgroup 0.
+  auto ln_bwd_rows = [&](raw_t (&raw_dy)[RPW], raw_t (&raw_x)[RPW], const float* mean_in, const float* rstd_in, const float* gamma,
+                         uint32_t site, T* dx_out, int64_t rs_dx, bool dx_through, T* dxm_out, int64_t rs_dxm, float* dgamma, float* dbeta) {
+    float gm[E], dg[E], db[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { gm[e] = gamma[lane * E + e]; dg[e] = 0.f; db[e] = 0.f; }
+    float xh[RPW][E], gv[RPW][E], s1[RPW], s2[RPW], rs[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
+      const bool ok = r < B;
+      const float mean = mean_in[(int64_t)rc * q.stat_stride];
+      rs[i] = rstd_in[(int64_t)rc * q.stat_stride];
+      float xv[E], dv[E];
+      unpack(raw_x[i], xv); unpack(raw_dy[i], dv);
+      s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float x_hat = ok ? (xv[e] - mean) * rs[i] : 0.f, d = ok ? dv[e] : 0.f, gg = d * gm[e];
+        xh[i][e] = x_hat; gv[i][e] = gg;
+        s1[i] += gg; s2[i] += gg * x_hat;
+        dg[e] += d * x_hat; db[e] += d;
+      }
+    }
+    wave_sum_batch<RPW>(s1);
+    wave_sum_batch<RPW>(s2);
+    const uint32_t key = dropout_key(dseed, site);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + TAIL_WAVES * i;
+      const bool ok = r < B;
+      const float m1 = s1[i] * inv_d, m2 = s2[i] * inv_d;
+      uint32_t keep = 0xFu;
+      if (drop) keep = dropout_keep4k(key, (uint64_t)((int64_t)r * q.phys_stride * D + lane * E) >> 2, thr) >> ((lane * E) & 3);
+      float o[E], om[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        o[e] = rs[i] * (gv[i][e] - m1 - xh[i][e] * m2);
+        om[e] = drop ? (((keep >> e) & 1u) ? o[e] * inv_keep : 0.f) : o[e];
+        if (!ok) { o[e] = 0.f; om[e] = 0.f; }
+      }
+      const raw_t ob = pack(o), mb = pack(om);
+      *reinterpret_cast<raw_t*>(sA + r * LDX + lane * E) = mb;
+      if (ok && r % G == g) {
+        store_row(dx_out + (int64_t)r * rs_dx + lane * E, ob, dx_through);
+        store_row(dxm_out + (int64_t)r * rs_dxm + lane * E, mb, false);
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) { sRed[(wave * 2 + 0) * D + lane * E + e] = dg[e]; sRed[(wave * 2 + 1) * D + lane * E + e] = db[e]; }
+    }
+    __syncthreads();  // (also: sA is complete)
+    if (g == 0) {
+      for (int c = tid; c < 2 * D; c += TAIL_WAVES * 64) {
+        const int which = c / D, col = c % D;
+        float t = 0.f;
+        for (int w = 0; w < TAIL_WAVES; ++w) t += sRed[(w * 2 + which) * D + col];
+        atomicAdd((which ? dbeta : dgamma) + col, t);
+      }
+    }
+  };
+
+  TAIL_STAMP(0);
+  // ---------------- this workgroup's FFN2-dgrad weights -> LDS; stage 1's rows requested
+  {
+    const T* W2t = reinterpret_cast<const T*>(q.W2t);
+    constexpr int CPR = D / 8, WCH = 64 * CPR / (TAIL_WAVES * 64);
+    u32x4 wv[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + i * TAIL_WAVES * 64, row = c / CPR, ch = c % CPR;
+      wv[i] = *reinterpret_cast<const u32x4*>(W2t + (int64_t)(g * 64 + row) * q.ldw2t + ch * 8);
+    }
+    raw_t rdy[RPW], rx[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
+      rdy[i] = *reinterpret_cast<const raw_t*>(dy + (int64_t)rc * q.rs_dy + lane * E);
+      rx[i] = *reinterpret_cast<const raw_t*>(h2 + (int64_t)rc * q.rs_d + lane * E);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + i * TAIL_WAVES * 64, row = c / CPR, ch = c % CPR;
+      *reinterpret_cast<u32x4*>(sW + row * LDX + ch * 8) = wv[i];
+    }
+    // ---------------- stage 1: LayerNorm-2 backward of every row
+    ln_bwd_rows(rdy, rx, q.mean2, q.rstd2, q.g2, q.site0 + 2, dh, q.rs_c, true, dhm, q.rs_c, q.dg2, q.db2);
+  }
+  TAIL_STAMP(1);
+  // ---------------- stage 2: d(pre)[:, 64 g ..] = ((dhm W2t^T) / (1 - p)) gated by a > 0     (16-column block wq per wave)
+  const T* W1t = reinterpret_cast<const T*>(q.W1t) + (int64_t)(n2 + li) * q.ldw1t + 8 * lq + 32 * KQ2 * wq;
+  vec8 w1f[KQ2];  // this wave's quarter of the FFN1-dgrad weights of stage 3: requested before the barrier
+  {
+    const u32x2 gate8 = m_ok ? *reinterpret_cast<const u32x2*>(a + (int64_t)m * q.rs_a + n1 + 4 * lq) : u32x2{0u, 0u};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+      const vec8 xf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sA + m * LDX + 32 * ks + 8 * lq));
+      const vec8 wf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sW + (16 * wq + li) * LDX + 32 * ks + 8 * lq));
+      acc = Act<T>::mfma16(wf, xf, acc);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KQ2; ++ks) w1f[ks] = frag16<T>(W1t + 32 * ks, true);
+    if (m_ok) {
+      const uint16_t gb[4] = {(uint16_t)(gate8[0] & 0xffff), (uint16_t)(gate8[0] >> 16), (uint16_t)(gate8[1] & 0xffff), (uint16_t)(gate8[1] >> 16)};
+      uint16_t hb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>((bits_to_f32<T>(gb[e]) > 0.f) ? acc[e] * inv_keep : 0.f);
+      store8_sc1(dpre + (int64_t)m * q.rs_dpre + n1 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+    }
+  }
+  TAIL_STAMP(2);
+  grid_sync(q.sync, G);
+  TAIL_STAMP(3);
+
+  // ---------------- stage 3: dx1[:, 16 g ..] = d(pre) W1t^T + dh        (K = 4 D, a quarter per wave)
+  const T* Wpt = reinterpret_cast<const T*>(q.Wpt) + (int64_t)(n2 + li) * q.ldwpt + 8 * lq + 32 * KQ1 * wq;
+  vec8 wpf[KQ1];
+  {
+    const T* Ar = dpre + (int64_t)m * q.rs_dpre + 8 * lq + 32 * KQ2 * wq;
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    vec8 xf[KQ2];
+#pragma unroll
+    for (int ks = 0; ks < KQ2; ++ks) xf[ks] = frag16_sc1<T>(Ar + ks * 32, m_ok);
+    u32x2 rv = {0u, 0u};
+    if (wq == 0 && m_ok) rv = load8_sc1(dh + (int64_t)m * q.rs_c + n2 + 4 * lq);
+#pragma unroll
+    for (int ks = 0; ks < KQ1; ++ks) wpf[ks] = frag16<T>(Wpt + 32 * ks, true);  // stage 5's weights
+#pragma unroll
+    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w1f[ks], xf[ks], part);
+    const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
+    if (wq == 0 && m_ok) {
+      const float r4[4] = {bits_to_f32<T>((uint16_t)(rv[0] & 0xffff)), bits_to_f32<T>((uint16_t)(rv[0] >> 16)),
+                           bits_to_f32<T>((uint16_t)(rv[1] & 0xffff)), bits_to_f32<T>((uint16_t)(rv[1] >> 16))};
+      uint16_t hb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>(acc[e] + r4[e]);
+      store8_sc1(dx1 + (int64_t)m * q.rs_c + n2 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+    }
+  }
+  TAIL_STAMP(4);
+  grid_sync(q.sync, 2 * G);
+  TAIL_STAMP(5);
+
+  // ---------------- stage 4: LayerNorm-1 backward of every row (operand of stage 5 in LDS)
+  {
+    raw_t rdy[RPW], rx[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
+      if constexpr (E == 4) load8_sc1_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 4);
+      else load4_sc1_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 2);
+      rx[i] = *reinterpret_cast<const raw_t*>(h1 + (int64_t)rc * q.rs_d + lane * E);
+    }
+    sc1_wait4(rdy);
+    ln_bwd_rows(rdy, rx, q.mean1, q.rstd1, q.g1, q.site0, dh1, q.rs_dh1, false, dh1m, q.rs_c, q.dg1, q.db1);
+  }
+  TAIL_STAMP(6);
+  // ---------------- stage 5: datt[:, 16 g ..] = dh1m Wpt^T        (K quarter per wave)
+  {
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KQ1; ++ks) {
+      const vec8 xf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(sA + m * LDX + 32 * (KQ1 * wq + ks) + 8 * lq));
+      part = Act<T>::mfma16(wpf[ks], xf, part);
+    }
+    const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
+    if (wq == 0 && m_ok) {
+      uint16_t hb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>(acc[e]);
+      *reinterpret_cast<u32x2*>(datt + (int64_t)m * q.rs_datt + n2 + 4 * lq) =
+          u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
+    }
   }
   TAIL_STAMP(7);
 }
@@ -365,9 +620,41 @@ extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stre
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(q.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8), dim3(256), 0, s, q);
+    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16), dim3(1024), 0, s, q);
+    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8), dim3(1024), 0, s, q);
     MST_CHECK_LAUNCH("row_tail_fwd_kernel");
+    return MST_OK;
+  });
+}
+
+extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr, "mst_row_tail_bwd: null args");
+  const mst_row_tail_bwd_args& q = *args;
+  MST_CHECK_ARG(q.B > 0 && q.B <= 64, "mst_row_tail_bwd: 1..64 rows (got %lld)", (long long)q.B);
+  MST_CHECK_ARG(q.D == 128 || q.D == 256, "mst_row_tail_bwd: width must be 128 or 256 (got %lld)", (long long)q.D);
+  MST_CHECK_ARG(q.dy && q.h2 && q.h1 && q.a && q.mean1 && q.rstd1 && q.mean2 && q.rstd2 && q.g1 && q.g2 && q.W2t && q.W1t && q.Wpt && q.dh &&
+                q.dhm && q.dx1 && q.dh1m && q.dpre && q.dh1 && q.datt && q.dg1 && q.db1 && q.dg2 && q.db2 && q.sync, "mst_row_tail_bwd: null pointer");
+  MST_CHECK_ARG(q.rs_dy % 8 == 0 && q.rs_d % 8 == 0 && q.rs_a % 8 == 0 && q.rs_c % 8 == 0 && q.rs_dpre % 8 == 0 && q.rs_dh1 % 8 == 0 &&
+                q.rs_datt % 8 == 0 && q.ldw2t % 8 == 0 && q.ldw1t % 8 == 0 && q.ldwpt % 8 == 0, "mst_row_tail_bwd: strides must be multiples of 8 elements");
+  MST_CHECK_ARG((((uintptr_t)q.dy | (uintptr_t)q.h2 | (uintptr_t)q.h1 | (uintptr_t)q.a | (uintptr_t)q.W2t | (uintptr_t)q.W1t | (uintptr_t)q.Wpt |
+                  (uintptr_t)q.dh | (uintptr_t)q.dhm | (uintptr_t)q.dx1 | (uintptr_t)q.dh1m | (uintptr_t)q.dpre | (uintptr_t)q.dh1 | (uintptr_t)q.datt) % 16) == 0,
+                "mst_row_tail_bwd: operands must be 16-byte aligned");
+  MST_CHECK_ARG(q.dropout_p >= 0.f && q.dropout_p < 1.f && q.phys_stride > 0 && q.stat_stride > 0, "mst_row_tail_bwd: bad dropout / strides");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(q.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    const size_t lds = (size_t)2 * 64 * ((size_t)q.D + 8) * 2 + (size_t)16 * 2 * q.D * 4 + (size_t)4 * 64 * 16 * 4;
+    static size_t opted[2] = {64 * 1024, 64 * 1024};
+    const int wi = q.D == 256 ? 0 : 1;
+    const void* fn = wi == 0 ? reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 256>) : reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 128>);
+    if (lds > opted[wi]) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("row_tail_bwd_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted[wi] = lds;
+    }
+    if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16), dim3(1024), lds, s, q);
+    else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8), dim3(1024), lds, s, q);
+    MST_CHECK_LAUNCH("row_tail_bwd_kernel");
     return MST_OK;
   });
 }

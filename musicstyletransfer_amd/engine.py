@@ -386,6 +386,7 @@ class StepPlan:
         # the attention output projection inside the feed-forward launches: "head" = W_proj + LayerNorm-1 in front of the
         # forward block (two launches less per layer at equal time), "all" = also its dgrad behind the backward block
         # (measured slower: +14 us on a launch that is already one latency-bound workgroup per CU), "0" = neither
+        self.fuse_tail_bwd = os.environ.get("MST_TAIL_BWD", "1") != "0"  # the top layer's position-0 backward chain in one launch
         fp = os.environ.get("MST_FUSE_PROJ", "head")
         self.fuse_proj, self.fuse_proj_bwd = fp != "0", fp == "all"
         self.logits = None if self.fuse_bce else act(B * T, cfg.out_dim)
@@ -805,6 +806,15 @@ class StepPlan:
             return buf.view(B, S, -1)[:, 0, :]
 
         dy = row0(self.d_enc_out)
+        if o.can_row_tail(B, D) and self.fuse_tail_bwd:
+            # LayerNorm-2 backward, both FFN dgrads, LayerNorm-1 backward and the W_proj dgrad of the B rows in one launch
+            o.row_tail_bwd(dy, row0(L.h2), row0(L.h1), row0(L.a), L.mean1, L.rstd1, L.mean2, L.rstd2, st.p(f"{pre}.ln1.gamma"),
+                           st.p(f"{pre}.ln2.gamma"), st.t(f"{pre}.ff2.weight"), st.t(f"{pre}.ff1.weight"), st.t(f"{pre}.att.W_proj.weight"),
+                           c.dh, c.dhm, c.dx1, c.dh1m, c.dpre, row0(self.sp_dh1), row0(self.sp_datt), st.grad(f"{pre}.ln1.gamma"),
+                           st.grad(f"{pre}.ln1.beta"), st.grad(f"{pre}.ln2.gamma"), st.grad(f"{pre}.ln2.beta"), self.sync_words[1:2],
+                           stat_stride=S, phys_stride=S, dropout_p=p, dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
+            dff, dproj = c.dhm, c.dh1m
+            return self._top_encoder_layer_bwd_rest(i, L, x_in, dx_in, t, next_ln, dff, dproj)
         if p > 0:
             o.layernorm_bwd(row0(L.h2), st.p(f"{pre}.ln2.gamma"), L.mean2, L.rstd2, dy, c.dh, st.grad(f"{pre}.ln2.gamma"),
                             st.grad(f"{pre}.ln2.beta"), D=D, M=B, row_id_stride=S, dx_masked=c.dhm, mask_mode=1,
@@ -828,6 +838,19 @@ class StepPlan:
             dproj = dh1_rows
         # d(attention output): rows b*S of a buffer that is zero elsewhere
         o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), self.sp_datt, M=B, N=D, K=D, c_remap=(1, S, 0))
+        return self._top_encoder_layer_bwd_rest(i, L, x_in, dx_in, t, next_ln, dff, dproj)
+
+    def _top_encoder_layer_bwd_rest(self, i, L, x_in, dx_in, t, next_ln, dff, dproj):
+        """attention backward (dO is zero outside position 0), the K | Q | V dgrad and the layer's deferred weight gradients"""
+        cfg, st, B = self.cfg, self.store, self.B
+        S = self.T
+        D, H = cfg.e_model, cfg.e_heads
+        pre = f"encoder.layer{i}"
+        c = self.top
+
+        def row0(buf):
+            return buf.view(B, S, -1)[:, 0, :]
+
         o.attn_bwd(L.qkv, self.keymask_e, L.lse, self.sp_datt, t.dqkv, t.delta, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
         if next_ln is not None:  # as in _layer_bwd: the layer below's LayerNorm-2 backward rides on this GEMM
             kw, t_below = next_ln

@@ -106,6 +106,27 @@ def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a
     call("mst_row_tail_fwd", C.byref(q), stream())
 
 
+def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wpt, dh, dhm, dx1, dh1m, dpre, dh1, datt, dg1, db1, dg2, db2,
+                 sync, stat_stride, phys_stride, dropout_p=0.0, dropout_seed_ptr=None, site0=0):
+    """backward of row_tail_fwd's chain in one launch (mst_row_tail_bwd); dy / h2 / h1 / a / dh1 / datt: [B, width] row views,
+    dh / dhm / dx1 / dh1m / dpre: compact [B, width] scratch; sync: one zeroed int32 device word"""
+    q = _lib.RowTailBwdArgs()
+    q.dtype, q.B, q.D = dt(dy), dy.shape[0], Wpt.shape[0]
+    q.dy, q.rs_dy = ptr(dy), dy.stride(0)
+    assert h2.stride(0) == h1.stride(0)
+    q.h2, q.h1, q.rs_d, q.a, q.rs_a = ptr(h2), ptr(h1), h2.stride(0), ptr(a), a.stride(0)
+    q.mean1, q.rstd1, q.mean2, q.rstd2, q.stat_stride = ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2), stat_stride
+    q.g1, q.g2 = ptr(g1), ptr(g2)
+    q.W2t, q.ldw2t, q.W1t, q.ldw1t, q.Wpt, q.ldwpt = ptr(W2t), ld(W2t), ptr(W1t), ld(W1t), ptr(Wpt), ld(Wpt)
+    assert dh.stride(0) == dhm.stride(0) == dx1.stride(0) == dh1m.stride(0)
+    q.dh, q.dhm, q.dx1, q.dh1m, q.rs_c = ptr(dh), ptr(dhm), ptr(dx1), ptr(dh1m), dh.stride(0)
+    q.dpre, q.rs_dpre, q.dh1, q.rs_dh1, q.datt, q.rs_datt = ptr(dpre), dpre.stride(0), ptr(dh1), dh1.stride(0), ptr(datt), datt.stride(0)
+    q.dg1, q.db1, q.dg2, q.db2 = ptr(dg1), ptr(db1), ptr(dg2), ptr(db2)
+    q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = dropout_p, 0, ptr(dropout_seed_ptr), site0
+    q.phys_stride, q.sync = phys_stride, ptr(sync)
+    call("mst_row_tail_bwd", C.byref(q), stream())
+
+
 def can_fuse_bce(P, T):
     """shapes the output-layer GEMM + BCE launch exists for (mst_gemm_sigmoid_bce)"""
     return P in (128, 256) and T % 64 == 0

@@ -34,8 +34,8 @@ def close(a, b, rtol, atol, what=""):
 @pytest.mark.parametrize("B,S,D,p,dtype", [(64, 8, 256, 0.2, BF), (5, 3, 128, 0.0, BF), (33, 4, 256, 0.2, torch.float16), (16, 2, 128, 0.2, BF)])
 def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     """mst_row_tail_fwd (W_proj + LN1 + FFN1 + FFN2 + LN2 on the B position-0 rows, one launch with three grid barriers)
-    against the five launches it replaces on the same strided rows: same MFMA order per element and the same dropout
-    counters, so h1 / a are bit-identical; the LayerNorms sum a row in another order (an ulp here and there)"""
+    against the five launches it replaces on the same strided rows: the same dropout counters and rounding points; the K
+    sums and the LayerNorm sums run in another order (an ulp here and there)"""
     o = ops()
     F = 4 * D
     g = torch.Generator().manual_seed(7)
@@ -66,9 +66,9 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
                    dropout_seed_ptr=seedp if p > 0 else None, site0=6)
     torch.cuda.synchronize()
     assert int(sync[0].item()) == 3 * (D // 16)  # three barriers, every workgroup arrived at each
-    assert torch.equal(row0(f["h1"]), row0(u["h1"])), "h1"
+    # (the 16-column stages sum their K range in four quarters, one per group of waves: another order of the same fp32 sums)
     ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
-    for k in ("x1", "a", "h2", "x2"):
+    for k in ("h1", "x1", "a", "h2", "x2"):
         d = (row0(f[k]).float() - row0(u[k]).float()).abs()
         ref = row0(u[k]).float().abs().clamp(min=1.0)
         assert (d <= 2 * ulp * ref).all(), (k, d.max().item())
@@ -77,6 +77,63 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
         close(f[k][::S], u[k][::S], 2e-3, 2e-4, k)
     # rows other than position 0 are never touched
     assert (f["h1"].view(B, S, -1)[:, 1:] == 0).all() and (f["a"].view(B, S, -1)[:, 1:] == 0).all()
+
+
+@pytest.mark.parametrize("B,S,D,p,dtype", [(64, 256, 256, 0.2, BF), (64, 8, 128, 0.2, BF), (37, 4, 256, 0.0, BF), (64, 16, 256, 0.1, torch.float16)])
+def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
+    """mst_row_tail_bwd (LayerNorm-2 backward, FFN2 / FFN1 dgrads, LayerNorm-1 backward, W_proj dgrad on the B position-0 rows in
+    one launch with two grid barriers) against the five launches it replaces on the same strided rows: the same dropout counters
+    and MFMA order; the LayerNorm sums run in another order, so results agree to a rounding of the activation type"""
+    o = ops()
+    F = 4 * D
+    g = torch.Generator().manual_seed(11)
+    r = lambda *sh, sc=1.0, dt=dtype: (torch.randn(*sh, generator=g) * sc).to(dt).to(gpu)
+    dy, h2, h1 = r(B * S, D, sc=0.5), r(B * S, D), r(B * S, D)
+    a = torch.relu(r(B * S, F))
+    W2t, W1t, Wpt = r(F, D, sc=0.05), r(D, F, sc=0.05), r(D, D, sc=0.06)
+    g1, g2 = 1 + r(D, sc=0.1, dt=torch.float32), 1 + r(D, sc=0.1, dt=torch.float32)
+    row0 = lambda t: t.view(B, S, -1)[:, 0, :]
+    m1, m2 = torch.zeros(B * S, device=gpu), torch.zeros(B * S, device=gpu)
+    r1, r2 = torch.zeros(B * S, device=gpu), torch.zeros(B * S, device=gpu)
+    m1[::S], m2[::S] = row0(h1).float().mean(1), row0(h2).float().mean(1)
+    r1[::S] = 1.0 / torch.sqrt(row0(h1).float().var(1, unbiased=False) + 1e-5)
+    r2[::S] = 1.0 / torch.sqrt(row0(h2).float().var(1, unbiased=False) + 1e-5)
+    seedp = torch.tensor([99, 0, 0, 0], dtype=torch.int64, device=gpu)
+    inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+    dk = dict(dropout_p=p, dropout_seed_ptr=seedp) if p > 0 else {}
+
+    def bufs():
+        z = lambda n, w: torch.zeros(n, w, dtype=dtype, device=gpu)
+        return dict(dh=z(B, D), dhm=z(B, D), dx1=z(B, D), dh1m=z(B, D), dpre=z(B, F), dh1=z(B * S, D), datt=z(B * S, D),
+                    dg1=torch.zeros(D, device=gpu), db1=torch.zeros(D, device=gpu), dg2=torch.zeros(D, device=gpu), db2=torch.zeros(D, device=gpu))
+
+    u = bufs()
+    mk = dict(dx_masked=u["dhm"], mask_mode=1, dropout_site=8, **dk) if p > 0 else {}
+    o.layernorm_bwd(row0(h2), g2, m2, r2, row0(dy), u["dh"], u["dg2"], u["db2"], D=D, M=B, row_id_stride=S, **mk)
+    dff = u["dhm"] if p > 0 else u["dh"]
+    o.gemm_nt(dff, W2t, u["dpre"], N=F, K=D, gate=row0(a), alpha=inv_keep)
+    o.gemm_nt(u["dpre"], W1t, u["dx1"], N=D, K=F, resid=u["dh"])
+    mk = dict(dx_masked=u["dh1m"], mask_mode=1, dropout_site=6, **dk) if p > 0 else {}
+    o.layernorm_bwd(row0(h1), g1, m1, r1, u["dx1"], row0(u["dh1"]), u["dg1"], u["db1"], D=D, M=B, row_id_stride=S, **mk)
+    dproj = u["dh1m"] if p > 0 else row0(u["dh1"])
+    o.gemm_nt(dproj, Wpt, u["datt"], M=B, N=D, K=D, c_remap=(1, S, 0))
+    f = bufs()
+    sync = torch.zeros(4, dtype=torch.int32, device=gpu)
+    o.row_tail_bwd(row0(dy), row0(h2), row0(h1), row0(a), m1, r1, m2, r2, g1, g2, W2t, W1t, Wpt, f["dh"], f["dhm"], f["dx1"], f["dh1m"], f["dpre"],
+                   row0(f["dh1"]), row0(f["datt"]), f["dg1"], f["db1"], f["dg2"], f["db2"], sync[1:2], stat_stride=S, phys_stride=S,
+                   dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6)
+    torch.cuda.synchronize()
+    assert int(sync[1].item()) == 2 * (D // 16)  # two barriers, every workgroup arrived at each
+    keys = ["dh", "dpre", "dx1", "dh1", "datt"] + (["dhm", "dh1m"] if p > 0 else [])
+    for k in keys:
+        sc = u[k].float().abs().max().item()
+        assert sc > 0, k
+        close(f[k], u[k], 2e-2, 1e-2 * sc, k)
+        assert (f[k] != u[k]).float().mean().item() < (0.1 if dtype == BF else 0.4), k  # (fp16: finer grid, more last-bit flips)
+    for k in ("dg1", "db1", "dg2", "db2"):
+        close(f[k], u[k], 2e-3, 2e-3 * u[k].abs().max().item(), k)
+    # rows other than position 0 are never touched
+    assert (f["dh1"].view(B, S, -1)[:, 1:] == 0).all() and (f["datt"].view(B, S, -1)[:, 1:] == 0).all()
 
 
 # ------------------------------------------------------------------------------------------ layout
