@@ -396,7 +396,7 @@ int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const float* sigma
  * = mst_gemm_nt (+resid) · mst_layernorm_fwd · mst_gemm_nt (ReLU) · mst_gemm_nt (+resid) · mst_layernorm_fwd on those rows,
  * same rounding points and dropout counters (sites site0, site0+1, site0+2; counter row = row * phys_stride), as D / 16
  * workgroups that own output-column slices and meet at three grid barriers. Row r of every tensor sits at element offset
- * r * (its row stride); statistics at index r * stat_stride. `sync`: one zeroed device word (mst_step_begin's zero list).
+ * r * (its row stride); statistics at index r * stat_stride. `sync`: THREE zeroed device words (mst_step_begin's zero list): barrier counter, claimed XCD, roles handed out — the launch oversubscribes the grid and keeps the workgroups of one XCD (one L2).
  * ------------------------------------------------------------------------ */
 typedef struct mst_row_tail_args {
   int32_t dtype;
@@ -425,7 +425,7 @@ int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
  *  -> mst_gemm_nt(dh1m, Wpt)                                 datt rows
  * in one launch (same results to rounding of the LayerNorm sums). W2t [4 D, D], W1t [D, 4 D], Wpt [D, D]: the transposed
  * 16-bit weights (K-contiguous dgrad operands). dh / dhm / dx1 / dh1m: compact [B, >= D] scratch rows (row stride rs_c);
- * dh1 / datt: rows of the strided full-size buffers the following launches read. `sync`: one zeroed device word. */
+ * dh1 / datt: rows of the strided full-size buffers the following launches read. `sync`: three zeroed device words (as above). */
 typedef struct mst_row_tail_bwd_args {
   int32_t dtype;
   int64_t B, D;

@@ -107,6 +107,70 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok)
   return __builtin_bit_cast(typename Act<T>::vec8, v);
 }
 
+// diagnostic build only (-DMST_TAIL_STAMPS): workgroup 0 leaves s_memrealtime stamps (100 MHz) in sync[8 + i]
+#ifdef MST_TAIL_STAMPS
+#define TAIL_STAMP(i) do { if (g == 0 && threadIdx.x == 0) q.sync[8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_STAMP(i) do { } while (0)
+#endif
+
+// ONE XCD. An agent-scope (sc1) access has to be served behind the L2s — each XCD has its own, and they are not coherent
+// with each other — so with the G workgroups dealt round-robin over the eight XCDs every row that crossed a barrier
+// travelled over the fabric: 8 us for the 128 KB of stage 3, 3-5 us per barrier waiting for write-through acknowledgements
+// from memory. The kernels therefore launch 12 x more workgroups than they need and let them JOIN: the first arrival
+// claims its XCD (s_getreg XCC_ID) with a compare-and-swap, workgroups on that XCD take the roles 0..G-1 in arrival order,
+// everybody else leaves at once. All participants then share one L2, and the bytes that cross a barrier move with
+// workgroup-scope-in-threadgroup-split semantics (sc0: stores write through the CU's L1 to the L2, loads miss in the L1 and
+// are served by the L2). Correct for ANY dispatch order (participants share an XCD by construction; a launch that put
+// fewer than G workgroups on the claimed XCD would leave the bounded barrier spin and fail the step's parity, not hang).
+// sync: [0] barrier counter, [1] claimed XCD + 1, [2] roles handed out (all zero at launch).
+#ifndef MST_TAIL_OVERSUBSCRIBE
+#define MST_TAIL_OVERSUBSCRIBE 12  /* 8 is exact under round-robin dispatch; measured 8 / 10 / 12 / 16: 0.7245 / 0.7234 / 0.7256 / 0.7256 ms per step */
+#endif
+constexpr int TAIL_OVERSUBSCRIBE = MST_TAIL_OVERSUBSCRIBE;
+__device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
+  __shared__ int role;
+  if (threadIdx.x == 0) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xFu) + 1u;
+    uint32_t seen = 0u;
+    __hip_atomic_compare_exchange_strong(sync + 1, &seen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t claimed = seen == 0u ? xcc : seen;
+    int r = -1;
+    if (claimed == xcc) {
+      const uint32_t k = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k < (uint32_t)G) r = (int)k;
+    }
+    role = r;
+  }
+  __syncthreads();
+  return role;
+}
+__device__ __forceinline__ void store8_l2(void* p, u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store4_l2(void* p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void load16_l2_nowait(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void load8_l2_nowait(u32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void load4_l2_nowait(uint32_t& dst, const void* p) {
+  asm volatile("global_load_dword %0, %1, off sc0" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename V, int N>
+__device__ __forceinline__ void l2_wait(V (&r)[N]) {  // the *_nowait destinations may be used only behind this
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8, "batch size");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]) : : "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : : "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : : "memory");
+}
+
 // LayerNorm of one row held as 4 elements per lane (D = 256) or 2 (D = 128): layernorm_fwd_kernel's arithmetic
 template <typename T, int D>
 __device__ __forceinline__ void ln_row(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -115,12 +179,16 @@ __device__ __forceinline__ void ln_row(const T* __restrict__ x, const float* __r
   float v[E];
   float s = 0.f;
   if constexpr (E == 4) {
-    const u32x2 r = load8_sc1(x + lane * 4);
-    v[0] = bits_to_f32<T>((uint16_t)(r[0] & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r[0] >> 16));
-    v[2] = bits_to_f32<T>((uint16_t)(r[1] & 0xffff)); v[3] = bits_to_f32<T>((uint16_t)(r[1] >> 16));
+    u32x2 r[1];
+    load8_l2_nowait(r[0], x + lane * 4);
+    l2_wait(r);
+    v[0] = bits_to_f32<T>((uint16_t)(r[0][0] & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r[0][0] >> 16));
+    v[2] = bits_to_f32<T>((uint16_t)(r[0][1] & 0xffff)); v[3] = bits_to_f32<T>((uint16_t)(r[0][1] >> 16));
   } else {
-    const uint32_t r = load4_sc1(x + lane * 2);
-    v[0] = bits_to_f32<T>((uint16_t)(r & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r >> 16));
+    uint32_t r[1];
+    load4_l2_nowait(r[0], x + lane * 2);
+    l2_wait(r);
+    v[0] = bits_to_f32<T>((uint16_t)(r[0] & 0xffff)); v[1] = bits_to_f32<T>((uint16_t)(r[0] >> 16));
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) s += v[e];
@@ -132,13 +200,6 @@ __device__ __forceinline__ void ln_row(const T* __restrict__ x, const float* __r
 #pragma unroll
   for (int e = 0; e < E; ++e) y[e] = (v[e] - mean) * rstd * gamma[lane * E + e] + beta[lane * E + e];
 }
-
-// diagnostic build only (-DMST_TAIL_STAMPS): workgroup 0 leaves s_memrealtime stamps (100 MHz) in sync[8 + i]
-#ifdef MST_TAIL_STAMPS
-#define TAIL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) q.sync[8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TAIL_STAMP(i) do { } while (0)
-#endif
 
 // Sixteen waves per workgroup (four per SIMD): every stage is a chain of dependent L2 round trips, and with one wave per
 // SIMD nothing ran under them (four waves: forward 30 us, backward 43 us against 39 for its five launches). Wave (mi, wq):
@@ -176,11 +237,13 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = blockIdx.x;
+  const int g = tail_join(q.sync, G);
+  if (g < 0) return;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
   const int m = mi * 16 + li;  // the row this lane's accumulator column belongs to
   const bool m_ok = m < B;
+  const int mc = m_ok ? m : 0;  // (row of the unconditional loads)
   const int64_t pm = (int64_t)m * q.phys_stride;  // physical row in the [B * S, N] tensors: the dropout counter's row
   const float p = q.dropout_p;
   const bool drop = p > 0.f;
@@ -212,7 +275,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
       if (drop) t = ((keep >> e) & 1u) ? t * inv_keep : 0.f;
       hb[e] = f32_to_bits<T>(t + r4[e]);
     }
-    store8_sc1(dst + n, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+    store8_l2(dst + n, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
   };
 
   TAIL_STAMP(0);
@@ -251,10 +314,10 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
-      if constexpr (E == 4) load8_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 4);
-      else load4_sc1_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 2);
+      if constexpr (E == 4) load8_l2_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 4);
+      else load4_l2_nowait(raw[i], h1 + (int64_t)rc * q.rs_d + lane * 2);
     }
-    sc1_wait4(raw);
+    l2_wait(raw);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const bool ok = wave + TAIL_WAVES * i < B;
@@ -333,13 +396,14 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 
   // ---------------- stage 3: h2[:, 16 g ..] = x1 + dropout(a W2^T + b2)        (K = 4 D: the whole hidden row, a quarter per wave)
   {
-    const T* Ar = a + (int64_t)m * q.rs_a + 8 * lq + 32 * KQ2 * wq;
+    const T* Ar = a + (int64_t)mc * q.rs_a + 8 * lq + 32 * KQ2 * wq;
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
-    vec8 xf[KQ2];  // the hidden row's fragments: every load in flight at once
+    u32x4 xr[KQ2];  // the hidden row's fragments: every load in flight at once
 #pragma unroll
-    for (int ks = 0; ks < KQ2; ++ks) xf[ks] = frag16_sc1<T>(Ar + ks * 32, m_ok);
+    for (int ks = 0; ks < KQ2; ++ks) load16_l2_nowait(xr[ks], Ar + ks * 32);
+    l2_wait(xr);
 #pragma unroll
-    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w2f[ks], xf[ks], part);
+    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w2f[ks], __builtin_bit_cast(vec8, m_ok ? xr[ks] : u32x4{0u, 0u, 0u, 0u}), part);
     const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
     if (wq == 0 && m_ok) finish4(acc, q.b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
   }
@@ -382,11 +446,13 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = blockIdx.x;
+  const int g = tail_join(q.sync, G);
+  if (g < 0) return;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
   const int m = mi * 16 + li;
   const bool m_ok = m < B;
+  const int mc = m_ok ? m : 0;
   const float p = q.dropout_p;
   const bool drop = p > 0.f;
   const uint64_t dseed = q.dropout_seed ^ ((drop && q.dropout_seed_ptr) ? q.dropout_seed_ptr[0] : 0ull);
@@ -414,9 +480,8 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
     else return (uint32_t)f32_to_bits<T>(v[0]) | ((uint32_t)f32_to_bits<T>(v[1]) << 16);
   };
   auto store_row = [&](T* dst, raw_t v, bool through) {  // `through`: another workgroup reads it behind a grid barrier
-    if constexpr (E == 4) { if (through) store8_sc1(dst, v); else *reinterpret_cast<u32x2*>(dst) = v; }
-    else { if (through) __hip_atomic_store(reinterpret_cast<uint32_t*>(dst), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-           else *reinterpret_cast<uint32_t*>(dst) = v; }
+    if constexpr (E == 4) { if (through) store8_l2(dst, v); else *reinterpret_cast<u32x2*>(dst) = v; }
+    else { if (through) store4_l2(dst, v); else *reinterpret_cast<uint32_t*>(dst) = v; }
   };
 
   // LayerNorm backward of every row (rows wave, wave + 16, ... of this wave; columns E * lane ..): layernorm_bwd_kernel's
@@ -530,7 +595,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
       uint16_t hb[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>((bits_to_f32<T>(gb[e]) > 0.f) ? acc[e] * inv_keep : 0.f);
-      store8_sc1(dpre + (int64_t)m * q.rs_dpre + n1 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+      store8_l2(dpre + (int64_t)m * q.rs_dpre + n1 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
     }
   }
   TAIL_STAMP(2);
@@ -541,17 +606,20 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   const T* Wpt = reinterpret_cast<const T*>(q.Wpt) + (int64_t)(n2 + li) * q.ldwpt + 8 * lq + 32 * KQ1 * wq;
   vec8 wpf[KQ1];
   {
-    const T* Ar = dpre + (int64_t)m * q.rs_dpre + 8 * lq + 32 * KQ2 * wq;
+    const T* Ar = dpre + (int64_t)mc * q.rs_dpre + 8 * lq + 32 * KQ2 * wq;
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
-    vec8 xf[KQ2];
+    u32x4 xr[KQ2];
 #pragma unroll
-    for (int ks = 0; ks < KQ2; ++ks) xf[ks] = frag16_sc1<T>(Ar + ks * 32, m_ok);
-    u32x2 rv = {0u, 0u};
-    if (wq == 0 && m_ok) rv = load8_sc1(dh + (int64_t)m * q.rs_c + n2 + 4 * lq);
+    for (int ks = 0; ks < KQ2; ++ks) load16_l2_nowait(xr[ks], Ar + ks * 32);
+    u32x2 rvv[1];
+    load8_l2_nowait(rvv[0], dh + (int64_t)mc * q.rs_c + n2 + 4 * lq);
+    l2_wait(xr);
+    l2_wait(rvv);
+    const u32x2 rv = rvv[0];
 #pragma unroll
     for (int ks = 0; ks < KQ1; ++ks) wpf[ks] = frag16<T>(Wpt + 32 * ks, true);  // stage 5's weights
 #pragma unroll
-    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w1f[ks], xf[ks], part);
+    for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w1f[ks], __builtin_bit_cast(vec8, m_ok ? xr[ks] : u32x4{0u, 0u, 0u, 0u}), part);
     const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
     if (wq == 0 && m_ok) {
       const float r4[4] = {bits_to_f32<T>((uint16_t)(rv[0] & 0xffff)), bits_to_f32<T>((uint16_t)(rv[0] >> 16)),
@@ -559,7 +627,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
       uint16_t hb[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>(acc[e] + r4[e]);
-      store8_sc1(dx1 + (int64_t)m * q.rs_c + n2 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
+      store8_l2(dx1 + (int64_t)m * q.rs_c + n2 + 4 * lq, u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)});
     }
   }
   TAIL_STAMP(4);
@@ -572,11 +640,11 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = wave + TAIL_WAVES * i, rc = r < B ? r : B - 1;
-      if constexpr (E == 4) load8_sc1_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 4);
-      else load4_sc1_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 2);
+      if constexpr (E == 4) load8_l2_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 4);
+      else load4_l2_nowait(rdy[i], dx1 + (int64_t)rc * q.rs_c + lane * 2);
       rx[i] = *reinterpret_cast<const raw_t*>(h1 + (int64_t)rc * q.rs_d + lane * E);
     }
-    sc1_wait4(rdy);
+    l2_wait(rdy);
     ln_bwd_rows(rdy, rx, q.mean1, q.rstd1, q.g1, q.site0, dh1, q.rs_dh1, false, dh1m, q.rs_c, q.dg1, q.db1);
   }
   TAIL_STAMP(6);
@@ -620,8 +688,8 @@ extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stre
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(q.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16), dim3(1024), 0, s, q);
-    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8), dim3(1024), 0, s, q);
+    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q);
+    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q);
     MST_CHECK_LAUNCH("row_tail_fwd_kernel");
     return MST_OK;
   });
@@ -652,8 +720,8 @@ extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t 
       if (e != hipSuccess) { set_error("row_tail_bwd_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
       opted[wi] = lds;
     }
-    if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16), dim3(1024), lds, s, q);
-    else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8), dim3(1024), lds, s, q);
+    if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q);
+    else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q);
     MST_CHECK_LAUNCH("row_tail_bwd_kernel");
     return MST_OK;
   });

@@ -376,7 +376,7 @@ class StepPlan:
         # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B);
         # the same zero list clears the grid-barrier words of the one-launch position-0 tails (mst_row_tail_*)
         nb4 = (B + 3) // 4 * 4
-        self._recon_buf = torch.zeros(nb4 + 4, **f32)
+        self._recon_buf = torch.zeros(nb4 + 8, **f32)  # (+ 8 sync words of the position-0 tail launches, zeroed with it by step_begin)
         self.recon = self._recon_buf[:B]
         self.sync_words = self._recon_buf[nb4:].view(torch.int32)
         self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
@@ -557,7 +557,7 @@ class StepPlan:
                            st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), st.h(f"{pre}.ff1.weight"), st.p(f"{pre}.ff1.bias"),
                            st.h(f"{pre}.ff2.weight"), st.p(f"{pre}.ff2.bias"), st.p(f"{pre}.ln2.gamma"), st.p(f"{pre}.ln2.beta"),
                            row0(L.h1), row0(L.x1), row0(L.a), row0(L.h2), row0(L.x2), L.mean1, L.rstd1, L.mean2, L.rstd2,
-                           self.sync_words[0:1], stat_stride=S, phys_stride=S, dropout_p=p,
+                           self.sync_words[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
                            dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
             return L.x2
         rows = (1, S, 0)  # output row b -> physical row b*S
@@ -811,7 +811,7 @@ class StepPlan:
             o.row_tail_bwd(dy, row0(L.h2), row0(L.h1), row0(L.a), L.mean1, L.rstd1, L.mean2, L.rstd2, st.p(f"{pre}.ln1.gamma"),
                            st.p(f"{pre}.ln2.gamma"), st.t(f"{pre}.ff2.weight"), st.t(f"{pre}.ff1.weight"), st.t(f"{pre}.att.W_proj.weight"),
                            c.dh, c.dhm, c.dx1, c.dh1m, c.dpre, row0(self.sp_dh1), row0(self.sp_datt), st.grad(f"{pre}.ln1.gamma"),
-                           st.grad(f"{pre}.ln1.beta"), st.grad(f"{pre}.ln2.gamma"), st.grad(f"{pre}.ln2.beta"), self.sync_words[1:2],
+                           st.grad(f"{pre}.ln1.beta"), st.grad(f"{pre}.ln2.gamma"), st.grad(f"{pre}.ln2.beta"), self.sync_words[4:7],
                            stat_stride=S, phys_stride=S, dropout_p=p, dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
             dff, dproj = c.dhm, c.dh1m
             return self._top_encoder_layer_bwd_rest(i, L, x_in, dx_in, t, next_ln, dff, dproj)

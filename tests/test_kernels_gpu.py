@@ -60,9 +60,9 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     o.gemm_nt(row0(u["a"]), W2, u["h2"], M=B, K=F, bias=b2, resid=row0(u["x1"]), c_remap=rows, **dk(8))
     o.layernorm_fwd(row0(u["h2"]), g2, be2, row0(u["x2"]), u["m2"], u["r2"], D=D, M=B, row_id_stride=S)
     f = bufs()
-    sync = torch.zeros(4, dtype=torch.int32, device=gpu)
+    sync = torch.zeros(8, dtype=torch.int32, device=gpu)
     o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(f["h1"]), row0(f["x1"]), row0(f["a"]), row0(f["h2"]),
-                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:1], stat_stride=S, phys_stride=S, dropout_p=p,
+                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
                    dropout_seed_ptr=seedp if p > 0 else None, site0=6)
     torch.cuda.synchronize()
     assert int(sync[0].item()) == 3 * (D // 16)  # three barriers, every workgroup arrived at each
@@ -118,12 +118,13 @@ def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     dproj = u["dh1m"] if p > 0 else row0(u["dh1"])
     o.gemm_nt(dproj, Wpt, u["datt"], M=B, N=D, K=D, c_remap=(1, S, 0))
     f = bufs()
-    sync = torch.zeros(4, dtype=torch.int32, device=gpu)
+    sync = torch.zeros(8, dtype=torch.int32, device=gpu)
     o.row_tail_bwd(row0(dy), row0(h2), row0(h1), row0(a), m1, r1, m2, r2, g1, g2, W2t, W1t, Wpt, f["dh"], f["dhm"], f["dx1"], f["dh1m"], f["dpre"],
-                   row0(f["dh1"]), row0(f["datt"]), f["dg1"], f["db1"], f["dg2"], f["db2"], sync[1:2], stat_stride=S, phys_stride=S,
+                   row0(f["dh1"]), row0(f["datt"]), f["dg1"], f["db1"], f["dg2"], f["db2"], sync[4:7], stat_stride=S, phys_stride=S,
                    dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6)
     torch.cuda.synchronize()
-    assert int(sync[1].item()) == 2 * (D // 16)  # two barriers, every workgroup arrived at each
+    assert int(sync[4].item()) == 2 * (D // 16)  # two barriers, every participating workgroup arrived at each
+    assert 1 <= int(sync[5].item()) <= 8 and int(sync[6].item()) >= D // 16  # one XCD claimed, enough workgroups found on it
     keys = ["dh", "dpre", "dx1", "dh1", "datt"] + (["dhm", "dh1m"] if p > 0 else [])
     for k in keys:
         sc = u[k].float().abs().max().item()

@@ -25,7 +25,7 @@ for it in range(12):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(h1), row0(x1), row0(a), row0(h2), row0(x2),
-                   st[0], st[1], st[2], st[3], sync[0:1], stat_stride=S, phys_stride=S, dropout_p=0.2, dropout_seed_ptr=seedp, site0=6)
+                   st[0], st[1], st[2], st[3], sync[0:3], stat_stride=S, phys_stride=S, dropout_p=0.2, dropout_seed_ptr=seedp, site0=6)
     e1.record(); torch.cuda.synchronize()
     t = sync[8:20].cpu().numpy().astype(np.int64)
     inner = [((t[16 - 8] - t[2]) & 0xffffffff) / 100.0, ((t[17 - 8] - t[16 - 8]) & 0xffffffff) / 100.0, ((t[18 - 8] - t[17 - 8]) & 0xffffffff) / 100.0,
