@@ -835,8 +835,14 @@ __host__ __device__ inline bool lone_row_shape(int64_t S, int dh) { return dh <=
 #define MST_ATT16_WAVES_BWD 4
 #endif
 // (batch*head) of a 1-D grid; batch elements are dealt to the XCDs so that the heads of one element share an L2
+#ifndef MST_XCD_ROWS
+#define MST_XCD_ROWS 1
+#endif
 __device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
   const int64_t lin = blockIdx.x;
+  // (batch, head) pairs in XCD-contiguous eighths: the samples whose K | Q | V rows the projection GEMM's tiles left in
+  // this XCD's L2 (common.hpp xcd_chunk; the heads of a sample stay together)
+  if (MST_XCD_ROWS) return xcd_chunk(lin, B * H);
   if (B % 8 != 0) return lin;
   const int64_t xcd = lin % 8, j = lin / 8;
   return (xcd + 8 * (j / H)) * H + j % H;

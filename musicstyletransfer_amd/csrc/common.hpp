@@ -129,6 +129,16 @@ template <int LANES> __device__ __forceinline__ float group_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
+// Work index of launch-order id `bid` when the n items are to sit in XCD-contiguous eighths: workgroup ids are dealt
+// round-robin to the 8 XCDs, so XCD x receives ids x, x + 8, ... and takes items [x n / 8, (x + 1) n / 8). EVERY kernel
+// that walks the rows of the activations uses this order (the GEMMs through gemm_mainloop's tile order): rows
+// [x M / 8, (x + 1) M / 8) are produced and consumed by XCD x, so a launch finds its input rows in the L2 the previous
+// launch left them in instead of fetching them across the fabric.
+__device__ __forceinline__ int64_t xcd_chunk(int64_t bid, int64_t n) {
+  const int64_t q = n / 8, r = n % 8, x = bid % 8, y = bid / 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+}
+
 // logical → physical row remap (see mst_gemm_args)
 __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t rpg, int64_t stride, int64_t off) {
   return rpg > 0 ? (m / rpg) * stride + off + (m % rpg) : m;

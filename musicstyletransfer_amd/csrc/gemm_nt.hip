@@ -847,7 +847,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   float* sBias1 = reinterpret_cast<float*>(sX + BM * LDA);  // [F] the first GEMM's bias (zeros without one)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+#ifndef MST_XCD_ROWS
+#define MST_XCD_ROWS 1
+#endif
+  // (row tiles in XCD-contiguous eighths, like the GEMMs' tiles and the attention workgroups: common.hpp xcd_chunk)
+  const int64_t m0 = (MST_XCD_ROWS ? xcd_chunk(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x) * BM;
   const int64_t F = g1.N;
   FFN_STAMP(0); FFN_RT(190);
   const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
