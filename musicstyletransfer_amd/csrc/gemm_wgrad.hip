@@ -19,7 +19,8 @@ namespace mst {
 constexpr int WG_MAXP = 16;  // problems per launch (the whole backward pass of configs[1] is 15)
 struct WgradBatch {
   int n;
-  int split;                      // largest M split factor of the batch
+  uint32_t narrow;                // bit p: problem p runs 256 x 128 tiles inside the 256 x 256 launch (K <= 128: half the MFMAs of a
+                                  // 256 x 256 tile on the same bytes); the slot layout stays that of the wide tiles
   int split_p[WG_MAXP];           // M split of each problem: min(split, what its row count supports) — a 64-row problem
                                   // gets ONE slab instead of `split` workgroups of which all but one exit at once
   int64_t item_prefix[WG_MAXP + 1];  // prefix sums of tiles_p * split_p: work items of problem p are [prefix[p], prefix[p+1])
@@ -52,6 +53,7 @@ __device__ __forceinline__ i16x4 tr_read(const void* p) {
 #define MST_WGRAD_STAMP_WG 64
 #endif
 __device__ uint64_t g_wgrad_stamps[4 + 64 * 4];
+__device__ uint64_t g_wgrad_wg[512 * 2];  // [item] = realtime stamps (100 MHz) at the workgroup's start and end
 #define WG_STAMP(slot) do { if (blockIdx.x == MST_WGRAD_STAMP_WG && threadIdx.x == 0 && (slot) < 4 + 64 * 4) g_wgrad_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WG_STAMP(slot) do { } while (0)
@@ -61,7 +63,7 @@ __device__ uint64_t g_wgrad_stamps[4 + 64 * 4];
 // exactly 256 VGPRs, and a run-time branch in the stage loop (an extra register array, or partial-register updates)
 // cost EVERY problem of the launch (92 -> 160 us for the step's batch); as two bodies in one kernel the 16-bit problems
 // keep their code and the two embedding-table problems take the other copy.
-template <typename T, int BN, int BKO, int WGN, int WGK, bool AU8>
+template <typename T, int BN, int BKO, int WGN, int WGK, bool AU8, int SLOT = BN * BKO>
 __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* smem, int pi, int64_t item) {
   constexpr int NT = WGN * WGK * 64;
   constexpr int WTN = BN / WGN, WTK = BKO / WGK;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
 #define MST_WGRAD_IL 1
 #endif
   bool done_il = false;
-  if constexpr (MST_WGRAD_IL && TN * (BMR / 32) == A_CH + B_CH) {
+  if constexpr (MST_WGRAD_IL && A_CH + B_CH <= TN * (BMR / 32)) {
     if ((m_end - m_begin) % BMR == 0 && !div_a && !div_b) {
       done_il = true;
       // every load is unconditional: a chunk beyond N / K reads the tile's first column instead and is zeroed when it is
@@ -277,13 +279,13 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
           *reinterpret_cast<u32x4*>(wB + buf * BMR * LDB_S + (p - A_CH) * B_RSTEP * LDB_S) = b_ok ? rb[p - A_CH] : zero4;
         }
       };
+      constexpr int NPC = A_CH + B_CH;  // pieces of a stage: one per MFMA row of the stage, as far as they go
       auto all_pieces = [&](auto&& f) {
         f(std::integral_constant<int, 0>()); f(std::integral_constant<int, 1>()); f(std::integral_constant<int, 2>()); f(std::integral_constant<int, 3>());
-        if constexpr (A_CH + B_CH > 4) {
-          f(std::integral_constant<int, 4>()); f(std::integral_constant<int, 5>()); f(std::integral_constant<int, 6>()); f(std::integral_constant<int, 7>());
-        }
+        if constexpr (NPC > 4) { f(std::integral_constant<int, 4>()); f(std::integral_constant<int, 5>()); }
+        if constexpr (NPC > 6) { f(std::integral_constant<int, 6>()); f(std::integral_constant<int, 7>()); }
       };
-      static_assert(A_CH + B_CH == 4 || A_CH + B_CH == 8, "piece list");
+      static_assert(NPC == 4 || NPC == 6 || NPC == 8, "piece list");
       WG_STAMP(0);
       all_pieces([&](auto pc) { ld(pc); });
       advance();
@@ -320,10 +322,12 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
 #pragma unroll
               for (int i = 0; i < TK; ++i) acc[j][i] = Act<T>::mfma16(af[j], bf[i], acc[j][i]);
               if (bias_wave) acc_b[j] = Act<T>::mfma16(af[j], ones, acc_b[j]);
-              __builtin_amdgcn_sched_barrier(0);
-              st(std::integral_constant<int, ms * TN + j>(), cur ^ 1);
-              ld(std::integral_constant<int, ms * TN + j>());
-              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (ms * TN + j < NPC) {
+                __builtin_amdgcn_sched_barrier(0);
+                st(std::integral_constant<int, ms * TN + j>(), cur ^ 1);
+                ld(std::integral_constant<int, ms * TN + j>());
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           };
           static_assert(TN <= 4, "the group list covers four rows of MFMAs");
@@ -371,7 +375,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
     // The accumulators sit 4 rows x 64 bytes per wave-instruction; stored like that (or added atomically like that)
     // the 256 KiB tile leaves the CU in 64-byte pieces and the launch spends ~50 us on it. Instead each group of WTN
     // rows is transposed through LDS (the stage buffers are dead) and leaves as whole 1-KiB rows, 16 bytes per lane.
-    float* slot = b.partial + item * (int64_t)(BN * BKO);
+    float* slot = b.partial + item * (int64_t)SLOT;  // (rows of BKO floats; a narrower form uses the front of its slot)
     constexpr int LDF = BKO + 4;
     static_assert((size_t)WTN * LDF * 4 <= (size_t)2 * BMR * (BN + BKO + 2 * LDS_PAD) * 2, "row-group staging must fit the stage buffers");
     float* sF = reinterpret_cast<float*>(smem);
@@ -429,12 +433,29 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   const int64_t per_xcd = (n_items + 7) / 8;
   const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (item >= n_items) return;
+#ifdef MST_WGRAD_STAMPS
+  if (threadIdx.x == 0 && item < 512) g_wgrad_wg[2 * item] = __builtin_amdgcn_s_memrealtime();
+#endif
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < WG_MAXP; ++i)
     if (i < b.n && item >= b.item_prefix[i]) pi = i;
-  if (b.p[pi].a_u8) wgrad_body<T, BN, BKO, WGN, WGK, true>(b, smem, pi, item);  // (uniform for the workgroup)
-  else wgrad_body<T, BN, BKO, WGN, WGK, false>(b, smem, pi, item);
+  bool done = false;
+  if constexpr (BN == 256 && BKO == 256) {
+    // (the whole-step form: problems with K <= 128 run 256 x 128 tiles, in the same launch and the same slot layout)
+    if ((b.narrow >> pi) & 1u) {
+      if (b.p[pi].a_u8) wgrad_body<T, 256, 128, WGN, WGK, true, 256 * 256>(b, smem, pi, item);
+      else wgrad_body<T, 256, 128, WGN, WGK, false, 256 * 256>(b, smem, pi, item);
+      done = true;
+    }
+  }
+  if (!done) {
+    if (b.p[pi].a_u8) wgrad_body<T, BN, BKO, WGN, WGK, true>(b, smem, pi, item);  // (uniform for the workgroup)
+    else wgrad_body<T, BN, BKO, WGN, WGK, false>(b, smem, pi, item);
+  }
+#ifdef MST_WGRAD_STAMPS
+  if (threadIdx.x == 0 && item < 512) g_wgrad_wg[2 * item + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // dW[n, k] += scale * sum over the M-slabs (in slab order) of the tiles wgrad_kernel left in the scratch buffer.
@@ -455,10 +476,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, Partial
   const mst_wgrad_args& a = b.p[pi];
   const int64_t local = tile_lin - b.tile_prefix[pi];
   const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
-  const int64_t tiles_k = (a.K + BKO - 1) / BKO;
-  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * BKO;
+  const int bk = ((b.narrow >> pi) & 1u) ? 128 : BKO;  // this problem's tile width in k (rows of the slot are bk floats long)
+  const int64_t tiles_k = (a.K + bk - 1) / bk;
+  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * bk;
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // element of the tile
-  const int nl = e / BKO, kl = e % BKO;
+  if (e >= BN * bk) return;
+  const int nl = e / bk, kl = e % bk;
   const int64_t n = n0 + nl, k = k0 + kl;
   if (n >= a.N || k >= a.K) return;
   // slabs that own rows of this problem (wgrad_kernel returns early, writing nothing, for the others)
@@ -585,30 +608,43 @@ extern "C" int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, floa
   else if (out_elems >= (int64_t)256 * 128 * 36) big = 2;  // (a 0.79 M-output batch measured 58 us with 128x128, 62 with 256x128)
   else if (out_elems >= (int64_t)128 * 128 * 24) big = 1;
   const int bn = big >= 2 ? 256 : (big ? 128 : 64), bk = big == 3 ? 256 : (big ? 128 : 64);
+  static const bool mixed = !(getenv("MST_WGRAD_MIXED") && getenv("MST_WGRAD_MIXED")[0] == '0');
   b.tile_prefix[0] = 0;
-  for (int i = 0; i < n; ++i)
-    b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bk);
+  int bk_p[WG_MAXP];
+  b.narrow = 0u;
+  for (int i = 0; i < n; ++i) {
+    bk_p[i] = (big == 3 && mixed && list[i].K <= 128) ? 128 : bk;
+    if (bk_p[i] != bk) b.narrow |= 1u << i;
+    b.tile_prefix[i + 1] = b.tile_prefix[i] + cdiv(list[i].N, bn) * cdiv(list[i].K, bk_p[i]);
+  }
   for (int i = n + 1; i <= WG_MAXP; ++i) b.tile_prefix[i] = b.tile_prefix[n];
   const int64_t tiles = b.tile_prefix[n];
   // One full resident round of workgroups, no more (the workgroup that does not fit starts a second round: 105 vs
   // 83 us). Every problem is split min(S, rows / 128) ways — a 64-row problem (the top encoder layer's position-0 path)
   // gets one slab, where a batch-wide split left 26 % of the launch's workgroups with nothing to do — and S is the
   // largest value for which the items still fit.
+  // A stage of a narrower (256 x 128) tile is cheaper, so its problems get proportionally FEWER slabs (longer ones): the
+  // workgroups of both kinds then finish together, and the wide tiles' slabs get shorter.
   const int64_t slots = big >= 2 ? 256 : (big ? 512 : 1024);
+  auto split_of = [&](int i, int64_t S) -> int64_t {
+    const int64_t cap = cdiv(list[i].M, 2 * BMR);
+#ifndef MST_WGRAD_NARROW_SPLIT
+#define MST_WGRAD_NARROW_SPLIT 1
+#endif
+    // (per-workgroup stamps, tools/bench_wgrad_wgs.py: a narrow tile's stage costs ~0.93 us, a wide one's ~2.0)
+    int64_t sp = (bk_p[i] < bk) ? (MST_WGRAD_NARROW_SPLIT == 0 ? S : MST_WGRAD_NARROW_SPLIT == 1 ? (S * 5 + 4) / 8 : S / 2) : S;
+    if (sp < 1) sp = 1;
+    return sp < cap ? sp : cap;
+  };
   int64_t split = 1, n_items = 0;
   for (int64_t S = cdiv(maxM, 2 * BMR); S >= 1; --S) {
     int64_t items = 0;
-    for (int i = 0; i < n; ++i) {
-      const int64_t cap = cdiv(list[i].M, 2 * BMR);
-      items += (b.tile_prefix[i + 1] - b.tile_prefix[i]) * (S < cap ? S : cap);
-    }
+    for (int i = 0; i < n; ++i) items += (b.tile_prefix[i + 1] - b.tile_prefix[i]) * split_of(i, S);
     if (items <= slots || S == 1) { split = S; n_items = items; break; }
   }
-  b.split = (int)split;
   b.item_prefix[0] = 0;
   for (int i = 0; i < n; ++i) {
-    const int64_t cap = cdiv(list[i].M, 2 * BMR);
-    b.split_p[i] = (int)(split < cap ? split : cap);
+    b.split_p[i] = (int)split_of(i, split);
     b.item_prefix[i + 1] = b.item_prefix[i] + (b.tile_prefix[i + 1] - b.tile_prefix[i]) * b.split_p[i];
   }
   for (int i = n; i < WG_MAXP; ++i) b.split_p[i] = 1;
@@ -637,6 +673,9 @@ extern "C" int mst_gemm_wgrad(const mst_wgrad_args* args, mst_stream_t stream) {
 }
 
 #ifdef MST_WGRAD_STAMPS
+extern "C" int mst_debug_wgrad_wg(uint64_t* host_out) {  // diagnostic builds only: 512 x (start, end) realtime stamps
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_wgrad_wg), sizeof(uint64_t) * 1024) == hipSuccess ? 0 : -1;
+}
 extern "C" int mst_debug_wgrad_stamps(uint64_t* host_out) {  // diagnostic builds only
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_wgrad_stamps), sizeof(uint64_t) * (4 + 64 * 4)) == hipSuccess ? 0 : -1;
 }
