@@ -188,7 +188,7 @@ def kernel_families(plan, o, iters=30):
         fams.append(dict(
             kernel=f"wgrad batch [the step's {len(wg)} weight-gradient problems in one launch + reduction pass]",
             fn=lambda: o.gemm_wgrad_batch(wg, scratch=plan.wgrad_scratch, sums=ps), flops=fl, bytes=by, launches_per_step=1,
-            pmc_key="wgrad_kernel<256,256,4,2>@122880"))
+            pmc_key="wgrad_kernel<256,256,4,2>@*+wgrad_reduce_kernel<256, 256>@*"))  # (both passes of the launch; any grid)
     ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
     out = []
     for f in fams:
@@ -210,7 +210,16 @@ def roofline(plan, o, config_id):
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             j = json.load(f)
         if config_id == 1 and best["pmc_key"]:
-            traffic, src = j["bytes_per_launch"].get(best["pmc_key"]), j.get("source")
+            table, src = j["bytes_per_launch"], j.get("source")
+
+            def lookup(key):  # "name@grid", or "name@*" for the entry of that kernel whatever its grid
+                if not key.endswith("@*"):
+                    return table.get(key)
+                hits = [v for k, v in table.items() if k.startswith(key[:-1])]
+                return max(hits) if hits else None
+
+            parts = [lookup(k) for k in best["pmc_key"].split("+")]
+            traffic = sum(parts) if all(v is not None for v in parts) else None
     except (OSError, ValueError, KeyError):
         pass
     hbm = best["bound"] == "hbm"
