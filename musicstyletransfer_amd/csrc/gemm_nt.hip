@@ -494,9 +494,11 @@ template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
                                                  f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0,
                                                  const T* lds_resid = nullptr, int lds_resid_ld = 0,
-                                                 T* lds_out = nullptr, int lds_out_ld = 0) {
+                                                 T* lds_out = nullptr, int lds_out_ld = 0, const float* lds_par = nullptr) {
   // lds_resid: the workgroup's BM residual rows already sit in LDS (row stride lds_resid_ld elements, outside the staging
   // tile): they are read from there instead of from a.resid
+  // lds_par: [bias | gamma | beta] (3 x BN floats) already in LDS (outside the staging tile): in a kernel that is one
+  // workgroup per CU these cold parameter lines (the optimizer rewrote them) are an exposed round trip at the epilogue's start
   // lds_out: the result rows ALSO go to this LDS tile (outside the staging tile; rows past M as zeros): the LayerNorm output
   // (mode 1) or the input gradient — its masked copy when there is one — (mode 2), for a GEMM that follows in the same launch
   constexpr int NT = WGM * WGN * 64;
@@ -527,9 +529,15 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
   float bias8[8], gam8[8], bet8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    bias8[e] = a.bias ? a.bias[nc + e] : 0.f;
-    gam8[e] = l.gamma[nc + e];
-    bet8[e] = (MODE == 1) ? l.beta[nc + e] : 0.f;
+    if (lds_par) {
+      bias8[e] = lds_par[nc + e];
+      gam8[e] = lds_par[BN + nc + e];
+      bet8[e] = (MODE == 1) ? lds_par[2 * BN + nc + e] : 0.f;
+    } else {
+      bias8[e] = a.bias ? a.bias[nc + e] : 0.f;
+      gam8[e] = l.gamma[nc + e];
+      bet8[e] = (MODE == 1) ? l.beta[nc + e] : 0.f;
+    }
   }
   float dg8[8], db8[8];
 #pragma unroll
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   T* sH = reinterpret_cast<T*>(smem + (DW ? (size_t)0 : (size_t)2 * BN * BK * 2));
   T* sX = sH + (DW ? 2 : 1) * BM * LDA;
   float* sBias1 = reinterpret_cast<float*>(sX + BM * LDA);  // [F] the first GEMM's bias (zeros without one)
+  float* sPar = sBias1 + g1.N;   // [2][3 BN]: bias | gamma | beta of the final epilogue, then of the head's (EXTRA forward)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
 #ifndef MST_XCD_ROWS
@@ -857,6 +866,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
   for (int i = tid * 4; i < (int)F; i += NT * 4)
     *reinterpret_cast<f32x4*>(sBias1 + i) = g1.bias ? *reinterpret_cast<const f32x4*>(g1.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < BN; i += NT) {
+    sPar[i] = g2.bias ? g2.bias[i] : 0.f;
+    sPar[BN + i] = ln.gamma[i];
+    sPar[2 * BN + i] = (MODE == 1) ? ln.beta[i] : 0.f;
+    if constexpr (HEAD) {
+      sPar[3 * BN + i] = gx.bias ? gx.bias[i] : 0.f;
+      sPar[4 * BN + i] = lnx.gamma[i];
+      sPar[5 * BN + i] = lnx.beta[i];
+    }
+  }
   const int n_chunks = (int)(F / BN);
   // Chunk order rotated per workgroup: every workgroup streams BOTH weight matrices in full, and 256 of them walking the
   // same lines in lockstep hit the same L2 channels at the same time. Workgroup i of an XCD starts at hidden chunk
@@ -1124,7 +1143,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   if constexpr (HEAD) {
     // h1 = epi(att Wp^T) (+ x), x1 = LayerNorm(h1): mst_gemm_nt_ln's forward epilogue; x1 also lands in the x tile
     extra_gemm(-1);
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA, sPar + 3 * BN);
     __syncthreads();  // the staging tile (over the weight stages) is dead, the x tile complete
   }
   if constexpr (!DW) store_stage(0, ring[0]);
@@ -1254,11 +1273,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   FFN_STAMP(2);
   if constexpr (DW) __syncthreads();  // the staging tile overlays the hidden chunks other waves may still be reading
   if constexpr (!TAIL) {
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA, nullptr, 0, sPar);
   } else {
     // the LayerNorm-1 backward result (masked copy, if any) -> x tile (dead: the residual is read from global memory here),
     // then datt = that tile x Wp (the transposed shadow, [BN, BN] K-contiguous), stored as 16-bit rows
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA, sPar);
     __syncthreads();  // the reduction scratch (over the weight stages) is dead, the tile complete
     extra_gemm(n_chunks);
     constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
@@ -1294,7 +1313,8 @@ static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const
   constexpr int DWN = BN >= 256 ? MST_FFN_DW_WGN256 : 8;  // waves of the direct-weight form
   static const int dw_env = getenv("MST_FFN_DW") ? 1 : 0;  // experiment, off: see the DW note above ffn_ln_kernel
   const int dw = gx ? 0 : dw_env, ex = gx ? 1 : 0;
-  const size_t lds_loop = (dw ? (size_t)3 * BM * (BN + 8) * 2 : (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2) + (size_t)g1.N * 4;
+  const size_t lds_loop = (dw ? (size_t)3 * BM * (BN + 8) * 2 : (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2) + (size_t)g1.N * 4 +
+                          (size_t)6 * BN * 4;
   const size_t lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   const int full = g1.M % BM == 0 ? 1 : 0;
