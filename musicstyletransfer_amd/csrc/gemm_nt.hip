@@ -32,7 +32,8 @@ namespace mst {
 // DROP, likewise: dropout / self_resid compiled in (half of the step's GEMM launches are gradient GEMMs without it).
 template <typename T, int BM, int BN, int WGM, int WGN, bool C_F32, bool ROWOPS, int PATH, bool DROP>
 __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned char* smem,
-                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0) {
+                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0, int64_t n0,
+                                              const float (&bias_pre)[8] /* gemm_bias_preload's */) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const float alpha = a.alpha;
   float bias8[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && nc + e < N32) ? a.bias[nc + e] : 0.f;
+  for (int e = 0; e < 8; ++e) bias8[e] = bias_pre[e];
   const T* resid = reinterpret_cast<const T*>(a.resid);
   const T* gate = reinterpret_cast<const T*>(a.gate);
 
@@ -325,6 +326,27 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   }
 }
 
+// The workgroup's tile (the XCD-aware order of gemm_mainloop, which recomputes it) and the epilogue's bias for this thread's
+// 8-column chunk, requested BEFORE the K loop: the parameters are cold lines after every optimizer step, and a load issued at
+// the epilogue's start is a round trip that nothing covers once the tile's MFMAs are done.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_tile_origin(const mst_gemm_args& a, int64_t& m0, int64_t& n0) {
+  const int64_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM, nwg = tiles_m * tiles_n;
+  int64_t bid = blockIdx.x;
+  const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
+  bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  m0 = (bid / tiles_n) * BM;
+  n0 = (bid % tiles_n) * BN;
+}
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float (&bias8)[8]) {
+  int64_t m0, n0;
+  gemm_tile_origin<BM, BN>(a, m0, n0);
+  const int nc = (int)n0 + ((int)threadIdx.x % (BN / 8)) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && nc + e < (int)a.N) ? a.bias[nc + e] : 0.f;
+}
+
 // The tile's K loop, shared by the kernels below: locates the workgroup's tile (m0, n0) and leaves the fp32
 // accumulators in `acc`; on return every wave has passed the loop's last barrier, so `smem` is free to reuse.
 // AREMAP: the A row remap is compiled in (a 64-bit division per staged chunk of the prologue).
@@ -462,9 +484,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
+  float bias_pre[8];
+  gemm_bias_preload<BM, BN>(a, bias_pre);
   gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS, AU8>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
-  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0);
+  gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -679,8 +703,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
+  // bias | gamma | beta wait in LDS behind the K-loop tiles / the staging tile (launch_gemm_ln sizes it): cold lines, requested now
+  constexpr size_t LOOP_B = (size_t)2 * (BM + BN) * 64 * 2, EPI_B = (size_t)BM * (BN + 4) * 4;
+  float* sPar = reinterpret_cast<float*>(smem + (LOOP_B > EPI_B ? LOOP_B : EPI_B));
+  for (int i = threadIdx.x; i < BN; i += WGM * WGN * 64) {
+    sPar[i] = a.bias ? a.bias[i] : 0.f;
+    sPar[BN + i] = l.gamma[i];
+    sPar[2 * BN + i] = (MODE == 1) ? l.beta[i] : 0.f;
+  }
   gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
-  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(a, l, smem, acc, m0);
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(a, l, smem, acc, m0, nullptr, 0, nullptr, 0, sPar);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -699,6 +731,8 @@ __global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_
   __shared__ float red[NT / 64];
   f32x4 acc[TN][TM];
   int64_t m0, n0;
+  float bias8[8];
+  gemm_bias_preload<BM, BN>(a, bias8);  // (BN == N: the chunk's columns do not depend on the tile)
   gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
@@ -727,9 +761,6 @@ __global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_
   __syncthreads();                              // staged tile visible (and `red` free again)
   const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
   const float inv_n = 1.f / ((float)q.T * (float)BN), ls = q.label_smoothing;
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = a.bias ? a.bias[nc + e] : 0.f;
   float lsum = 0.f;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -1348,7 +1379,7 @@ static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_gemm_ln(const mst_gemm_args& a, const mst_ln_args& l, hipStream_t s) {
   const size_t lds_loop = (size_t)2 * (BM + BN) * 64 * 2, lds_epi = (size_t)BM * (BN + 4) * 4;
-  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  const size_t lds = (lds_loop > lds_epi ? lds_loop : lds_epi) + (size_t)3 * BN * 4;  // + bias | gamma | beta
   dim3 grid((unsigned)cdiv(a.M, BM)), block(WGM * WGN * 64);
   const int mi = l.mode == 2 ? 1 : 0;
   const void* fn = mi ? reinterpret_cast<const void*>(&gemm_nt_ln_kernel<T, BM, BN, WGM, WGN, 2>)
