@@ -1214,12 +1214,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         const int tc = t < SPC ? c : (TAIL || c + 1 < n_chunks ? c + 1 : c);
         const bool more = s + 1 < SPC || c + 1 < n_chunks;  // a next stage exists: its weights go to the other LDS buffer
         // interleaved form: piece k of { load of stage s + AHEAD, LDS store of stage s + 1 } behind the k-th row of MFMAs
+#ifndef MST_FFN_COPY_IL
+#define MST_FFN_COPY_IL 0  /* measured: -1 us on the isolated launch, +1..2 us at step level (in-call A/B): off */
+#endif
+        // (experiment) forward: the finished chunk's copy to `a` rides behind the last MFMA rows of the second GEMM's first
+        // stage, a 16-byte piece of a row at a time, instead of standing between the barrier and that stage
+        constexpr bool COPY_IL = MST_FFN_COPY_IL && MODE == 1 && !DW && OUT_CH <= 2 * TN;
         auto piece = [&](auto kc) {
           constexpr int k = decltype(kc)::value;
           if constexpr (IL && k < B_CH) {
             __builtin_amdgcn_sched_barrier(0);
             load_piece(tc, t % SPC, ring[t % RING], kc);
             if (more) sB[((s + 1) & 1) * BN * CHUNKS + b_lds[k]] = ring[(s + 1) % RING][k];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (COPY_IL && s == KST && k >= 2 * TN - OUT_CH) {
+            constexpr int i = k - (2 * TN - OUT_CH), CPRc = BN / 8;
+            const int cc = tid + i * NT, row = cc / CPRc, ch = cc % CPRc;
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sH + row * LDA + ch * 8);
+            if (m0 + row < Mg) *reinterpret_cast<u32x4*>(Aout + (m0 + row) * g1.ldc + (int64_t)pc * BN + ch * 8) = v;
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -1269,7 +1283,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         } else if constexpr (s == KST - 1) {
           __syncthreads();  // the chunk is complete in LDS
         }
-        if constexpr (s == KST - 1) {
+        if constexpr (s == KST - 1 && !COPY_IL) {
           // the finished chunk goes out to `a` (the backward pass needs it) as whole 16-byte pieces of rows, while the
           // second GEMM's stages run
           constexpr int CPR = BN / 8;
