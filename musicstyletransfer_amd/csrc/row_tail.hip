@@ -30,6 +30,8 @@ __device__ __forceinline__ void grid_sync(uint32_t* ctr, uint32_t target) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
+    // (agent-scope counter operations even though the participants share an XCD: an atomic add without scope bits + sc0 polling
+    // loads was tried and is NOT reliable — most launches sat out the spin bound)
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -119,10 +121,16 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok)
 // travelled over the fabric: 8 us for the 128 KB of stage 3, 3-5 us per barrier waiting for write-through acknowledgements
 // from memory. The kernels therefore launch 12 x more workgroups than they need and let them JOIN: the first arrival
 // claims its XCD (s_getreg XCC_ID) with a compare-and-swap, workgroups on that XCD take the roles 0..G-1 in arrival order,
-// everybody else leaves at once. All participants then share one L2, and the bytes that cross a barrier move with
-// workgroup-scope-in-threadgroup-split semantics (sc0: stores write through the CU's L1 to the L2, loads miss in the L1 and
-// are served by the L2). Correct for ANY dispatch order (participants share an XCD by construction; a launch that put
-// fewer than G workgroups on the claimed XCD would leave the bounded barrier spin and fail the step's parity, not hang).
+// everybody else leaves at once. All participants then share one L2, and the bytes that cross a barrier are written through
+// the CU's L1 to that L2 (sc0 stores, complete — s_waitcnt vmcnt(0) — before the workgroup arrives at the barrier) and read
+// behind the barrier with loads that find them there. What makes those loads safe is NOT a cache-bypass bit (a polling loop
+// of sc0 loads was tried for the barrier counter and kept reading its first value: the L1 serves repeats) but that every such
+// line is read by a CU for the FIRST time since the L1 invalidate at kernel start — each stage's operand rows are new to the
+// workgroup that loads them, and the L1 does not allocate on the write-through of a partial line (the 32-byte column slices a
+// workgroup itself stored: parity tests cover exactly that) — so the load misses and is served by the shared L2. Correct
+// for ANY dispatch order (participants share an XCD by construction; a launch that put fewer than G workgroups on the
+// claimed XCD would leave the bounded barrier spin and fail the step's parity, not hang). The barrier counter itself stays
+// agent-scope.
 // sync: [0] barrier counter, [1] claimed XCD + 1, [2] roles handed out (all zero at launch).
 #ifndef MST_TAIL_OVERSUBSCRIBE
 #define MST_TAIL_OVERSUBSCRIBE 12  /* 8 is exact under round-robin dispatch; measured 8 / 10 / 12 / 16: 0.7245 / 0.7234 / 0.7256 / 0.7256 ms per step */
@@ -233,12 +241,22 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;  // k-steps per K quarter of the two 16-column stages
   __shared__ __attribute__((aligned(16))) T sX1[64 * LDX];  // LayerNorm-1 output of every row (FFN1's operand, FFN2's residual)
   __shared__ __attribute__((aligned(16))) float sP[4 * 64 * 16];
+  // every bias / gamma / beta of the chain, requested at once at the start: they are cold lines after an optimizer step, and
+  // each would be one more dependent round trip inside its stage ([bp | g1 | be1 | b2 | g2 | be2 | b1])
+  __shared__ __attribute__((aligned(16))) float sPar[6 * D + F];
   typedef typename Act<T>::vec8 vec8;
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
   const int g = tail_join(q.sync, G);
   if (g < 0) return;
+  for (int i = tid; i < D; i += TAIL_WAVES * 64) {
+    sPar[i] = q.bp[i]; sPar[D + i] = q.g1[i]; sPar[2 * D + i] = q.be1[i];
+    sPar[3 * D + i] = q.b2[i]; sPar[4 * D + i] = q.g2[i]; sPar[5 * D + i] = q.be2[i];
+  }
+  for (int i = tid; i < F; i += TAIL_WAVES * 64) sPar[6 * D + i] = q.b1[i];
+  const float* const s_bp = sPar, * const s_g1 = sPar + D, * const s_be1 = sPar + 2 * D, * const s_b2 = sPar + 3 * D,
+             * const s_g2 = sPar + 4 * D, * const s_be2 = sPar + 5 * D, * const s_b1 = sPar + 6 * D;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
   const int m = mi * 16 + li;  // the row this lane's accumulator column belongs to
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 #pragma unroll
     for (int ks = 0; ks < KQ1; ++ks) part = Act<T>::mfma16(wf[ks], xf[ks], part);
     const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
-    if (wq == 0 && m_ok) finish4(acc, q.bp, n0 + 4 * lq, q.site0, D, false, xin + (int64_t)m * q.rs_res, h1 + (int64_t)m * q.rs_d);
+    if (wq == 0 && m_ok) finish4(acc, s_bp, n0 + 4 * lq, q.site0, D, false, xin + (int64_t)m * q.rs_res, h1 + (int64_t)m * q.rs_d);
   }
   // (memory-level parallelism is the whole game here: every stage is a few dependent L2 / fabric round trips, so the
   // next stage's weight fragments are requested BEFORE the barrier they do not depend on, and rows are loaded in batches)
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
     }
     float gm[E], bt[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { gm[e] = q.g1[lane * E + e]; bt[e] = q.be1[lane * E + e]; }
+    for (int e = 0; e < E; ++e) { gm[e] = s_g1[lane * E + e]; bt[e] = s_be1[lane * E + e]; }
 #ifdef MST_TAIL_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TAIL_STAMP(8);
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
     TAIL_STAMP(11);
 #pragma unroll
     for (int ks = 0; ks < KQ2; ++ks) w2f[ks] = frag16<T>(W2p + 32 * ks, true);
-    if (m_ok) finish4(acc, q.b1, n1 + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
+    if (m_ok) finish4(acc, s_b1, n1 + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
   }
   TAIL_STAMP(3);
   grid_sync(q.sync, 2 * G);
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 #pragma unroll
     for (int ks = 0; ks < KQ2; ++ks) part = Act<T>::mfma16(w2f[ks], __builtin_bit_cast(vec8, m_ok ? xr[ks] : u32x4{0u, 0u, 0u, 0u}), part);
     const f32x4 acc = quarter_sum(sP, part, wq, m, lq);
-    if (wq == 0 && m_ok) finish4(acc, q.b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
+    if (wq == 0 && m_ok) finish4(acc, s_b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
   }
   TAIL_STAMP(5);
   grid_sync(q.sync, 3 * G);
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   // ---------------- stage 4: x2 = LN2(h2), rows dealt to the workgroups
   for (int r = g + G * wave; r < B; r += TAIL_WAVES * G) {
     float y[E], mean, rstd;
-    ln_row<T, D>(h2 + (int64_t)r * q.rs_d, q.g2, q.be2, q.eps, lane, y, mean, rstd);
+    ln_row<T, D>(h2 + (int64_t)r * q.rs_d, s_g2, s_be2, q.eps, lane, y, mean, rstd);
     uint16_t yb[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) yb[e] = f32_to_bits<T>(y[e]);
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   T* sW = sA + 64 * LDX;                                        // [64][LDX] W2t rows 64 g .. 64 g + 63
   float* sRed = reinterpret_cast<float*>(sW + 64 * LDX);        // [16 waves][2][D]
   float* sP = sRed + TAIL_WAVES * 2 * D;                        // [4][64][16]
+  float* sGam = sP + 4 * 64 * 16;                               // [g2 | g1]: cold parameter lines, requested at the start
   typedef typename Act<T>::vec8 vec8;
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -567,13 +586,17 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
       rdy[i] = *reinterpret_cast<const raw_t*>(dy + (int64_t)rc * q.rs_dy + lane * E);
       rx[i] = *reinterpret_cast<const raw_t*>(h2 + (int64_t)rc * q.rs_d + lane * E);
     }
+    float gpre[2] = {0.f, 0.f};
+    if (tid < D) { gpre[0] = q.g2[tid]; gpre[1] = q.g1[tid]; }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int c = tid + i * TAIL_WAVES * 64, row = c / CPR, ch = c % CPR;
       *reinterpret_cast<u32x4*>(sW + row * LDX + ch * 8) = wv[i];
     }
+    if (tid < D) { sGam[tid] = gpre[0]; sGam[D + tid] = gpre[1]; }
+    __syncthreads();  // (the gammas; every load of this stage is already in flight)
     // ---------------- stage 1: LayerNorm-2 backward of every row
-    ln_bwd_rows(rdy, rx, q.mean2, q.rstd2, q.g2, q.site0 + 2, dh, q.rs_c, true, dhm, q.rs_c, q.dg2, q.db2);
+    ln_bwd_rows(rdy, rx, q.mean2, q.rstd2, sGam, q.site0 + 2, dh, q.rs_c, true, dhm, q.rs_c, q.dg2, q.db2);
   }
   TAIL_STAMP(1);
   // ---------------- stage 2: d(pre)[:, 64 g ..] = ((dhm W2t^T) / (1 - p)) gated by a > 0     (16-column block wq per wave)
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
       rx[i] = *reinterpret_cast<const raw_t*>(h1 + (int64_t)rc * q.rs_d + lane * E);
     }
     l2_wait(rdy);
-    ln_bwd_rows(rdy, rx, q.mean1, q.rstd1, q.g1, q.site0, dh1, q.rs_dh1, false, dh1m, q.rs_c, q.dg1, q.db1);
+    ln_bwd_rows(rdy, rx, q.mean1, q.rstd1, sGam + D, q.site0, dh1, q.rs_dh1, false, dh1m, q.rs_c, q.dg1, q.db1);
   }
   TAIL_STAMP(6);
   // ---------------- stage 5: datt[:, 16 g ..] = dh1m Wpt^T        (K quarter per wave)
@@ -711,7 +734,7 @@ extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t 
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(q.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    const size_t lds = (size_t)2 * 64 * ((size_t)q.D + 8) * 2 + (size_t)16 * 2 * q.D * 4 + (size_t)4 * 64 * 16 * 4;
+    const size_t lds = (size_t)2 * 64 * ((size_t)q.D + 8) * 2 + (size_t)16 * 2 * q.D * 4 + (size_t)4 * 64 * 16 * 4 + (size_t)2 * q.D * 4;
     static size_t opted[2] = {64 * 1024, 64 * 1024};
     const int wi = q.D == 256 ? 0 : 1;
     const void* fn = wi == 0 ? reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 256>) : reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 128>);
