@@ -518,7 +518,8 @@ template <typename T, int BM, int BN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const mst_ln_args& l, unsigned char* smem,
                                                  f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t m0,
                                                  const T* lds_resid = nullptr, int lds_resid_ld = 0,
-                                                 T* lds_out = nullptr, int lds_out_ld = 0, const float* lds_par = nullptr) {
+                                                 T* lds_out = nullptr, int lds_out_ld = 0, const float* lds_par = nullptr,
+                                                 const uint64_t* dseed_pre = nullptr /* the step's dropout seed, already loaded */) {
   // lds_resid: the workgroup's BM residual rows already sit in LDS (row stride lds_resid_ld elements, outside the staging
   // tile): they are read from there instead of from a.resid
   // lds_par: [bias | gamma | beta] (3 x BN floats) already in LDS (outside the staging tile): in a kernel that is one
@@ -547,7 +548,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
   const float inv_n = 1.f / (float)BN;
   const float inv_keep = dropout_inv_keep(a.dropout_p);
   const bool has_drop = a.dropout_p > 0.f;
-  const uint64_t dseed = a.dropout_seed ^ ((has_drop && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
+  const uint64_t dseed = dseed_pre ? *dseed_pre : a.dropout_seed ^ ((has_drop && a.dropout_seed_ptr) ? a.dropout_seed_ptr[0] : 0ull);
   const uint32_t dkey = dropout_key(dseed, a.dropout_site), dthr = dropout_thr(a.dropout_p);
   const T* resid = reinterpret_cast<const T*>(a.resid);
   float bias8[8], gam8[8], bet8[8];
@@ -897,6 +898,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
   for (int i = tid * 4; i < (int)F; i += NT * 4)
     *reinterpret_cast<f32x4*>(sBias1 + i) = g1.bias ? *reinterpret_cast<const f32x4*>(g1.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // (the step's dropout seed words too: a scalar load at an epilogue's start is one more exposed round trip)
+  const uint64_t seed2 = g2.dropout_seed ^ ((g2.dropout_p > 0.f && g2.dropout_seed_ptr) ? g2.dropout_seed_ptr[0] : 0ull);
+  const uint64_t seedx = EXTRA ? gx.dropout_seed ^ ((gx.dropout_p > 0.f && gx.dropout_seed_ptr) ? gx.dropout_seed_ptr[0] : 0ull) : 0ull;
   for (int i = tid; i < BN; i += NT) {
     sPar[i] = g2.bias ? g2.bias[i] : 0.f;
     sPar[BN + i] = ln.gamma[i];
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   if constexpr (HEAD) {
     // h1 = epi(att Wp^T) (+ x), x1 = LayerNorm(h1): mst_gemm_nt_ln's forward epilogue; x1 also lands in the x tile
     extra_gemm(-1);
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA, sPar + 3 * BN);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA, sPar + 3 * BN, &seedx);
     __syncthreads();  // the staging tile (over the weight stages) is dead, the x tile complete
   }
   if constexpr (!DW) store_stage(0, ring[0]);
@@ -1318,11 +1322,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   FFN_STAMP(2);
   if constexpr (DW) __syncthreads();  // the staging tile overlays the hidden chunks other waves may still be reading
   if constexpr (!TAIL) {
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA, nullptr, 0, sPar);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA, nullptr, 0, sPar, &seed2);
   } else {
     // the LayerNorm-1 backward result (masked copy, if any) -> x tile (dead: the residual is read from global memory here),
     // then datt = that tile x Wp (the transposed shadow, [BN, BN] K-contiguous), stored as 16-bit rows
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA, sPar);
+    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA, sPar, &seed2);
     __syncthreads();  // the reduction scratch (over the weight stages) is dead, the tile complete
     extra_gemm(n_chunks);
     constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
