@@ -113,14 +113,15 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const int ch = tid % CPR;
   const int nc = (int)n0 + ch * 8;             // first column of this thread's chunk (N < 2^31)
   const int N32 = (int)a.N;
-  const bool edge = PATH != 1 && ((m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
+  const bool edge = PATH != 1 && PATH != 4 && ((m0 + BM > a.M) || ((int)n0 + BN > N32) || (a.ldc % 8 != 0) ||
                                   (a.resid && ((a.ldr % 8 != 0) || ((uintptr_t)a.resid % 16 != 0))) ||
                                   (a.gate && ((a.ldg % 8 != 0) || ((uintptr_t)a.gate % 16 != 0))));
   const bool has_drop = DROP && a.dropout_p > 0.f;
   const bool has_rowops = ROWOPS && (a.rowadd || a.grpadd);
   // row-indexed adds (positional table row m % period, class row grp_index[m / period]) ride on the fast path when a
   // tile cannot straddle a period: the class row is then one per tile and the positional rows advance with the tile rows
-  const bool fast = PATH == 1;
+  const bool fast = PATH == 1 || PATH == 4;
+  constexpr bool SPLIT = PATH == 4;  // stage one wave-row block per pass: (BM / WGM) x (BN + 4) floats of LDS instead of BM x (BN + 4)
   float ga8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) ga8[e] = 0.f;
@@ -139,19 +140,32 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 
   // every wave stages its accumulators at once (the launch sizes LDS for the whole BM x (BN+4) fp32 tile): one barrier
   // per workgroup instead of two per wave-row pass
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
-  __syncthreads();
+      for (int j = 0; j < TN; ++j)
+        *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+    __syncthreads();
+  }
   for (int pass = 0; pass < WGM; ++pass) {
-    const float* sFp = sF + pass * WTM * LDS_F;  // this row block of the staged tile
+    if constexpr (SPLIT) {
+      if (pass > 0) __syncthreads();  // the previous block's readers are done
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4*>(sF + (i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
+      }
+      __syncthreads();
+    }
+    const float* sFp = sF + (SPLIT ? 0 : pass * WTM * LDS_F);  // this row block of the staged tile
     // Fast path (interior tile, 16-bit output, no row remap / row-indexed adds, < 2^32 output elements): the row
     // loop carries pointers and a 32-bit dropout counter forward by constant strides. At two waves per SIMD the
     // epilogue is VALU-bound (measured per workgroup: 7.7 us of a 13.9 us life in FFN1, most of it 64-bit address
     // and counter arithmetic per 8-column chunk).
-    if constexpr (PATH == 1) {
+    if constexpr (PATH == 1 || PATH == 4) {
       constexpr int RSTEP = NT / CPR;
       const int row0 = tid / CPR;
       const int64_t mf = m0 + pass * WTM + row0;
@@ -1416,6 +1430,25 @@ static int launch_gemm_ln(const mst_gemm_args& a, const mst_ln_args& l, hipStrea
   return MST_OK;
 }
 
+// 128 x 128 tiles at THREE or four workgroups per CU: 32-deep K stages (32 KB) and the accumulators staged one 64-row block at
+// a time (34 KB) instead of 64 KB + 68 KB. For launches of 513..768 tiles (the K | Q | V projections: 768) that is one
+// resident round instead of a full one and a half-empty one at two per CU. Eligibility as launch_gemm's fast form without
+// dropout / row ops; returns 1 when the launch is not eligible (caller falls back).
+template <typename T>
+static int launch_gemm_3cu(const mst_gemm_args& a, hipStream_t s) {
+  constexpr int BM = 128, BN = 128, BK = 32;
+  const bool rowops = a.rowadd || a.grpadd || a.a_rows_per_group > 0 || a.c_rows_per_group > 0;
+  const bool ok = !a.c_f32 && !a.a_u8 && !rowops && a.dropout_p == 0.f && !a.self_resid && a.M % BM == 0 && a.N % BN == 0 && a.K % BK == 0 &&
+                  a.ldc % 8 == 0 && (uint64_t)a.M * (uint64_t)a.N < (1ull << 32) &&
+                  (!a.resid || (a.ldr % 8 == 0 && (uintptr_t)a.resid % 16 == 0)) && (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0));
+  if (!ok) return 1;
+  const size_t lds_loop = (size_t)2 * (BM + BN) * BK * 2, lds_epi = (size_t)(BM / 2) * (BN + 4) * 4;
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, 2, 2, false, BK, false, 4, false>), dim3((unsigned)((a.M / BM) * (a.N / BN))), dim3(256), lds, s, a);
+  MST_CHECK_LAUNCH("gemm_nt_kernel");
+  return MST_OK;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int BK = 64>
 static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -1680,8 +1713,15 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // (a launch whose rows are whole 64-row tiles but not whole 128-row tiles — the decoder's 64 x 257 — keeps the
     // fast-epilogue kernel with 64x64 tiles)
     const bool ragged128 = a.M % 128 != 0 && a.M % 64 == 0 && a.N % 128 == 0 && !a.c_f32;
+    static const bool three = !(getenv("MST_GEMM_3CU") && getenv("MST_GEMM_3CU")[0] == '0');
+    if (three && big_tiles > 512 && big_tiles <= 768 && a.N >= 128 && !ragged128) {
+      const int rc = launch_gemm_3cu<T>(a, s);
+      if (rc <= 0) return rc;
+    }
     if (big_tiles >= 384 && a.N >= 128 && !stub_round && !ragged128) return launch_gemm<T, 128, 128, 2, 2>(a, s);
     if (a.M <= 64 && a.K >= 512 && a.K % 256 == 0) return launch_gemm<T, 64, 64, 2, 2, 256>(a, s);
+    // (32-deep K stages for launches of 1281..2048 64 x 64 tiles — eight workgroups per CU, one resident round for the decoder's
+    // 257 x 6 projection tiles — measured no faster: +2 us per step)
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
   });
 }
