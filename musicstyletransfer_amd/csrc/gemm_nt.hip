@@ -370,6 +370,11 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0) {
   constexpr int CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
+  // XOR swizzle of a row's 16-byte chunk index (conflict-free ds_read_b128 of 16 rows at one k): the row's low 3 bits with
+  // 8+ chunks per row (128-byte rows and wider); with 4 chunks (32-deep stages, 64-byte rows) four rows share a 256-byte
+  // bank window, so bits 2..3 of the row — and the result stays inside the row's own four slots
+  auto swz = [](int row) { return CHUNKS >= 8 ? (row & 7) : ((row >> 2) & (CHUNKS - 1)); };
+  static_assert(CHUNKS >= 4, "K stages are at least 32 deep");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
   constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 sub-tiles per wave
   constexpr int A_CH = (BM * CHUNKS + NT - 1) / NT, B_CH = BN * CHUNKS / NT;  // a short A tile may not occupy every thread
@@ -412,7 +417,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
     int64_t pm = AREMAP ? remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : (a_ok[i] ? m : 0);
     a_ptr[i] = A + pm * a.lda + ch * 8;
     a_ch[i] = ch * 8;
-    a_lds[i] = row * CHUNKS + (ch ^ (row & 7));
+    a_lds[i] = row * CHUNKS + (ch ^ swz(row));
   }
   const T* b_ptr[B_CH];
   bool b_ok[B_CH];
@@ -424,7 +429,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
     b_ok[i] = n < a.N;
     b_ptr[i] = B + (b_ok[i] ? n : 0) * a.ldb + ch * 8;
     b_ch[i] = ch * 8;
-    b_lds[i] = row * CHUNKS + (ch ^ (row & 7));
+    b_lds[i] = row * CHUNKS + (ch ^ swz(row));
   }
 
   u32x4 ra[A_CH], rb[B_CH];
@@ -474,13 +479,13 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         int row = wm * WTM + i * 16 + frow;
-        u32x4 v = cA[row * CHUNKS + (kc ^ (row & 7))];
+        u32x4 v = cA[row * CHUNKS + (kc ^ swz(row))];
         xf[i] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         int row = wn * WTN + j * 16 + frow;
-        u32x4 v = cB[row * CHUNKS + (kc ^ (row & 7))];
+        u32x4 v = cB[row * CHUNKS + (kc ^ swz(row))];
         wf[j] = __builtin_bit_cast(vec8, v);
       }
 #pragma unroll

@@ -340,6 +340,10 @@ class StepPlan:
             # piano-roll frames stay uint8 in HBM, exactly as the batcher delivers them (1 byte per pitch; rows padded to 8):
             # the embedding GEMMs and their weight gradients widen them while staging tiles into LDS (a_u8)
             seg = [("roll", B * T * roundup(cfg.in_dim, 8)), ("labels", B * T * cfg.out_dim)]
+            # one-hot class id of every frame ([B*T, 8] uint8): the class-embedding gradient (a column sum of d(x0) per class) is
+            # then one more problem of the step's weight-gradient launch instead of a launch of its own
+            if cfg.num_classes <= 8 and os.environ.get("MST_CLS_WGRAD", "1") != "0":
+                seg.append(("cls_rows", B * T * 8))
         seg += [("seq_lens", B * 4), ("classes", B * 4)]
         self.in_layout, off = {}, 0
         for name, nbytes in seg:
@@ -452,7 +456,7 @@ class StepPlan:
         kernels read are re-pointed, nothing is copied. A graph captured afterwards reads THAT buffer — a batcher that
         fills two or more such buffers in turn (or bench.py's resident batches) needs no device-to-device hop."""
         cfg, B, T = self.cfg, self.B, self.T
-        need = self.in_layout["classes"][0] + self.in_layout["classes"][1]
+        need = max(a + n for a, n in self.in_layout.values())
         if not (buf.dtype == torch.uint8 and buf.is_contiguous() and buf.is_cuda and buf.data_ptr() % 16 == 0 and buf.numel() >= need):
             raise ValueError("bind_inputs: need a contiguous, 16-byte aligned device uint8 blob of pack_batch()'s size")
         self.inbuf = buf
@@ -469,6 +473,7 @@ class StepPlan:
             self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
         self.seq_lens = inview("seq_lens", torch.int32, B)
         self.classes = inview("classes", torch.int32, B)
+        self.cls_rows = inview("cls_rows", torch.uint8, B * T, 8) if "cls_rows" in self.in_layout else None
 
     def load_batch(self, x, seq_lens, classes, labels, eps=None):
         """Copy one batch (host or device tensors / numpy arrays) into the static input buffers."""
@@ -485,6 +490,9 @@ class StepPlan:
             self.labels.copy_(dev(labels, torch.uint8).view(B * T, cfg.out_dim))
         self.seq_lens.copy_(dev(seq_lens, torch.int32))
         self.classes.copy_(dev(classes, torch.int32))
+        if self.cls_rows is not None:
+            onehot = (self.classes.view(B, 1).to(torch.int64) == torch.arange(8, device=self.dev).view(1, 8)).to(torch.uint8)
+            self.cls_rows.view(B, T, 8).copy_(onehot.view(B, 1, 8).expand(B, T, 8))
         if eps is not None:
             self.eps.copy_(dev(eps, torch.float32))
 
@@ -517,6 +525,9 @@ class StepPlan:
             np.copyto(seg("labels", np.uint8, B * T, cfg.out_dim), as_np(labels).reshape(B * T, cfg.out_dim), casting="unsafe")
         np.copyto(seg("seq_lens", np.int32, B), as_np(seq_lens).reshape(B), casting="unsafe")
         np.copyto(seg("classes", np.int32, B), as_np(classes).reshape(B), casting="unsafe")
+        if "cls_rows" in self.in_layout:
+            cr = seg("cls_rows", np.uint8, B, T, 8)
+            cr[...] = (as_np(classes).reshape(B, 1, 1).astype(np.int64) == np.arange(8).reshape(1, 1, 8)).astype(np.uint8)
         return blob
 
     def pack_batch(self, x, seq_lens, classes, labels):
@@ -954,7 +965,11 @@ class StepPlan:
         else:
             self._wgrads.append(o.wgrad_problem(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim,
                                                 K=De, scale=sq_e))
-            o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
+            if self.cls_rows is not None:  # dcls[c, :] = sq_e * sum over the frames of class c of d(x0): onehot^T d(x0)
+                self._wgrads.append(o.wgrad_problem(self.cls_rows, d_x0_e, st.grad("encoder.class2hid.weight"), M=B * T,
+                                                    N=cfg.num_classes, K=De, scale=sq_e))
+            else:
+                o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
         # every (remaining) Dense weight / bias gradient in ONE launch — all 15 problems of the step at configs[1] on a
         # single GPU: one resident round of workgroups with the smallest possible M-split instead of six launches
         self._flush_grads()

@@ -145,7 +145,7 @@ def test_selftest_layout_maps(gpu):
 
 # ------------------------------------------------------------------------------------------ GEMM NT
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (16384, 256, 256), (1000, 96, 160), (15, 10, 32), (16448, 128, 128),
-                                   (2048, 1024, 256), (512, 296, 128)])
+                                   (2048, 1024, 256), (512, 296, 128), (16384, 768, 256), (8192, 1536, 96)])  # (last two: 768 tiles of 128 x 128, the three-per-CU form with 32-deep stages)
 def test_gemm_nt_plain(gpu, M, N, K):
     o = ops()
     A = rnd((M, K), gpu, seed=1)
