@@ -135,6 +135,11 @@ class ParamStore:
                 order += [p + "W_k.bias", p + "W_q.bias", p + "W_v.bias"]
             else:
                 order.append(name)
+        if cfg.kind == "pianoroll":
+            # the class table right behind the input embedding: [in_dim + C, De] is then ONE matrix, and the class-embedding
+            # gradient is the last C rows of the embedding's weight-gradient problem (StepPlan.cls_fold)
+            order.remove("encoder.class2hid.weight")
+            order.insert(order.index("encoder.embedding.weight") + 1, "encoder.class2hid.weight")
         self.shapes, self.offsets = shapes, OrderedDict()
         off = 0
         for name in order:
@@ -339,11 +344,16 @@ class StepPlan:
         else:
             # piano-roll frames stay uint8 in HBM, exactly as the batcher delivers them (1 byte per pitch; rows padded to 8):
             # the embedding GEMMs and their weight gradients widen them while staging tiles into LDS (a_u8)
-            seg = [("roll", B * T * roundup(cfg.in_dim, 8)), ("labels", B * T * cfg.out_dim)]
-            # one-hot class id of every frame ([B*T, 8] uint8): the class-embedding gradient (a column sum of d(x0) per class) is
-            # then one more problem of the step's weight-gradient launch instead of a launch of its own
-            if cfg.num_classes <= 8 and os.environ.get("MST_CLS_WGRAD", "1") != "0":
-                seg.append(("cls_rows", B * T * 8))
+            # The class-embedding gradient is a column sum of d(x0) per class = onehot(class)^T d(x0): with the one-hot class id
+            # of a frame in C extra columns behind its pitches, and the class table behind the embedding table in the flat
+            # buffers, it is rows in_dim.. of the encoder embedding's weight-gradient problem — whose 256-row tile has the
+            # room — instead of a launch of its own (MST_CLS_WGRAD=0: the group_colsum launch)
+            C_ = cfg.num_classes
+            self.cls_fold = (os.environ.get("MST_CLS_WGRAD", "1") != "0" and cfg.in_dim % 8 == 0 and
+                             roundup(cfg.in_dim + C_, 256) == roundup(cfg.in_dim, 256) and
+                             store.offsets["encoder.class2hid.weight"] == store.offsets["encoder.embedding.weight"] + cfg.in_dim * De)
+            self.ld_roll = roundup(cfg.in_dim + (C_ if self.cls_fold else 0), 8)
+            seg = [("roll", B * T * self.ld_roll), ("labels", B * T * cfg.out_dim)]
         seg += [("seq_lens", B * 4), ("classes", B * 4)]
         self.in_layout, off = {}, 0
         for name, nbytes in seg:
@@ -469,11 +479,11 @@ class StepPlan:
             self.tokens = inview("tokens", torch.int32, B, T)
             self.labels = inview("labels", torch.int32, B, T)
         else:
-            self.roll = inview("roll", torch.uint8, B * T, roundup(cfg.in_dim, 8))
+            self.roll_cls = inview("roll", torch.uint8, B * T, self.ld_roll)  # [pitches | one-hot class | 0]
+            self.roll = self.roll_cls[:, : roundup(cfg.in_dim, 8)]
             self.labels = inview("labels", torch.uint8, B * T, cfg.out_dim)
         self.seq_lens = inview("seq_lens", torch.int32, B)
         self.classes = inview("classes", torch.int32, B)
-        self.cls_rows = inview("cls_rows", torch.uint8, B * T, 8) if "cls_rows" in self.in_layout else None
 
     def load_batch(self, x, seq_lens, classes, labels, eps=None):
         """Copy one batch (host or device tensors / numpy arrays) into the static input buffers."""
@@ -490,9 +500,10 @@ class StepPlan:
             self.labels.copy_(dev(labels, torch.uint8).view(B * T, cfg.out_dim))
         self.seq_lens.copy_(dev(seq_lens, torch.int32))
         self.classes.copy_(dev(classes, torch.int32))
-        if self.cls_rows is not None:
-            onehot = (self.classes.view(B, 1).to(torch.int64) == torch.arange(8, device=self.dev).view(1, 8)).to(torch.uint8)
-            self.cls_rows.view(B, T, 8).copy_(onehot.view(B, 1, 8).expand(B, T, 8))
+        if cfg.kind != "token" and self.cls_fold:
+            w = self.ld_roll - cfg.in_dim
+            onehot = (self.classes.view(B, 1).to(torch.int64) == torch.arange(w, device=self.dev).view(1, w)).to(torch.uint8)
+            self.roll_cls.view(B, T, -1)[:, :, cfg.in_dim:].copy_(onehot.view(B, 1, w).expand(B, T, w))
         if eps is not None:
             self.eps.copy_(dev(eps, torch.float32))
 
@@ -517,17 +528,18 @@ class StepPlan:
             np.copyto(seg("tokens", np.int32, B, T), as_np(x).reshape(B, T), casting="unsafe")
             np.copyto(seg("labels", np.int32, B, T), as_np(labels).reshape(B, T), casting="unsafe")
         else:
-            ldp = roundup(cfg.in_dim, 8)
+            ldp = self.ld_roll
             roll = seg("roll", np.uint8, B * T, ldp)
             np.copyto(roll[:, : cfg.in_dim], as_np(x).reshape(B * T, cfg.in_dim), casting="unsafe")
-            if ldp != cfg.in_dim:
+            if self.cls_fold:
+                w = ldp - cfg.in_dim
+                roll.reshape(B, T, ldp)[:, :, cfg.in_dim:] = (as_np(classes).reshape(B, 1, 1).astype(np.int64) ==
+                                                              np.arange(w).reshape(1, 1, w)).astype(np.uint8)
+            elif ldp != cfg.in_dim:
                 roll[:, cfg.in_dim:] = 0
             np.copyto(seg("labels", np.uint8, B * T, cfg.out_dim), as_np(labels).reshape(B * T, cfg.out_dim), casting="unsafe")
         np.copyto(seg("seq_lens", np.int32, B), as_np(seq_lens).reshape(B), casting="unsafe")
         np.copyto(seg("classes", np.int32, B), as_np(classes).reshape(B), casting="unsafe")
-        if "cls_rows" in self.in_layout:
-            cr = seg("cls_rows", np.uint8, B, T, 8)
-            cr[...] = (as_np(classes).reshape(B, 1, 1).astype(np.int64) == np.arange(8).reshape(1, 1, 8)).astype(np.uint8)
         return blob
 
     def pack_batch(self, x, seq_lens, classes, labels):
@@ -963,12 +975,10 @@ class StepPlan:
             o.embed_bwd(self.tokens, st.grad("encoder.embedding.weight"), d_x0_e.view(B, Se, -1), 0, sq_e,
                         classes=self.classes, dcls=st.grad("encoder.class2hid.weight"))
         else:
-            self._wgrads.append(o.wgrad_problem(self.roll, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T, N=cfg.in_dim,
-                                                K=De, scale=sq_e))
-            if self.cls_rows is not None:  # dcls[c, :] = sq_e * sum over the frames of class c of d(x0): onehot^T d(x0)
-                self._wgrads.append(o.wgrad_problem(self.cls_rows, d_x0_e, st.grad("encoder.class2hid.weight"), M=B * T,
-                                                    N=cfg.num_classes, K=De, scale=sq_e))
-            else:
+            # with cls_fold, rows in_dim.. of this problem are the class table's gradient (model.py:89: one class row per frame)
+            self._wgrads.append(o.wgrad_problem(self.roll_cls, d_x0_e, st.grad("encoder.embedding.weight"), M=B * T,
+                                                N=cfg.in_dim + (cfg.num_classes if self.cls_fold else 0), K=De, scale=sq_e))
+            if not self.cls_fold:
                 o.group_colsum(d_x0_e.view(B, Se, -1), T, De, 0, self.classes, st.grad("encoder.class2hid.weight"), sq_e)
         # every (remaining) Dense weight / bias gradient in ONE launch — all 15 problems of the step at configs[1] on a
         # single GPU: one resident round of workgroups with the smallest possible M-split instead of six launches
