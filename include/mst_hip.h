@@ -112,6 +112,12 @@ typedef struct mst_gemm_args {
 
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
 
+/* Two mst_gemm_nt problems in ONE launch: the piano-roll ends' two embedding GEMMs (model.py:81-91 encoder input and
+ * model.py:241-245 decoder input, transformer.py:237,270: the same uint8 frames against two tables), whose outputs and epilogues
+ * differ but whose kernel form is the same. Both problems uint8-A, 16-bit C, whole 64 x 64 tiles, row-indexed adds / C row
+ * remap only: one launch; anything else: exactly mst_gemm_nt(args0) followed by mst_gemm_nt(args1). */
+int mst_gemm_nt_pair(const mst_gemm_args* args0, const mst_gemm_args* args1, mst_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * K12 + K14 in one launch: the decoder's output layer Dense[D -> P] (model.py:253-256) with sigmoid + BinaryCrossEntropy
  * (loss.py:27-80) in its epilogue, for P = 128 or 256 (a 64-row x P tile holds whole rows of pitches, and — T a multiple

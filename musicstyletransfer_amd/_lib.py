@@ -141,6 +141,7 @@ SIGNATURES = {
     "mst_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(c_f32)]),
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "mst_gemm_nt_pair": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
     "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),

@@ -344,18 +344,18 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
 // 8-column chunk, requested BEFORE the K loop: the parameters are cold lines after every optimizer step, and a load issued at
 // the epilogue's start is a round trip that nothing covers once the tile's MFMAs are done.
 template <int BM, int BN>
-__device__ __forceinline__ void gemm_tile_origin(const mst_gemm_args& a, int64_t& m0, int64_t& n0) {
+__device__ __forceinline__ void gemm_tile_origin(const mst_gemm_args& a, int64_t& m0, int64_t& n0, int64_t bid_in = -1) {
   const int64_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM, nwg = tiles_m * tiles_n;
-  int64_t bid = blockIdx.x;
+  int64_t bid = bid_in < 0 ? (int64_t)blockIdx.x : bid_in;  // (bid_in: the tile's index inside its own problem, mst_gemm_nt_pair)
   const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
   bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
   m0 = (bid / tiles_n) * BM;
   n0 = (bid % tiles_n) * BN;
 }
 template <int BM, int BN>
-__device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float (&bias8)[8]) {
+__device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float (&bias8)[8], int64_t bid_in = -1) {
   int64_t m0, n0;
-  gemm_tile_origin<BM, BN>(a, m0, n0);
+  gemm_tile_origin<BM, BN>(a, m0, n0, bid_in);
   const int nc = (int)n0 + ((int)threadIdx.x % (BN / 8)) * 8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && nc + e < (int)a.N) ? a.bias[nc + e] : 0.f;
@@ -367,7 +367,8 @@ __device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float 
 // AU8: A holds uint8 elements (mst_gemm_args.a_u8): a chunk is an 8-byte load, widened when it is written to LDS.
 template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false>
 __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
-                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0) {
+                                              f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0,
+                                              int64_t bid_in = -1) {
   constexpr int CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   // XOR swizzle of a row's 16-byte chunk index (conflict-free ds_read_b128 of 16 rows at one k): the row's low 3 bits with
@@ -393,7 +394,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   const int64_t tiles_n = (a.N + BN - 1) / BN;
   const int64_t tiles_m = (a.M + BM - 1) / BM;
   const int64_t nwg = tiles_m * tiles_n;
-  int64_t bid = blockIdx.x;
+  int64_t bid = bid_in < 0 ? (int64_t)blockIdx.x : bid_in;
   {
     const int64_t q = nwg / 8, r = nwg % 8, x = bid % 8, y = bid / 8;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
@@ -508,6 +509,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS, AU8>(a, smem, acc, m0, n0);
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0, bias_pre);
+}
+
+// Two GEMMs of one kernel form in ONE launch (mst_gemm_nt_pair): the first `tiles0` workgroups are the first problem's tiles,
+// the rest the second's. The piano-roll ends' two embedding GEMMs (model.py:81-91 and :241-245: the same uint8 frames against the
+// encoder's and the decoder's table) — small launches whose cost is mostly the launch.
+template <typename T, int BM, int BN, int WGM, int WGN, int BK, int PATH>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_args a0, mst_gemm_args a1, int tiles0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+  int64_t m0, n0;
+  float bias_pre[8];
+  // (two straight-line copies of the tile, each reading its own argument block from the kernel arguments)
+  if ((int)blockIdx.x < tiles0) {
+    gemm_bias_preload<BM, BN>(a0, bias_pre, blockIdx.x);
+    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a0, smem, acc, m0, n0, blockIdx.x);
+    gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a0, smem, acc, m0, n0, bias_pre);
+  } else {
+    const int64_t bid = (int64_t)blockIdx.x - tiles0;
+    gemm_bias_preload<BM, BN>(a1, bias_pre, bid);
+    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a1, smem, acc, m0, n0, bid);
+    gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a1, smem, acc, m0, n0, bias_pre);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1454,6 +1477,20 @@ static int launch_gemm_3cu(const mst_gemm_args& a, hipStream_t s) {
   return MST_OK;
 }
 
+// every tile interior and every optional operand 16-byte friendly: the launch takes the kernel that holds only the fast row loop
+template <int BM, int BN>
+static bool gemm_fast_form(const mst_gemm_args& a) {
+  const bool rowops = a.rowadd || a.grpadd || a.a_rows_per_group > 0 || a.c_rows_per_group > 0;
+  const int64_t phys_rows = a.c_rows_per_group > 0 ? (a.M / a.c_rows_per_group + 1) * a.c_group_stride + a.c_group_offset : a.M;
+  return !a.c_f32 && a.M % BM == 0 && a.N % BN == 0 && a.ldc % 8 == 0 &&
+         (a.c_rows_per_group <= 0 || a.c_rows_per_group % BM == 0) &&
+         (uint64_t)phys_rows * (uint64_t)a.N < (1ull << 32) &&
+         (!a.resid || (a.ldr % 8 == 0 && (uintptr_t)a.resid % 16 == 0)) &&
+         (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0)) &&
+         (!rowops || (a.rowadd_period % BM == 0 && (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
+                      (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int BK = 64>
 static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const int64_t tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -1462,16 +1499,7 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
   // ("row ops" in the kernel choice: row-indexed adds or a row remap of A or C)
   const bool rowops = a.rowadd || a.grpadd || a.a_rows_per_group > 0 || a.c_rows_per_group > 0;
-  // every tile interior and every optional operand 16-byte friendly: the launch takes the kernel that holds only the
-  // fast row loop (conditions of the former per-tile test, now decided once per launch)
-  const int64_t phys_rows = a.c_rows_per_group > 0 ? (a.M / a.c_rows_per_group + 1) * a.c_group_stride + a.c_group_offset : a.M;
-  const bool fast = !a.c_f32 && a.M % BM == 0 && a.N % BN == 0 && a.ldc % 8 == 0 &&
-                    (a.c_rows_per_group <= 0 || a.c_rows_per_group % BM == 0) &&
-                    (uint64_t)phys_rows * (uint64_t)a.N < (1ull << 32) &&
-                    (!a.resid || (a.ldr % 8 == 0 && (uintptr_t)a.resid % 16 == 0)) &&
-                    (!a.gate || (a.ldg % 8 == 0 && (uintptr_t)a.gate % 16 == 0)) &&
-                    (!rowops || (a.rowadd_period % BM == 0 && (!a.rowadd || (a.ldra % 4 == 0 && (uintptr_t)a.rowadd % 16 == 0)) &&
-                                 (!a.grpadd || (a.ldga % 4 == 0 && (uintptr_t)a.grpadd % 16 == 0))));
+  const bool fast = gemm_fast_form<BM, BN>(a);
   const bool drop = a.dropout_p > 0.f || a.self_resid;
   // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
   // (measured, in-call A/B at configs[1]: 0.787 ms per step with the direct form on its 8 eligible launches against 0.783
@@ -1728,6 +1756,33 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // (32-deep K stages for launches of 1281..2048 64 x 64 tiles — eight workgroups per CU, one resident round for the decoder's
     // 257 x 6 projection tiles — measured no faster: +2 us per step)
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
+  });
+}
+
+extern "C" int mst_gemm_nt_pair(const mst_gemm_args* args0, const mst_gemm_args* args1, mst_stream_t stream) {
+  MST_CHECK_ARG(args0 != nullptr && args1 != nullptr, "mst_gemm_nt_pair: null args");
+  const mst_gemm_args &a0 = *args0, &a1 = *args1;
+  // one launch for two uint8-A problems of the fast row-op form (what the embedding GEMMs are); anything else is two launches
+  // of mst_gemm_nt, which also reports what is wrong with an argument
+  auto plain = [](const mst_gemm_args& a) {
+    return a.a_u8 && !a.c_f32 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc >= a.N &&
+           a.A && a.B && a.C && (uintptr_t)a.A % 16 == 0 && (uintptr_t)a.B % 16 == 0 && (uintptr_t)a.C % 16 == 0 && !a.resid && !a.gate &&
+           a.act == 0 && a.dropout_p == 0.f && !a.self_resid && ((!a.rowadd && !a.grpadd) || a.rowadd_period > 0) &&
+           (!a.grpadd || a.grp_index) && gemm_fast_form<64, 64>(a) && cdiv(a.M, 64) * cdiv(a.N, 64) < (1 << 20);
+  };
+  static const bool off = getenv("MST_GEMM_PAIR") && getenv("MST_GEMM_PAIR")[0] == '0';
+  if (off || a0.dtype != a1.dtype || !plain(a0) || !plain(a1)) {
+    const int rc = mst_gemm_nt(args0, stream);
+    return rc != MST_OK ? rc : mst_gemm_nt(args1, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a0.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    const int tiles0 = (int)((a0.M / 64) * (a0.N / 64)), tiles1 = (int)((a1.M / 64) * (a1.N / 64));
+    const size_t lds = (size_t)2 * (64 + 64) * 64 * 2;  // K-loop stages; the 64 x 68 fp32 epilogue staging is smaller
+    hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(tiles0 + tiles1)), dim3(256), lds, s, a0, a1, tiles0);
+    MST_CHECK_LAUNCH("gemm_nt_pair_kernel");
+    return MST_OK;
   });
 }
 

@@ -649,8 +649,11 @@ class StepPlan:
             o.embed_fwd(self.tokens, st.p("encoder.embedding.weight"), self.pos_e, self.x0_e.view(B, Se, -1), 0, sq_e,
                         classes=self.classes, cls_table=st.p("encoder.class2hid.weight"), keymask=self.keymask_e)
         else:
-            o.gemm_nt(self.roll, st.t("encoder.embedding.weight"), self.x0_e, N=De, alpha=sq_e,
-                      grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T)
+            # both ends' embedding GEMMs read the same frames: one launch (the decoder's rows 1..T; its row 0 is latent_fwd's)
+            o.gemm_nt_pair(dict(A=self.roll, B=st.t("encoder.embedding.weight"), C_out=self.x0_e, N=De, alpha=sq_e,
+                                grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T),
+                           dict(A=self.roll, B=st.t("decoder.embedding.weight"), C_out=self.x0_d, M=B * T, N=Dd, alpha=sq_d,
+                                rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1)))
         x = self.x0_e
         for i, L in enumerate(self.enc):
             x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, self._site_e(i))
@@ -663,9 +666,6 @@ class StepPlan:
         # ---- decoder positions 1..T (model.py:241-245, transformer.py:237)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos_d, self.x0_d.view(B, Sd, -1), 1, sq_d)
-        else:
-            o.gemm_nt(self.roll, st.t("decoder.embedding.weight"), self.x0_d, M=B * T, N=Dd, alpha=sq_d,
-                      rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1))
         x = self.x0_d
         site_d = self._site_d(0)
         for i, L in enumerate(self.dec):

@@ -84,6 +84,11 @@ def gemm_nt(A, B, C_out, **kw):
     call("mst_gemm_nt", C.byref(_gemm_args(A, B, C_out, **kw)), stream())
 
 
+def gemm_nt_pair(first, second):
+    """two gemm_nt problems, each a dict(A=, B=, C_out=, **kw), in one launch where their form allows (mst_gemm_nt_pair)"""
+    call("mst_gemm_nt_pair", C.byref(_gemm_args(**first)), C.byref(_gemm_args(**second)), stream())
+
+
 def can_row_tail(B, D):
     """shapes the one-launch position-0 tail of the top encoder layer exists for (mst_row_tail_fwd)"""
     return D in (128, 256) and 0 < B <= 64

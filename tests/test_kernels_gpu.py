@@ -200,6 +200,69 @@ def test_gemm_nt_and_wgrad_uint8_frames_equal_the_16bit_operand(gpu, M, P, N, pe
     close(grads[0], 0.5 * frames[:, :P].float().t() @ dY.float().cpu(), 1e-3, 1e-3 * math.sqrt(M), "embedding wgrad on uint8 frames")
 
 
+@pytest.mark.parametrize("B,T,P,De,Dd,dtype", [(64, 256, 128, 256, 128, BF), (4, 64, 2048, 128, 64, torch.float16), (3, 50, 40, 64, 64, BF)])
+def test_gemm_nt_pair_equals_the_two_launches(gpu, B, T, P, De, Dd, dtype):
+    """mst_gemm_nt_pair: the encoder's and the decoder's embedding GEMM (same uint8 frames, different tables, adds and output
+    row remap) in one launch — bit-identical to the two launches, also where the form falls back to them (the ragged third case)"""
+    o = ops()
+    g = torch.Generator().manual_seed(15)
+    M, ld8 = B * T, o.roundup(P + 2, 8)  # (two more byte columns behind the pitches, as the engine lays a frame out)
+    frames = torch.zeros(M, ld8, dtype=torch.uint8)
+    frames[:, :P] = (torch.rand(M, P, generator=g) < 0.05).to(torch.uint8)
+    frames[:, P:] = 1
+    f8 = frames.to(gpu)[:, : o.roundup(P, 8)]
+    te, td = rnd((De, o.roundup(P, 8)), gpu, 0.1, dtype, seed=16), rnd((Dd, o.roundup(P, 8)), gpu, 0.1, dtype, seed=17)
+    pos_e, pos_d = rnd((T, De), gpu, 1.0, torch.float32, seed=18), rnd((T + 1, Dd), gpu, 1.0, torch.float32, seed=19)
+    cls = rnd((3, De), gpu, 1.0, torch.float32, seed=20)
+    idx = torch.randint(0, 3, (B,), generator=g).to(torch.int32).to(gpu)
+
+    def problems(xe, xd):
+        return (dict(A=f8, B=te, C_out=xe, N=De, K=o.roundup(P, 8), alpha=1.5, grpadd=cls, grp_index=idx, rowadd=pos_e, rowadd_period=T),
+                dict(A=f8, B=td, C_out=xd, M=M, N=Dd, K=o.roundup(P, 8), alpha=0.5, rowadd=pos_d[1:], rowadd_period=T, c_remap=(T, T + 1, 1)))
+
+    outs = []
+    for pair in (True, False):
+        xe = torch.zeros(M, De, dtype=dtype, device=gpu)
+        xd = torch.full((B * (T + 1), Dd), 7.0, dtype=dtype, device=gpu)
+        first, second = problems(xe, xd)
+        if pair:
+            o.gemm_nt_pair(first, second)
+        else:
+            o.gemm_nt(first.pop("A"), first.pop("B"), first.pop("C_out"), **first)
+            o.gemm_nt(second.pop("A"), second.pop("B"), second.pop("C_out"), **second)
+        outs.append((xe, xd))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][1].view(B, T + 1, Dd)[:, 0] == 7.0).all(), "row 0 of every sample belongs to the latent block"
+    fr = frames[:, :P].float()
+    ref_e = 1.5 * (fr @ te[:, :P].float().cpu().t() + cls.cpu()[idx.cpu().long()[torch.arange(M) // T]]) + pos_e.cpu()[torch.arange(M) % T]
+    close(outs[0][0], ref_e, 2e-2, 2e-2, "encoder embedding of the pair")
+    ref_d = 0.5 * (fr @ td[:, :P].float().cpu().t()) + pos_d.cpu()[1:][torch.arange(M) % T]
+    close(outs[0][1].view(B, T + 1, Dd)[:, 1:].reshape(M, Dd), ref_d, 2e-2, 2e-2, "decoder embedding of the pair")
+
+
+def test_wgrad_class_columns_behind_the_pitches_give_the_class_gradient(gpu):
+    """StepPlan.cls_fold: the one-hot class id of a frame's sequence in C byte columns behind its pitches makes the class table's
+    gradient (model.py:89: one class row added to every frame) rows P.. of the embedding's weight-gradient problem"""
+    o = ops()
+    g = torch.Generator().manual_seed(21)
+    B, T, P, Cn, D = 8, 64, 128, 2, 256
+    M, ld = B * T, o.roundup(P + Cn, 8)
+    classes = torch.randint(0, Cn, (B,), generator=g)
+    frames = torch.zeros(B, T, ld, dtype=torch.uint8)
+    frames[:, :, :P] = (torch.rand(B, T, P, generator=g) < 0.05).to(torch.uint8)
+    frames[:, :, P:] = (classes.view(B, 1, 1) == torch.arange(ld - P).view(1, 1, -1)).to(torch.uint8)
+    dY = rnd((M, D), gpu, 1.0, BF, seed=22)
+    dW = torch.zeros(P + Cn + 3, D, dtype=torch.float32, device=gpu)
+    o.gemm_wgrad(frames.view(M, ld).to(gpu), dY, dW, N=P + Cn, K=D, scale=2.0)
+    torch.cuda.synchronize()
+    dy = dY.float().cpu().view(B, T, D)
+    close(dW[:P], 2.0 * frames.view(M, ld)[:, :P].float().t() @ dy.view(M, D), 1e-3, 1e-3 * math.sqrt(M), "embedding rows")
+    want = torch.stack([2.0 * dy[classes == c].sum((0, 1)) for c in range(Cn)])
+    close(dW[P: P + Cn], want, 1e-3, 1e-3 * math.sqrt(M), "class rows")
+    assert (dW[P + Cn:] == 0).all(), "rows beyond N are not touched"
+
+
 def test_gemm_nt_integer_exact_asymmetric(gpu):
     """small-integer operands: exact in bf16 and fp32, catches any transposed / permuted fragment"""
     o = ops()
