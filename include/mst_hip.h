@@ -218,7 +218,7 @@ int mst_ffn_ln_bwd_tail(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgra
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order
  * (deterministic). The LayerNorm-backward launches leave per-workgroup partial sums of dgamma / dbeta (`partials`
  * above and in mst_layernorm_bwd); one launch of this adds all of a backward pass's sites into the gradient bucket.
- * len % 4 == 0, stride % 4 == 0, src and dst 16-byte aligned; up to 24 jobs (host array) per launch.
+ * len % 4 == 0, stride % 4 == 0, src and dst 16-byte aligned; up to 20 jobs (host array) per launch.
  * ------------------------------------------------------------------------ */
 typedef struct mst_partial_sum {
   const float* src; int64_t n_parts; int64_t stride; int64_t len;
@@ -259,11 +259,28 @@ int mst_gemm_wgrad_batch(const mst_wgrad_args* list, int n, mst_stream_t stream)
  * summed in slab order by a second launch: no fp32 atomics on dW (deterministic gradients, and 62 MB of atomic traffic
  * less at configs[1]). Otherwise identical to mst_gemm_wgrad_batch. 64 MiB covers configs[1]. */
 int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes, mst_stream_t stream);
-/* The same plus up to 24 column-sum jobs (mst_partial_sum below: the LayerNorm-backward launches' per-workgroup dgamma /
+/* The same plus up to 20 column-sum jobs (mst_partial_sum below: the LayerNorm-backward launches' per-workgroup dgamma /
  * dbeta rows): they are executed by extra workgroups of the reduction pass when there is one, else by one
  * mst_partial_sums launch after the weight gradients — either way the flush of a backward pass is one call. */
 int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
                               const mst_partial_sum* sums, int n_sums, mst_stream_t stream);
+
+/* Deferred batch outer products: out[j, i] += sum_b L[b, j] * R[b, i] (out fp32 [J, I] contiguous, accumulated into) and, with
+ * obias, obias[j] += sum_b L[b, j]. L fp32 [B, J] contiguous; R [B, >= I] of r_dtype (MST_F32 / MST_BF16 / MST_F16) with row stride
+ * r_stride elements. The parameter gradients of a layer that sees one row per sample — the latent block's latent_proj and
+ * latent2hid (model.py:97-103,229-232; what mst_latent_bwd's second launch computes from mst_latent_bwd_vec's `scratch`) — which
+ * nothing downstream but the optimizer reads. Up to 2 jobs per call. */
+typedef struct mst_outer_job {
+  const float* L; const void* R; int32_t r_dtype; int64_t r_stride;
+  int64_t B, J, I;
+  float* out; float* obias;
+} mst_outer_job;
+int mst_outer_jobs(const mst_outer_job* jobs, int n, mst_stream_t stream);
+/* mst_gemm_wgrad_batch_sums plus up to 2 outer-product jobs: extra workgroups of the reduction pass when there is one, else one
+ * mst_outer_jobs launch after the weight gradients. */
+int mst_gemm_wgrad_batch_flush(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
+                               const mst_partial_sum* sums, int n_sums, const mst_outer_job* outers, int n_outers,
+                               mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K1/K2: token path input. out[b, s_off + t, :] = alpha*(table[tok[b,t]] + cls[classes[b]]) + pos[s_off+t]
@@ -388,6 +405,14 @@ int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    float* dWl, float* dbl, float* dWh, float* dbh, float* dcls_d, int64_t ld_cls,
                    void* d_enc_out, int64_t denc_sample_stride, float* scratch /* fp32 [B*(Dd+2Z)] */,
                    mst_stream_t stream);
+/* mst_latent_bwd's first launch on its own, with the decoder class table's gradient (dcls_d[classes[b], :] += t[b, :]) folded in:
+ * leaves t = alpha_d * d(dec_in[b, 0, :]) at scratch[0 .. B*Dd) and d[mu | sigma] at scratch[B*Dd .. B*(Dd + 2Z)), writes d(enc_out)
+ * row 0. The remaining parameter gradients are two mst_outer_job of the caller's weight-gradient flush:
+ *   dWl[2Z, De] += dlat^T enc_out[:, 0, :], dbl += sum_b dlat;   dWh[Dd, Z] += t^T z, dbh += sum_b t. */
+int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps, const float* Wh,
+                       const int32_t* classes, const float* mu, const float* sigma, const void* d_dec_in, int64_t dec_sample_stride,
+                       float alpha_d, float kl_weight, float gscale, float enc_scale, float* dcls_d, int64_t ld_cls,
+                       void* d_enc_out, int64_t denc_sample_stride, float* scratch, mst_stream_t stream);
 
 /* standalone reparameterisation + KL (loss.VariationalKLLoss, loss.py:4-12; model.py:292) */
 int mst_reparam_kl_fwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,

@@ -111,6 +111,14 @@ class PartialSum(C.Structure):
     ]
 
 
+class OuterJob(C.Structure):
+    _fields_ = [
+        ("L", vp), ("R", vp), ("r_dtype", c_i32), ("r_stride", c_i64),
+        ("B", c_i64), ("J", c_i64), ("I", c_i64),
+        ("out", vp), ("obias", vp),
+    ]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("dtype", c_i32),
@@ -158,6 +166,11 @@ SIGNATURES = {
     "mst_gemm_wgrad_batch": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
     "mst_gemm_wgrad_batch_ws": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, vp]),
     "mst_gemm_wgrad_batch_sums": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, C.POINTER(PartialSum), C.c_int, vp]),
+    "mst_gemm_wgrad_batch_flush": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp, c_i64, C.POINTER(PartialSum), C.c_int,
+                                             C.POINTER(OuterJob), C.c_int, vp]),
+    "mst_outer_jobs": (C.c_int, [C.POINTER(OuterJob), C.c_int, vp]),
+    "mst_latent_bwd_vec": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_f32,
+                                     c_f32, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,
                                 vp, c_i64, c_i64, c_i64, vp, vp]),
     "mst_embed_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, c_f32,

@@ -13,6 +13,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "partial_sums.hpp"
+#include "outer_jobs.hpp"
 
 namespace mst {
 
@@ -461,11 +462,12 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
 // dW[n, k] += scale * sum over the M-slabs (in slab order) of the tiles wgrad_kernel left in the scratch buffer.
 // grid = (tile elements / 1024, tiles); a thread owns 4 consecutive k of one n.
 template <int BN, int BKO>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, PartialSumBatch ps) {
-  if (blockIdx.y >= (unsigned)b.tile_prefix[b.n]) {  // rows of workgroups past the tiles: the caller's column-sum jobs
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, PartialSumBatch ps, OuterBatch ob) {
+  if (blockIdx.y >= (unsigned)b.tile_prefix[b.n]) {  // rows of workgroups past the tiles: the caller's column-sum / outer-product jobs
     __shared__ f32x4 red[16][16];
     const int wg = (int)((blockIdx.y - (unsigned)b.tile_prefix[b.n]) * gridDim.x + blockIdx.x);
     if (wg < ps.wg_prefix[ps.n]) partial_sums_wg(ps, wg, red);
+    else if (wg - ps.wg_prefix[ps.n] < ob.wg_prefix[ob.n]) outer_jobs_wg(ob, wg - ps.wg_prefix[ps.n], reinterpret_cast<float(*)[64]>(&red[0][0]));
     return;
   }
   const int64_t tile_lin = blockIdx.y;
@@ -496,11 +498,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, Partial
     if (k + c < a.K) d[c] += sum[c] * a.scale;
 }
 
-static_assert(sizeof(WgradBatch) + sizeof(PartialSumBatch) <= 4096, "kernel arguments of the reduction pass");
+static_assert(sizeof(WgradBatch) + sizeof(PartialSumBatch) + sizeof(OuterBatch) <= 4096, "kernel arguments of the reduction pass");
 
 // *ps_done: the column-sum jobs were taken along by the reduction pass
 template <typename T>
-static int launch_wgrad(const WgradBatch& b, int big, const PartialSumBatch* ps, bool* ps_done, hipStream_t s) {
+static int launch_wgrad(const WgradBatch& b, int big, const PartialSumBatch* ps, bool* ps_done, hipStream_t s, const OuterBatch& ob) {
   const int64_t total = cdiv(b.item_prefix[b.n], 8) * 8;  // padded to whole XCD rounds (see the kernel)
   if (big == 3) {
     constexpr int BN = 256, BKO = 256;
@@ -520,9 +522,9 @@ static int launch_wgrad(const WgradBatch& b, int big, const PartialSumBatch* ps,
       none.n = 0;
       for (int i = 0; i <= PS_MAXJ; ++i) none.wg_prefix[i] = 0;
       const PartialSumBatch& pb = ps ? *ps : none;
-      const unsigned extra = (unsigned)cdiv(pb.wg_prefix[pb.n], GX);
-      hipLaunchKernelGGL((wgrad_reduce_kernel<BN, BKO>), dim3(GX, (unsigned)b.tile_prefix[b.n] + extra), dim3(256), 0, s, b, pb);
-      if (ps) *ps_done = true;
+      const unsigned extra = (unsigned)cdiv(pb.wg_prefix[pb.n] + ob.wg_prefix[ob.n], GX);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<BN, BKO>), dim3(GX, (unsigned)b.tile_prefix[b.n] + extra), dim3(256), 0, s, b, pb, ob);
+      *ps_done = true;  // (the column sums and the outer products)
     }
   } else if (big == 2) {
     constexpr int BN = 256, BKO = 128;
@@ -579,7 +581,18 @@ extern "C" int mst_gemm_wgrad_batch_ws(const mst_wgrad_args* list, int n, float*
 
 extern "C" int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
                                          const mst_partial_sum* sums, int n_sums, mst_stream_t stream) {
+  return mst_gemm_wgrad_batch_flush(list, n, scratch, scratch_bytes, sums, n_sums, nullptr, 0, stream);
+}
+
+extern "C" int mst_gemm_wgrad_batch_flush(const mst_wgrad_args* list, int n, float* scratch, int64_t scratch_bytes,
+                                          const mst_partial_sum* sums, int n_sums, const mst_outer_job* outers, int n_outers,
+                                          mst_stream_t stream) {
   MST_CHECK_ARG(list != nullptr && n >= 1 && n <= WG_MAXP, "mst_gemm_wgrad_batch: need 1..%d problems", WG_MAXP);
+  OuterBatch ob;
+  {
+    int rc = pack_outer_jobs(outers, n_outers, ob);
+    if (rc) return rc;
+  }
   MST_CHECK_ARG(n_sums >= 0 && (n_sums == 0 || sums != nullptr), "mst_gemm_wgrad_batch_sums: bad column-sum job list");
   PartialSumBatch ps;
   if (n_sums > 0) {
@@ -657,9 +670,10 @@ extern "C" int mst_gemm_wgrad_batch_sums(const mst_wgrad_args* list, int n, floa
   bool ps_done = false;
   int rc = dispatch_act(list[0].dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    return launch_wgrad<T>(b, big, n_sums > 0 ? &ps : nullptr, &ps_done, s);
+    return launch_wgrad<T>(b, big, n_sums > 0 ? &ps : nullptr, &ps_done, s, ob);
   });
   if (rc == MST_OK && n_sums > 0 && !ps_done) rc = mst_partial_sums(sums, n_sums, stream);  // no reduction pass: own launch
+  if (rc == MST_OK && n_outers > 0 && !ps_done) rc = mst_outer_jobs(outers, n_outers, stream);
   return rc;
 }
 

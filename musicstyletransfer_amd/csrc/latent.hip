@@ -14,6 +14,7 @@
 // quantity in the ELBO.
 #include <math.h>
 #include "common.hpp"
+#include "outer_jobs.hpp"
 
 namespace mst {
 
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
                                                                      float alpha_d, float kl_weight, float gscale,
                                                                      float enc_scale, float* __restrict__ tvec,
                                                                      float* __restrict__ dlat, T* __restrict__ d_enc_out,
-                                                                     int64_t denc_stride) {
+                                                                     int64_t denc_stride, const int32_t* __restrict__ classes,
+                                                                     float* __restrict__ dcls, int64_t ld_cls) {
   extern __shared__ float sm[];
   float* t = sm;             // [Dd]
   float* dl = sm + Dd;       // [2Z]
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
     const float v = alpha_d * to_f32(d_dec_in[b * dec_stride + j]);
     t[j] = v;
     tvec[b * Dd + j] = v;
+    if (dcls) atomicAdd(dcls + (int64_t)classes[b] * ld_cls + j, v);  // (mst_latent_bwd_vec: the class table's gradient)
   }
   __syncthreads();
   // dz[i] = sum_j t[j] * Wh[j,i]: thread (i, part) sums every np-th j
@@ -253,49 +256,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   }
 }
 
-// parameter gradients: out[j, i] += sum_b L[b, j] * R[b, i]; obias[j] += sum_b L[b, j]. A 256-thread workgroup owns 64
-// outputs; its four waves take a quarter of the batch each (8 rows in flight per thread: the strided rows of R are cold
-// lines and the loop is one memory round trip per group — one thread per output walking the whole batch was 11 us) and
-// the quarters are added in order through LDS (deterministic).
-template <typename RT>
-__device__ __forceinline__ void batch_outer(int64_t blk, int tid, int64_t B, int J, int I, const float* __restrict__ L,
-                                            const RT* __restrict__ R, int64_t r_stride, float* __restrict__ out,
-                                            float* __restrict__ obias, float (*red)[64]) {
-  const int o = tid & 63, part = tid >> 6;
-  const int64_t idx = blk * 64 + o;
-  const int64_t per = (B + 3) / 4, b0 = part * per, b1 = b0 + per < B ? b0 + per : B;
-  float acc = 0.f, accb = 0.f;
-  if (idx < (int64_t)J * I) {
-    const int j = (int)((uint32_t)idx / (uint32_t)I), i = (int)((uint32_t)idx - (uint32_t)j * (uint32_t)I);  // (J * I < 2^31: host check)
-    float a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.f;
-    int64_t b = b0;
-    for (; b + 8 <= b1; b += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = fmaf(L[(b + u) * J + j], to_f32(R[(b + u) * r_stride + i]), a[u]);
-    }
-    for (; b < b1; ++b) a[0] = fmaf(L[b * J + j], to_f32(R[b * r_stride + i]), a[0]);
-    acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  }
-  if (obias && idx < J) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t b = b0;
-    for (; b + 4 <= b1; b += 4) {
-      a0 += L[(b + 0) * J + idx]; a1 += L[(b + 1) * J + idx]; a2 += L[(b + 2) * J + idx]; a3 += L[(b + 3) * J + idx];
-    }
-    for (; b < b1; ++b) a0 += L[b * J + idx];
-    accb = (a0 + a1) + (a2 + a3);
-  }
-  red[part][o] = acc;
-  red[4 + part][o] = accb;
-  __syncthreads();
-  if (part == 0) {
-    if (idx < (int64_t)J * I) out[idx] += (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-    if (obias && idx < J) obias[idx] += (red[4][o] + red[5][o]) + (red[6][o] + red[7][o]);
-  }
-}
-
+// (batch_outer: outer_jobs.hpp)
 // ONE launch for the three parameter-gradient pieces of the latent block (they were three ~5-14 us launches):
 // blocks [0, n_wl): dWl[2Z, De] += dlat^T h0, dbl; blocks [n_wl, n_wl + n_wh): dWh[Dd, Z] += t^T z, dbh;
 // the rest: dcls_d[class_b, :] += t[b, :]
@@ -368,7 +329,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
     typedef decltype(tag) T;
     hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
                        eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
-                       dlat, (T*)d_enc_out, denc_sample_stride);
+                       dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     hipLaunchKernelGGL((latent_param_grads_kernel<T>), dim3((unsigned)(n_wl + n_wh + n_cls)), dim3(256), 0, s, B, (int)De, (int)Z,
                        (int)Dd, dlat, (const T*)enc_out, enc_sample_stride, tvec, z, classes, dWl, dbl, dWh, dbh, dcls_d, ld_cls,
@@ -376,4 +337,40 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
     MST_CHECK_LAUNCH("latent_param_grads_kernel");
     return MST_OK;
   });
+}
+
+extern "C" int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps,
+                                  const float* Wh, const int32_t* classes, const float* mu, const float* sigma,
+                                  const void* d_dec_in, int64_t dec_sample_stride, float alpha_d, float kl_weight, float gscale,
+                                  float enc_scale, float* dcls_d, int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride,
+                                  float* scratch, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_bwd_vec: sizes must be positive");
+  MST_CHECK_ARG(Wl && eps && Wh && classes && mu && sigma && d_dec_in && dcls_d && d_enc_out && scratch, "mst_latent_bwd_vec: null pointer");
+  MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd_vec: latent size above %d", LAT_THREADS);
+  const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
+                       (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
+                       scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
+    MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
+    return MST_OK;
+  });
+}
+
+namespace mst {
+__global__ __launch_bounds__(256) void outer_jobs_kernel(OuterBatch b) {
+  __shared__ float red[8][64];
+  outer_jobs_wg(b, (int)blockIdx.x, red);
+}
+}  // namespace mst
+
+extern "C" int mst_outer_jobs(const mst_outer_job* jobs, int n, mst_stream_t stream) {
+  OuterBatch b;
+  int rc = pack_outer_jobs(jobs, n, b);
+  if (rc) return rc;
+  if (b.wg_prefix[b.n] == 0) return MST_OK;
+  hipLaunchKernelGGL(outer_jobs_kernel, dim3((unsigned)b.wg_prefix[b.n]), dim3(256), 0, (hipStream_t)stream, b);
+  MST_CHECK_LAUNCH("outer_jobs_kernel");
+  return MST_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace mst {
 
-constexpr int PS_MAXJ = 24;  // (the reduction pass of gemm_wgrad.hip passes this next to its own 2.6 KB of arguments)
+constexpr int PS_MAXJ = 20;  // (the reduction pass of gemm_wgrad.hip passes this and the outer-product jobs next to its own 2.8 KB of arguments)
 struct PartialSumBatch {
   int n;
   int wg_prefix[PS_MAXJ + 1];  // workgroups of job j are [wg_prefix[j], wg_prefix[j+1])

@@ -363,6 +363,8 @@ class StepPlan:
         self.bind_inputs(self.own_inbuf)
         self.eps = torch.zeros(B, Z, **f32)
         self.rng_state = store.rng_state(seed)
+        self.defer_latent_grads = os.environ.get("MST_DEFER_LATENT", "1") != "0"
+        self._outers = []
 
         self.pos_e = torch.from_numpy(positional_table(De, Se)).to(dev)
         self.pos_d = torch.from_numpy(positional_table(Dd, Sd)).to(dev)
@@ -715,9 +717,9 @@ class StepPlan:
 
     def _flush_grads(self):
         """the weight gradients collected so far in one wgrad launch; the LayerNorm column sums ride on its reduction pass"""
-        o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch, sums=self._psums)
+        o.gemm_wgrad_batch(self._wgrads, scratch=self.wgrad_scratch, sums=self._psums, outers=self._outers)
         self.last_wgrad_launch = (self._wgrads, self._psums)  # (bench.py re-launches the step's own wgrad batch to time it)
-        self._wgrads, self._psums = [], []
+        self._wgrads, self._psums, self._outers = [], [], []
 
     def _out_ln_bwd(self, side, i, L, D, p, site0, t, M):
         """The LayerNorm backward a layer's backward pass STARTS with (LN2 of an encoder layer, LN3 of a decoder layer),
@@ -910,7 +912,7 @@ class StepPlan:
         Se, Sd = T, T + 1
         sq_d = math.sqrt(float(Dd))
         # (the gradient bucket was cleared by forward()'s step_begin launch)
-        self._wgrads, self._psums = [], []
+        self._wgrads, self._psums, self._outers = [], [], []
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         fuse_d, fuse_e = o.ln_bwd_fusion_pays(Dd), o.ln_bwd_fusion_pays(De)
@@ -941,13 +943,24 @@ class StepPlan:
                                                 K=Dd, scale=sq_d, b_remap=(T, Sd, 1)))
         # gradient w.r.t. the encoder output: zero except position 0 of every sample
         d_enc = self.d_enc_out
-        o.latent_bwd(self.enc_out.view(B, Se, -1), st.p("encoder.latent_proj.weight"), self.eps,
-                     st.p("decoder.latent2hid.weight"), self.classes, self.mu, self.sigma, self.z,
-                     d_x0_d.view(B, Sd, -1), sq_d, self.kl_weight, self.gscale_enc,
-                     st.grad("encoder.latent_proj.weight"), st.grad("encoder.latent_proj.bias"),
-                     st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"),
-                     st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
-                     enc_scale=self.gscale_enc / self.gscale)
+        if self.defer_latent_grads:
+            # nothing but the optimizer reads the latent block's parameter gradients: they ride on the weight-gradient flush (extra
+            # workgroups of its reduction pass) instead of being a launch in the middle of the backward pass's dependent chain
+            o.latent_bwd_vec(st.p("encoder.latent_proj.weight"), self.eps, st.p("decoder.latent2hid.weight"), self.classes, self.mu,
+                             self.sigma, d_x0_d.view(B, Sd, -1), sq_d, self.kl_weight, self.gscale_enc,
+                             st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
+                             enc_scale=self.gscale_enc / self.gscale)
+            self._outers += o.latent_outer_jobs(self.lat_scratch, self.enc_out.view(B, Se, -1), self.z,
+                                                st.grad("encoder.latent_proj.weight"), st.grad("encoder.latent_proj.bias"),
+                                                st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"))
+        else:
+            o.latent_bwd(self.enc_out.view(B, Se, -1), st.p("encoder.latent_proj.weight"), self.eps,
+                         st.p("decoder.latent2hid.weight"), self.classes, self.mu, self.sigma, self.z,
+                         d_x0_d.view(B, Sd, -1), sq_d, self.kl_weight, self.gscale_enc,
+                         st.grad("encoder.latent_proj.weight"), st.grad("encoder.latent_proj.bias"),
+                         st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"),
+                         st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
+                         enc_scale=self.gscale_enc / self.gscale)
         top = cfg.e_layers - 1
         x_in = self.enc[top - 1].x2 if top > 0 else self.x0_e
         below = (self._out_ln_bwd("encoder", top - 1, self.enc[top - 1], De, cfg.e_dropout, self._site_e(top - 1), self.be_l[top - 1], self.Me),

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import LnArgs, LnBwdIn, PartialSum, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, LnBwdIn, PartialSum, OuterJob, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -287,7 +287,7 @@ def layernorm_bwd_parts(M, D):
     return int(_lib.load().mst_layernorm_bwd_parts(M, D))
 
 
-PARTIAL_SUM_MAX_JOBS = 24
+PARTIAL_SUM_MAX_JOBS = 20
 
 
 def partial_sum_job(src, n_parts, dst, scale=1.0, col_off=0, length=None):
@@ -302,7 +302,7 @@ def partial_sum_job(src, n_parts, dst, scale=1.0, col_off=0, length=None):
 
 
 def partial_sums(jobs):
-    """mst_partial_sums: every job's parts added in index order, 24 jobs per launch"""
+    """mst_partial_sums: every job's parts added in index order, 20 jobs per launch"""
     for i in range(0, len(jobs), PARTIAL_SUM_MAX_JOBS):
         chunk = jobs[i:i + PARTIAL_SUM_MAX_JOBS]
         call("mst_partial_sums", (PartialSum * len(chunk))(*chunk), len(chunk), stream())
@@ -326,27 +326,51 @@ def wgrad_problem(A, B, dW, db=None, M=None, N=None, K=None, scale=1.0, a_remap=
 
 
 WGRAD_MAX_PROBLEMS = 16
+OUTER_MAX_JOBS = 2
 
 
-def gemm_wgrad_batch(problems, scratch=None, sums=None):
+def outer_job(L, R, out, obias=None):
+    """out[J, I] += L[B, J]^T R[B, I], obias[J] += sum_b L[b, :] (mst_outer_job): L fp32 contiguous, R a [B, I] row view (fp32 or
+    the activation type) with any row stride, out / obias fp32 contiguous"""
+    q = OuterJob()
+    assert L.dtype == torch.float32 and L.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous() and R.stride(1) == 1
+    q.L, q.R, q.r_stride = ptr(L), ptr(R), R.stride(0)
+    q.r_dtype = 2 if R.dtype == torch.float32 else dt(R)
+    q.B, q.J, q.I = L.shape[0], L.shape[1], R.shape[1]
+    assert out.numel() == q.J * q.I and R.shape[0] == q.B and (obias is None or obias.numel() == q.J)
+    q.out, q.obias = ptr(out), ptr(obias)
+    return q
+
+
+def outer_jobs(jobs):
+    for i in range(0, len(jobs), OUTER_MAX_JOBS):
+        chunk = jobs[i:i + OUTER_MAX_JOBS]
+        call("mst_outer_jobs", (OuterJob * len(chunk))(*chunk), len(chunk), stream())
+
+
+def gemm_wgrad_batch(problems, scratch=None, sums=None, outers=None):
     """dW_i[N,K] += A_i^T @ B_i for a list of problems, 16 per launch. scratch: optional fp32 work buffer for the
-    atomic-free two-pass reduction of big batches (mst_gemm_wgrad_batch_ws). sums: column-sum jobs (partial_sum_job)
-    to execute along with the weight gradients (mst_gemm_wgrad_batch_sums)."""
-    sums = list(sums or [])
+    atomic-free two-pass reduction of big batches (mst_gemm_wgrad_batch_ws). sums: column-sum jobs (partial_sum_job),
+    outers: batch outer products (outer_job), to execute along with the weight gradients (mst_gemm_wgrad_batch_flush)."""
+    sums, outers = list(sums or []), list(outers or [])
     for i in range(0, len(problems), WGRAD_MAX_PROBLEMS):
         chunk = problems[i:i + WGRAD_MAX_PROBLEMS]
         arr = (WgradArgs * len(chunk))(*chunk)
-        if sums and i + WGRAD_MAX_PROBLEMS >= len(problems):  # the last launch takes (the first 24 of) the sums along
+        if (sums or outers) and i + WGRAD_MAX_PROBLEMS >= len(problems):  # the last launch takes (the first 20 of) the sums along
             take, sums = sums[:PARTIAL_SUM_MAX_JOBS], sums[PARTIAL_SUM_MAX_JOBS:]
-            call("mst_gemm_wgrad_batch_sums", arr, len(chunk), ptr(scratch),
+            tko, outers = outers[:OUTER_MAX_JOBS], outers[OUTER_MAX_JOBS:]
+            call("mst_gemm_wgrad_batch_flush", arr, len(chunk), ptr(scratch),
                  (scratch.numel() * scratch.element_size() if scratch is not None else 0),
-                 (PartialSum * len(take))(*take), len(take), stream())
+                 (PartialSum * len(take))(*take) if take else None, len(take),
+                 (OuterJob * len(tko))(*tko) if tko else None, len(tko), stream())
         elif scratch is None:
             call("mst_gemm_wgrad_batch", arr, len(chunk), stream())
         else:
             call("mst_gemm_wgrad_batch_ws", arr, len(chunk), ptr(scratch), scratch.numel() * scratch.element_size(), stream())
     if sums:
         partial_sums(sums)
+    if outers:
+        outer_jobs(outers)
 
 
 def gemm_wgrad(A, B, dW, db=None, **kw):
@@ -438,6 +462,23 @@ def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d,
          ptr(classes), ptr(mu), ptr(sigma), ptr(z), ptr(d_dec_in3), d_dec_in3.stride(0), alpha_d, kl_weight, gscale,
          enc_scale, ptr(dWl), ptr(dbl), ptr(dWh), ptr(dbh), ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3), d_enc_out3.stride(0),
          ptr(scratch), stream())
+
+
+def latent_bwd_vec(Wl, eps, Wh, classes, mu, sigma, d_dec_in3, alpha_d, kl_weight, gscale, dcls_d, d_enc_out3, scratch, enc_scale=1.0):
+    """latent_bwd's first launch with the decoder class table's gradient folded in (mst_latent_bwd_vec); the other parameter
+    gradients are latent_outer_jobs(...) of the caller's weight-gradient flush"""
+    B, De, Z, Dd = d_dec_in3.shape[0], Wl.shape[1], Wh.shape[1], Wh.shape[0]
+    call("mst_latent_bwd_vec", dt(d_dec_in3), B, De, Z, Dd, ptr(Wl), ptr(eps), ptr(Wh), ptr(classes), ptr(mu), ptr(sigma),
+         ptr(d_dec_in3), d_dec_in3.stride(0), alpha_d, kl_weight, gscale, enc_scale, ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3),
+         d_enc_out3.stride(0), ptr(scratch), stream())
+
+
+def latent_outer_jobs(scratch, enc_out3, z, dWl, dbl, dWh, dbh):
+    """the two outer products latent_bwd_vec leaves to the flush: dWl += dlat^T enc_out[:, 0], dWh += t^T z (and the biases)"""
+    B, Dd, Z2 = enc_out3.shape[0], dWh.shape[0], dWl.shape[0]
+    t = scratch[: B * Dd].view(B, Dd)
+    dlat = scratch[B * Dd: B * (Dd + Z2)].view(B, Z2)
+    return [outer_job(dlat, enc_out3[:, 0, :], dWl, dbl), outer_job(t, z, dWh, dbh)]
 
 
 def reparam_kl_fwd(mu, sigma, eps, z, kl):

@@ -1070,6 +1070,30 @@ def test_latent_fwd_bwd(gpu):
         close(got, ref, 1e-4, 1e-4 * max(1.0, ref.abs().max().item()), name)
     close(denc[:, 0], h0.grad, 1e-2, 1e-2 * h0.grad.abs().max().item(), "d enc row 0")
 
+    # the deferred form (mst_latent_bwd_vec + two mst_outer_job): identical arithmetic, (a) as one mst_outer_jobs launch,
+    # (b) as extra workgroups of a weight-gradient flush that has a reduction pass, (c) behind a flush that has none
+    M, N, K = 1024, 256, 256  # a problem of the whole-step tile form (two-pass reduction through the scratch buffer)
+    A, Bm = rnd((M, N), gpu, seed=69), rnd((M, K), gpu, seed=70)
+    for mode in ("own launch", "reduction pass", "no reduction pass"):
+        g = [torch.zeros_like(t) for t in (Wl, bl, Wh, bh, cls_d)]
+        denc2 = torch.zeros(B, S, De, dtype=BF, device=gpu)
+        scratch2 = torch.zeros(B * (Dd + 2 * Z), device=gpu)
+        o.latent_bwd_vec(Wl, eps, Wh, classes, mu, sigma, g0, alpha_d, beta, 1.0, g[4], denc2, scratch2)
+        jobs = o.latent_outer_jobs(scratch2, enc, z, g[0], g[1], g[2], g[3])
+        dW = torch.zeros(N, K, device=gpu)
+        if mode == "own launch":
+            o.outer_jobs(jobs)
+        else:
+            ws = torch.zeros(16 * 1024 * 1024, device=gpu) if mode == "reduction pass" else None
+            o.gemm_wgrad_batch([o.wgrad_problem(A, Bm, dW)], scratch=ws, outers=jobs)
+        torch.cuda.synchronize()
+        assert torch.equal(scratch2, scratch) and torch.equal(denc2, denc), mode
+        for got, want, name in zip(g[:4], (dWl, dbl, dWh, dbh), ("dWl", "dbl", "dWh", "dbh")):
+            assert torch.equal(got, want), f"{name} ({mode})"
+        close(g[4], dcls, 1e-6, 1e-6, f"dcls ({mode})")  # (atomics: the order of the adds is free)
+        if mode != "own launch":
+            close(dW, A.float().t() @ Bm.float(), 1e-3, 1e-3 * math.sqrt(M), f"the flush's own problem ({mode})")
+
 
 def test_reparam_kl_known_answers(gpu):
     o = ops()
