@@ -126,16 +126,24 @@ def cpu_baseline(c, dropout, budget_s=20.0):
                       f"(not MXNet), dropout {dropout}, {dt * 1e3:.0f} ms/step"}
 
 
-def time_launch(o, fn, iters):
+def time_launch(o, fn, iters, reps=5):
+    """average duration (ms) of one launch of `fn`, HIP events on the launch stream around a captured graph of `iters` back-to-back
+    launches — as the step itself runs them —, median of `reps` replays: eager launches measured the host as well (one stall of
+    the Python thread between two launches once put 1.9 ms on a 0.05 ms kernel)"""
     fn()
     torch.cuda.synchronize()
-    e0, e1 = o.Event(), o.Event()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.sync()
-    return e0.elapsed_ms(e1) / iters
+    g = o.Graph().capture(lambda: [fn() for _ in range(iters)])
+    g.launch()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        e0, e1 = o.Event(), o.Event()
+        e0.record()
+        g.launch()
+        e1.record()
+        e1.sync()
+        times.append(e0.elapsed_ms(e1) / iters)
+    return sorted(times)[len(times) // 2]
 
 
 def kernel_families(plan, o, iters=30):
