@@ -601,6 +601,19 @@ int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double b
                    const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se, int32_t add_e,
                    uint8_t* mask_d, int64_t Sd, int32_t add_d,
                    void* zero_a, int64_t zero_a_bytes, void* zero_b, int64_t zero_b_bytes, mst_stream_t stream);
+/* the same, arguments in a struct */
+typedef struct mst_step_begin_args {
+  uint64_t* rng_state; int32_t* adam_state; double lr, beta1, beta2;
+  float* eps_out; int64_t n_eps; uint32_t eps_site; int64_t eps_index0;
+  const int32_t* lens; int64_t B; uint8_t* mask_e; int64_t Se; int32_t add_e; uint8_t* mask_d; int64_t Sd; int32_t add_d;
+  void* zero_a; int64_t zero_a_bytes; void* zero_b; int64_t zero_b_bytes;
+} mst_step_begin_args;
+int mst_step_begin_v(const mst_step_begin_args* args, mst_stream_t stream);
+/* mst_step_begin and mst_gemm_nt_pair in ONE launch: nothing in the piano-roll ends' embedding GEMMs (the first arithmetic of the
+ * step) reads what the bookkeeping writes, so its workgroups ride in front of the tiles of that launch. Where mst_gemm_nt_pair
+ * would fall back to two launches this is exactly mst_step_begin_v(begin) followed by mst_gemm_nt_pair(args0, args1). */
+int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm_args* args1, const mst_step_begin_args* begin,
+                           mst_stream_t stream);
 /* eps ~ N(0,1) (replaces mx.nd.random_normal, model.py:292): Box-Muller over the counter hash;
  * effective seed = seed ^ (seed_ptr ? *seed_ptr : 0) */
 int mst_randn(int64_t n, float* out, uint64_t seed, const uint64_t* seed_ptr, uint32_t site, mst_stream_t stream);

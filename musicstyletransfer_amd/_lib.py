@@ -111,6 +111,15 @@ class PartialSum(C.Structure):
     ]
 
 
+class StepBeginArgs(C.Structure):
+    _fields_ = [
+        ("rng_state", vp), ("adam_state", vp), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+        ("eps_out", vp), ("n_eps", c_i64), ("eps_site", c_u32), ("eps_index0", c_i64),
+        ("lens", vp), ("B", c_i64), ("mask_e", vp), ("Se", c_i64), ("add_e", c_i32), ("mask_d", vp), ("Sd", c_i64), ("add_d", c_i32),
+        ("zero_a", vp), ("zero_a_bytes", c_i64), ("zero_b", vp), ("zero_b_bytes", c_i64),
+    ]
+
+
 class OuterJob(C.Structure):
     _fields_ = [
         ("L", vp), ("R", vp), ("r_dtype", c_i32), ("r_stride", c_i64),
@@ -150,6 +159,8 @@ SIGNATURES = {
     "mst_event_destroy": (C.c_int, [vp]),
     "mst_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "mst_gemm_nt_pair": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
+    "mst_gemm_nt_pair_begin": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(StepBeginArgs), vp]),
+    "mst_step_begin_v": (C.c_int, [C.POINTER(StepBeginArgs), vp]),
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
     "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <type_traits>
 #include "common.hpp"
+#include "step_begin.hpp"
 
 namespace mst {
 
@@ -514,19 +515,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
 // Two GEMMs of one kernel form in ONE launch (mst_gemm_nt_pair): the first `tiles0` workgroups are the first problem's tiles,
 // the rest the second's. The piano-roll ends' two embedding GEMMs (model.py:81-91 and :241-245: the same uint8 frames against the
 // encoder's and the decoder's table) — small launches whose cost is mostly the launch.
+// n_begin > 0 (mst_gemm_nt_pair_begin): the first n_begin workgroups of the grid are the step's bookkeeping (step_begin.hpp).
 template <typename T, int BM, int BN, int WGM, int WGN, int BK, int PATH>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_args a0, mst_gemm_args a1, int tiles0) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_args a0, mst_gemm_args a1, int tiles0, StepBegin sb, int n_begin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < n_begin) {
+    step_begin_wg<WGM * WGN * 64>(sb, (int)blockIdx.x, n_begin);
+    return;
+  }
   f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
   int64_t m0, n0;
   float bias_pre[8];
+  const int64_t tile = (int64_t)blockIdx.x - n_begin;  // (n_begin is a multiple of 8: a tile keeps its XCD)
   // (two straight-line copies of the tile, each reading its own argument block from the kernel arguments)
-  if ((int)blockIdx.x < tiles0) {
-    gemm_bias_preload<BM, BN>(a0, bias_pre, blockIdx.x);
-    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a0, smem, acc, m0, n0, blockIdx.x);
+  if (tile < tiles0) {
+    gemm_bias_preload<BM, BN>(a0, bias_pre, tile);
+    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a0, smem, acc, m0, n0, tile);
     gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a0, smem, acc, m0, n0, bias_pre);
   } else {
-    const int64_t bid = (int64_t)blockIdx.x - tiles0;
+    const int64_t bid = tile - tiles0;
     gemm_bias_preload<BM, BN>(a1, bias_pre, bid);
     gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a1, smem, acc, m0, n0, bid);
     gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a1, smem, acc, m0, n0, bias_pre);
@@ -1760,6 +1767,11 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
 }
 
 extern "C" int mst_gemm_nt_pair(const mst_gemm_args* args0, const mst_gemm_args* args1, mst_stream_t stream) {
+  return mst_gemm_nt_pair_begin(args0, args1, nullptr, stream);
+}
+
+extern "C" int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm_args* args1, const mst_step_begin_args* begin,
+                                      mst_stream_t stream) {
   MST_CHECK_ARG(args0 != nullptr && args1 != nullptr, "mst_gemm_nt_pair: null args");
   const mst_gemm_args &a0 = *args0, &a1 = *args1;
   // one launch for two uint8-A problems of the fast row-op form (what the embedding GEMMs are); anything else is two launches
@@ -1772,15 +1784,25 @@ extern "C" int mst_gemm_nt_pair(const mst_gemm_args* args0, const mst_gemm_args*
   };
   static const bool off = getenv("MST_GEMM_PAIR") && getenv("MST_GEMM_PAIR")[0] == '0';
   if (off || a0.dtype != a1.dtype || !plain(a0) || !plain(a1)) {
-    const int rc = mst_gemm_nt(args0, stream);
+    int rc = begin ? mst_step_begin_v(begin, stream) : MST_OK;
+    if (rc == MST_OK) rc = mst_gemm_nt(args0, stream);
     return rc != MST_OK ? rc : mst_gemm_nt(args1, stream);
+  }
+  StepBegin sb = {};
+  int n_begin = 0;
+  if (begin) {
+    int64_t grid = 0;
+    const int rc = pack_step_begin(*begin, sb, &grid);
+    if (rc) return rc;
+    n_begin = (int)((grid + 7) / 8 * 8);
   }
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a0.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     const int tiles0 = (int)((a0.M / 64) * (a0.N / 64)), tiles1 = (int)((a1.M / 64) * (a1.N / 64));
     const size_t lds = (size_t)2 * (64 + 64) * 64 * 2;  // K-loop stages; the 64 x 68 fp32 epilogue staging is smaller
-    hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(tiles0 + tiles1)), dim3(256), lds, s, a0, a1, tiles0);
+    hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(n_begin + tiles0 + tiles1)), dim3(256), lds, s, a0, a1,
+                       tiles0, sb, n_begin);
     MST_CHECK_LAUNCH("gemm_nt_pair_kernel");
     return MST_OK;
   });

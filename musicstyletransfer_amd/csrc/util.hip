@@ -7,6 +7,7 @@
 #include <math.h>
 #include "common.hpp"
 #include "partial_sums.hpp"
+#include "step_begin.hpp"
 
 namespace mst {
 
@@ -38,86 +39,7 @@ __global__ __launch_bounds__(256) void randn_kernel(int64_t n, float* __restrict
   }
 }
 
-// One launch at the top of every step (each kernel in the captured graph costs ~4.7 us however small):
-// advances the RNG state, advances Adam's step counter and bias-corrected learning rate, draws eps, and writes the
-// two padding masks from the sequence lengths (SequenceMask, model.py:246-247; the encoder's for the piano-roll ends).
-constexpr int SB_THREADS = 1024;
-__device__ __forceinline__ uint64_t step_seed(uint64_t base, uint64_t step) {
-  uint64_t x = base ^ (step * 0x9E3779B97F4A7C15ull);
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27; x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return x;
-}
-
-// Grid of several workgroups (the single-workgroup form took 29 us of the step). Every workgroup derives the new
-// seed itself from (base seed, step counter + 1); the state is written back by the workgroup that ARRIVES LAST at
-// rng_state[3], i.e. after every other workgroup has read the old counter.
-__global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1,
-                                                         double beta2, float* eps_out, int64_t n_eps, uint32_t eps_site, int64_t eps_index0,
-                                                         const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
-                                                         int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d,
-                                                         u32x4* zero_a, int64_t n16_a, u32x4* zero_b, int64_t n16_b, int n_state) {
-  // workgroups [0, n_state) do the bookkeeping (and take part in the arrival count); the rest of the grid only helps
-  // clearing the two buffers — the 7.5 MB gradient bucket is most of this launch's bytes and has no business waiting on
-  // 64 workgroups' worth of store bandwidth
-  const u32x4 z4 = {0u, 0u, 0u, 0u};
-  {
-    const int64_t zid = (int64_t)blockIdx.x * SB_THREADS + threadIdx.x, zsz = (int64_t)gridDim.x * SB_THREADS;
-    for (int64_t i = zid; i < n16_a; i += zsz) zero_a[i] = z4;
-    for (int64_t i = zid; i < n16_b; i += zsz) zero_b[i] = z4;
-  }
-  if ((int)blockIdx.x >= n_state) return;
-  const int64_t gid = (int64_t)blockIdx.x * SB_THREADS + threadIdx.x, gsz = (int64_t)n_state * SB_THREADS;
-  uint64_t step = 0, s = 0;
-  if (rng_state) {
-    step = rng_state[1] + 1;
-    s = step_seed(rng_state[2], step);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && adam_state) {  // nobody else in this launch touches the Adam state
-    const int t = adam_state[0] + 1;
-    adam_state[0] = t;
-    const double c1 = 1.0 - pow(beta1, (double)t), c2 = 1.0 - pow(beta2, (double)t);  // double, like the reference
-    reinterpret_cast<float*>(adam_state)[1] = (float)(lr * sqrt(c2) / c1);
-  }
-  if (eps_out) {
-    for (int64_t i = gid; i < (n_eps + 1) / 2; i += gsz) {
-      const uint32_t a = dropout_hash(s, eps_site, (uint64_t)(eps_index0 + 2 * i));
-      const uint32_t b = dropout_hash(s, eps_site, (uint64_t)(eps_index0 + 2 * i + 1));
-      const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
-      const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
-      const float r = sqrtf(-2.0f * logf(u1));
-      float sn, cs;
-      sincosf(6.283185307179586f * u2, &sn, &cs);
-      eps_out[2 * i] = r * cs;
-      if (2 * i + 1 < n_eps) eps_out[2 * i + 1] = r * sn;
-    }
-  }
-  // (32-bit quotients: B * S < 2^31 is checked on the host; each thread handles about one element of each mask, and the
-  // 64-bit division it used to start with was several hundred instructions)
-  if (mask_e)
-    for (int64_t i = gid; i < B * Se; i += gsz) {
-      const uint32_t q = (uint32_t)i / (uint32_t)Se, r = (uint32_t)i - q * (uint32_t)Se;
-      mask_e[i] = ((int64_t)r < (int64_t)lens[q] + add_e) ? 1 : 0;
-    }
-  if (mask_d)
-    for (int64_t i = gid; i < B * Sd; i += gsz) {
-      const uint32_t q = (uint32_t)i / (uint32_t)Sd, r = (uint32_t)i - q * (uint32_t)Sd;
-      mask_d[i] = ((int64_t)r < (int64_t)lens[q] + add_d) ? 1 : 0;
-    }
-  if (rng_state) {
-    __syncthreads();  // every thread of this workgroup has read the old counter
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(rng_state + 3), 1ull);
-      if (arrived == (unsigned long long)n_state - 1) {
-        rng_state[3] = 0;
-        rng_state[1] = step;
-        rng_state[0] = s;
-      }
-    }
-  }
-}
+__global__ __launch_bounds__(SB_THREADS) void step_begin_kernel(StepBegin q) { step_begin_wg<SB_THREADS>(q, (int)blockIdx.x, (int)gridDim.x); }
 
 __global__ __launch_bounds__(256) void partial_sums_kernel(PartialSumBatch b) {
   __shared__ f32x4 red[16][16];
@@ -128,36 +50,24 @@ __global__ __launch_bounds__(256) void partial_sums_kernel(PartialSumBatch b) {
 
 using namespace mst;
 
+extern "C" int mst_step_begin_v(const mst_step_begin_args* args, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr, "mst_step_begin: null args");
+  StepBegin q;
+  int64_t grid = 0;
+  int rc = pack_step_begin(*args, q, &grid);
+  if (rc) return rc;
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(SB_THREADS), 0, (hipStream_t)stream, q);
+  MST_CHECK_LAUNCH("step_begin_kernel");
+  return MST_OK;
+}
+
 extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double lr, double beta1, double beta2, float* eps_out,
                               int64_t n_eps, uint32_t eps_site, int64_t eps_index0, const int32_t* lens, int64_t B, uint8_t* mask_e, int64_t Se,
                               int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, void* zero_a, int64_t zero_a_bytes,
                               void* zero_b, int64_t zero_b_bytes, mst_stream_t stream) {
-  MST_CHECK_ARG((!zero_a || ((uintptr_t)zero_a % 16 == 0 && zero_a_bytes % 16 == 0)) &&
-                    (!zero_b || ((uintptr_t)zero_b % 16 == 0 && zero_b_bytes % 16 == 0)),
-                "mst_step_begin: zero buffers must be 16-byte aligned with sizes that are multiples of 16");
-  MST_CHECK_ARG(!eps_out || (rng_state && n_eps > 0), "mst_step_begin: eps needs the rng state");
-  MST_CHECK_ARG(eps_index0 >= 0 && eps_index0 % 2 == 0, "mst_step_begin: eps_index0 must be even (Box-Muller pairs)");
-  MST_CHECK_ARG((!mask_e && !mask_d) || (lens && B > 0), "mst_step_begin: masks need the lengths");
-  MST_CHECK_ARG((!mask_e || (Se > 0 && B * Se < (1ll << 31))) && (!mask_d || (Sd > 0 && B * Sd < (1ll << 31))), "mst_step_begin: B * S must stay below 2^31");
-  int64_t work = n_eps / 2;
-  if (mask_e && B * Se > work) work = B * Se;
-  if (mask_d && B * Sd > work) work = B * Sd;
-  const int64_t n16_a = zero_a ? zero_a_bytes / 16 : 0, n16_b = zero_b ? zero_b_bytes / 16 : 0;
-  if (n16_a > work) work = n16_a;
-  if (n16_b > work) work = n16_b;
-  // few, fat workgroups: every workgroup ends with one atomic on the SAME arrival counter, and same-address atomics
-  // are serialised at ~40 ns each (512 workgroups measured 20 us for this launch)
-  int64_t n_state = cdiv(work > 0 ? work : 1, SB_THREADS * 4);
-  if (n_state > 64) n_state = 64;
-  // (+ workgroups that only clear: 16 KiB of the zero lists each, one per CU at most)
-  int64_t grid = cdiv(n16_a + n16_b, SB_THREADS);
-  if (grid > 256) grid = 256;
-  if (grid < n_state) grid = n_state;
-  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(SB_THREADS), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2,
-                     eps_out, n_eps, eps_site, eps_index0, lens, B, mask_e, Se, add_e, mask_d, Sd, add_d, (u32x4*)zero_a, n16_a, (u32x4*)zero_b,
-                     n16_b, (int)n_state);
-  MST_CHECK_LAUNCH("step_begin_kernel");
-  return MST_OK;
+  const mst_step_begin_args a = {rng_state, adam_state, lr, beta1, beta2, eps_out, n_eps, eps_site, eps_index0, lens, B, mask_e, Se,
+                                 add_e, mask_d, Sd, add_d, zero_a, zero_a_bytes, zero_b, zero_b_bytes};
+  return mst_step_begin_v(&a, stream);
 }
 
 extern "C" int mst_partial_sums(const mst_partial_sum* jobs, int n, mst_stream_t stream) {

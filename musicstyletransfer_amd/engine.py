@@ -640,12 +640,16 @@ class StepPlan:
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
         # one bookkeeping launch: RNG seed of this step, Adam's step count / lr_t, eps, both padding masks
         need_rng = cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps
-        o.step_begin(rng_state=self.rng_state if need_rng else None,
+        begin = dict(rng_state=self.rng_state if need_rng else None,
                      adam_state=st.step_state if self._tick_adam else None, lr=self.lr, beta1=self.opt["beta1"],
                      beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None,
                      eps_index0=self.sample_offset * cfg.latent_dim, lens=self.seq_lens,
                      mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
                      zero_a=self._recon_buf, zero_b=st.g if self._tick_adam else None)
+        # (piano-roll ends: nothing in the embedding GEMMs reads what the bookkeeping writes — it rides on their launch)
+        ride = cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0"
+        if not ride:
+            o.step_begin(**begin)
         # ---- encoder input (model.py:81-91, transformer.py:270)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("encoder.embedding.weight"), self.pos_e, self.x0_e.view(B, Se, -1), 0, sq_e,
@@ -655,7 +659,8 @@ class StepPlan:
             o.gemm_nt_pair(dict(A=self.roll, B=st.t("encoder.embedding.weight"), C_out=self.x0_e, N=De, alpha=sq_e,
                                 grpadd=st.p("encoder.class2hid.weight"), grp_index=self.classes, rowadd=self.pos_e, rowadd_period=T),
                            dict(A=self.roll, B=st.t("decoder.embedding.weight"), C_out=self.x0_d, M=B * T, N=Dd, alpha=sq_d,
-                                rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1)))
+                                rowadd=self.pos_d[1:], rowadd_period=T, c_remap=(T, Sd, 1)),
+                           begin=begin if ride else None)
         x = self.x0_e
         for i, L in enumerate(self.enc):
             x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, self._site_e(i))

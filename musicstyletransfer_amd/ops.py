@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import LnArgs, LnBwdIn, PartialSum, OuterJob, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
+from ._lib import LnArgs, LnBwdIn, PartialSum, OuterJob, StepBeginArgs, StepMetrics, ACT_NONE, ACT_RELU, MST_BF16, MST_F16, GemmArgs, WgradArgs, call  # noqa: F401
 
 _DT = {torch.bfloat16: MST_BF16, torch.float16: MST_F16}
 
@@ -84,9 +84,14 @@ def gemm_nt(A, B, C_out, **kw):
     call("mst_gemm_nt", C.byref(_gemm_args(A, B, C_out, **kw)), stream())
 
 
-def gemm_nt_pair(first, second):
-    """two gemm_nt problems, each a dict(A=, B=, C_out=, **kw), in one launch where their form allows (mst_gemm_nt_pair)"""
-    call("mst_gemm_nt_pair", C.byref(_gemm_args(**first)), C.byref(_gemm_args(**second)), stream())
+def gemm_nt_pair(first, second, begin=None):
+    """two gemm_nt problems, each a dict(A=, B=, C_out=, **kw), in one launch where their form allows (mst_gemm_nt_pair);
+    begin: keyword arguments of step_begin — the step's bookkeeping rides on the same launch (mst_gemm_nt_pair_begin)"""
+    if begin is None:
+        call("mst_gemm_nt_pair", C.byref(_gemm_args(**first)), C.byref(_gemm_args(**second)), stream())
+    else:
+        call("mst_gemm_nt_pair_begin", C.byref(_gemm_args(**first)), C.byref(_gemm_args(**second)), C.byref(_step_begin_args(**begin)),
+             stream())
 
 
 def can_row_tail(B, D):
@@ -574,14 +579,22 @@ def randn(out, seed=0, seed_ptr=None, site=0):
     call("mst_randn", out.numel(), ptr(out), seed, ptr(seed_ptr), site, stream())
 
 
-def step_begin(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, eps_index0=0, lens=None,
-               mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None):
-    B = lens.shape[0] if lens is not None else 0
+def _step_begin_args(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, eps_index0=0,
+                     lens=None, mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None):
+    q = StepBeginArgs()
     nbytes = lambda t: t.numel() * t.element_size() if t is not None else 0
-    call("mst_step_begin", ptr(rng_state), ptr(adam_state), lr, beta1, beta2, ptr(eps_out),
-         (eps_out.numel() if eps_out is not None else 0), eps_site, eps_index0, ptr(lens), B, ptr(mask_e),
-         (mask_e.shape[1] if mask_e is not None else 0), add_e, ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d,
-         ptr(zero_a), nbytes(zero_a), ptr(zero_b), nbytes(zero_b), stream())
+    q.rng_state, q.adam_state, q.lr, q.beta1, q.beta2 = ptr(rng_state), ptr(adam_state), lr, beta1, beta2
+    q.eps_out, q.n_eps, q.eps_site, q.eps_index0 = ptr(eps_out), (eps_out.numel() if eps_out is not None else 0), eps_site, eps_index0
+    q.lens, q.B = ptr(lens), (lens.shape[0] if lens is not None else 0)
+    q.mask_e, q.Se, q.add_e = ptr(mask_e), (mask_e.shape[1] if mask_e is not None else 0), add_e
+    q.mask_d, q.Sd, q.add_d = ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d
+    q.zero_a, q.zero_a_bytes, q.zero_b, q.zero_b_bytes = ptr(zero_a), nbytes(zero_a), ptr(zero_b), nbytes(zero_b)
+    return q
+
+
+def step_begin(**kw):
+    """mst_step_begin (keyword arguments: _step_begin_args)"""
+    call("mst_step_begin_v", C.byref(_step_begin_args(**kw)), stream())
 
 
 def selftest():

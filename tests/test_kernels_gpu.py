@@ -1374,3 +1374,42 @@ def test_step_begin_matches_the_separate_kernels(gpu):
         want_lr = 1e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
         assert abs(adam.view(torch.float32)[1].item() - want_lr) < 1e-6 * want_lr + 1e-12
     assert abs(float(eps.mean())) < 0.06 and abs(float(eps.std()) - 1) < 0.05
+
+
+def test_step_begin_riding_on_the_embedding_launch_equals_its_own_launch(gpu):
+    """mst_gemm_nt_pair_begin: the step's bookkeeping as the first workgroups of the two embedding GEMMs' launch (256 threads each
+    instead of 1024) — RNG state, Adam tick, eps, both masks and the cleared buffers identical to mst_step_begin, the GEMM outputs
+    identical to mst_gemm_nt_pair; also where the pair falls back to separate launches (ragged M)"""
+    o = ops()
+    g = torch.Generator().manual_seed(23)
+    for B, T, P, De, Dd in ((64, 256, 128, 256, 128), (3, 50, 40, 64, 64)):
+        M, Z = B * T, 64
+        frames = (torch.rand(M, P, generator=g) < 0.05).to(torch.uint8).to(gpu)
+        te, td = rnd((De, P), gpu, 0.1, BF, seed=24), rnd((Dd, P), gpu, 0.1, BF, seed=25)
+        pos_e, pos_d = rnd((T, De), gpu, 1.0, torch.float32, seed=26), rnd((T + 1, Dd), gpu, 1.0, torch.float32, seed=27)
+        lens = torch.tensor([(i * 37) % T + 1 for i in range(B)], dtype=torch.int32, device=gpu)
+        results = []
+        for ride in (True, False):
+            state = torch.tensor([0, 5, 1234567, 0], dtype=torch.int64, device=gpu)
+            adam = torch.tensor([5, 0], dtype=torch.int32, device=gpu)
+            eps = torch.zeros(B, Z, device=gpu)
+            me = torch.full((B, T), 7, dtype=torch.uint8, device=gpu)
+            md = torch.full((B, T + 1), 7, dtype=torch.uint8, device=gpu)
+            za, zb = torch.full((1024 + 12,), 3.0, device=gpu), torch.full((300000,), 3.0, device=gpu)
+            xe = torch.zeros(M, De, dtype=BF, device=gpu)
+            xd = torch.zeros(B * (T + 1), Dd, dtype=BF, device=gpu)
+            begin = dict(rng_state=state, adam_state=adam, lr=1e-3, eps_out=eps, eps_site=99, eps_index0=128, lens=lens, mask_e=me,
+                         add_e=0, mask_d=md, add_d=1, zero_a=za, zero_b=zb)
+            first = dict(A=frames, B=te, C_out=xe, N=De, alpha=1.5, rowadd=pos_e, rowadd_period=T)
+            second = dict(A=frames, B=td, C_out=xd, M=M, N=Dd, alpha=0.5, rowadd=pos_d[1:], rowadd_period=T, c_remap=(T, T + 1, 1))
+            if ride:
+                o.gemm_nt_pair(first, second, begin=begin)
+            else:
+                o.step_begin(**begin)
+                o.gemm_nt_pair(first, second)
+            torch.cuda.synchronize()
+            results.append((state, adam, eps, me, md, za, zb, xe, xd))
+        for a_, b_, name in zip(results[0], results[1], ("rng state", "adam state", "eps", "mask_e", "mask_d", "zero_a", "zero_b", "x0_e", "x0_d")):
+            assert torch.equal(a_, b_), f"{name} (B={B})"
+        assert results[0][0][1].item() == 6 and results[0][0][3].item() == 0 and results[0][1][0].item() == 6
+        assert (results[0][5] == 0).all() and (results[0][6] == 0).all() and results[0][7].abs().sum() > 0
