@@ -8,6 +8,8 @@ import sys
 def timeline(path):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if "step_begin" in r["Kernel_Name"]]
+    if len(idx) < 3:  # the piano-roll ends: the bookkeeping rides on the step's first launch, the two embedding GEMMs
+        idx = [i for i, r in enumerate(rows) if "gemm_nt_pair_kernel" in r["Kernel_Name"]]
     acc = collections.defaultdict(list)
     n = idx[-1] - idx[-2]
     for a, b in zip(idx[10:-1], idx[11:]):
