@@ -7,7 +7,8 @@
 //   kl[b] = 0.5 * sum(sigma^2 + mu^2 - 1 - log(sigma^2))       loss.py:8-12   (no epsilon inside the log)
 //   dec_in[b,0,:] = alpha_d * (z · Wh^T + bh + cls_d[c_b]) + pos_d[0]   model.py:229-232,244; transformer.py:237
 // Backward: per-sample vectors in one kernel, then the parameter gradients as batch reductions
-// (no atomics: each output element is owned by one thread that loops over the batch).
+// (no atomics: each output element is owned by one thread that loops over the batch) — a second launch (mst_latent_bwd), or,
+// in the training step, two mst_outer_job that ride on the weight-gradient reduction pass (mst_latent_bwd_vec + outer_jobs.hpp).
 //
 // These are B x {De, 2Z, Dd} problems (64 x 256 x 128): far too small for MFMA tiles to matter;
 // they are kept in fp32 because the KL term's log(sigma^2) is the most precision-sensitive
