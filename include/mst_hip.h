@@ -169,6 +169,13 @@ typedef struct mst_ln_args {
 } mst_ln_args;
 
 int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream);
+/* mst_gemm_sigmoid_bce(args, bce) and mst_gemm_nt_ln(dgrad, ln) in ONE launch where `dgrad` is the output layer's input gradient
+ * (model.py:253-256 backward): A = the logit gradient `args` has just produced (dgrad->A == args->C), 128 pitches, row width 128,
+ * ln->mode 2 — the workgroup that holds a 64-row tile of logit gradients contracts it with W_out and runs the last decoder layer's
+ * LayerNorm backward on the result; the logit gradient is still stored (the weight-gradient launch reads it). Any other shape:
+ * exactly the two launches. */
+int mst_gemm_sigmoid_bce_dgrad_ln(const mst_gemm_args* args, const mst_bce_args* bce, const mst_gemm_args* dgrad,
+                                  const mst_ln_args* ln, mst_stream_t stream);
 int64_t mst_gemm_nt_ln_parts(int64_t M);
 
 /* The whole feed-forward block of a Transformer layer in one launch (transformer.py:38-40 with :152-158 or :194-200):

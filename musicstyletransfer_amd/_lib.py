@@ -162,6 +162,7 @@ SIGNATURES = {
     "mst_gemm_nt_pair_begin": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(StepBeginArgs), vp]),
     "mst_step_begin_v": (C.c_int, [C.POINTER(StepBeginArgs), vp]),
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
+    "mst_gemm_sigmoid_bce_dgrad_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
     "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),

@@ -366,7 +366,9 @@ __device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float 
 // accumulators in `acc`; on return every wave has passed the loop's last barrier, so `smem` is free to reuse.
 // AREMAP: the A row remap is compiled in (a 64-bit division per staged chunk of the prologue).
 // AU8: A holds uint8 elements (mst_gemm_args.a_u8): a chunk is an 8-byte load, widened when it is written to LDS.
-template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false>
+// A_IN_LDS: both K stages of the A tile already sit in the stage buffers (K == 2 * BK: stage t in buffer t, the layout store_tile
+// writes) — the operand was produced by this workgroup (gemm_bce_dgrad_ln_kernel); only B is loaded.
+template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false, bool A_IN_LDS = false>
 __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0,
                                               int64_t bid_in = -1) {
@@ -440,6 +442,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   auto load_tile = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
+      if constexpr (A_IN_LDS) continue;
       if constexpr (AU8) ra8[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x2*>(a_ptr[i] + k0) : u32x2{0u, 0u};
       else ra[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
     }
@@ -450,6 +453,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
+      if constexpr (A_IN_LDS) continue;
       if constexpr (AU8) ra[i] = expand_u8x8<T>(ra8[i]);
       if (BM * CHUNKS >= NT || tid < BM * CHUNKS) sA[buf * BM * CHUNKS + a_lds[i]] = ra[i];
     }
@@ -772,13 +776,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 // logit gradient (the backward pass's operand), optionally the probabilities (reconstruction output), and the sample's
 // loss sum — the arithmetic of sigmoid_bce_kernel on the logit rounded to the activation type, which is what the two-launch
 // form reads back. A tile holds rows of ONE sample (the host requires T % 64 == 0): one atomic per workgroup.
-template <typename T, int BN>
-__global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_args q) {
+// keepA (KEEP): the logit-gradient tile ALSO goes to LDS as the A operand of a GEMM that follows in the same launch, in
+// gemm_mainloop's stage layout (BK = 64: columns [64 s, 64 s + 64) in stage buffer s, 16-byte chunks XOR-swizzled by the row)
+template <typename T, int BN, bool KEEP>
+__device__ __forceinline__ void gemm_bce_tile(const mst_gemm_args& a, const mst_bce_args& q, unsigned char* smem, float* red, u32x4* keepA) {
   constexpr int BM = 64, WGM = 2, WGN = 4, NT = 512;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
   constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float red[NT / 64];
   f32x4 acc[TN][TM];
   int64_t m0, n0;
   float bias8[8];
@@ -842,6 +846,7 @@ __global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_
       gb.h[e] = f32_to_bits<T>(dbce * inv_n * q.gscale);
     }
     if (a.C) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + m * a.ldc + nc) = gb.u;
+    if constexpr (KEEP) keepA[(ch >> 3) * (BM * 8) + row * 8 + ((ch & 7) ^ (row & 7))] = gb.u;
     if (q.probs) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.probs) + m * q.ldp + nc) = pb.u;
     if (q.logits) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.logits) + m * q.ldl + nc) = xb.u;
   }
@@ -854,6 +859,53 @@ __global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_
     for (int i = 0; i < NT / 64; ++i) tot += red[i];
     atomicAdd(q.loss + b, tot * inv_n);
   }
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void gemm_bce_kernel(mst_gemm_args a, mst_bce_args q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[512 / 64];
+  gemm_bce_tile<T, BN, false>(a, q, smem, red, nullptr);
+}
+
+// mst_gemm_sigmoid_bce_dgrad_ln: the loss launch above followed IN THE SAME WORKGROUP by the first launch of the backward pass — the
+// output layer's input gradient d(dec_out) = dlogits W_out (K = the 128 pitches of the tile the workgroup has just produced) with the
+// last decoder layer's LayerNorm-3 backward in its epilogue (mst_gemm_nt_ln mode 2). The logit gradient still goes to HBM (the
+// weight-gradient launch reads it) but is not read back here, and a launch of the dependent chain disappears.
+// LDS: [0, 48 K) the first GEMM's stages, then its fp32 staging tile (33.8 K), later the LayerNorm epilogue's; [48 K, 64 K) the kept
+// logit-gradient tile (two 64 x 64 stages); [64 K, 96 K) the second GEMM's weight stages; then bias | gamma | beta.
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_bce_dgrad_ln_kernel(mst_gemm_args a, mst_bce_args q, mst_gemm_args g2, mst_ln_args l) {
+  constexpr int BM = 64, BN = 128, WGM = 2, WGN = 4;
+  constexpr size_t OFF2 = 48 * 1024, END2 = OFF2 + (size_t)2 * (BM + BN) * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[512 / 64];
+  float* sPar = reinterpret_cast<float*>(smem + END2);
+  for (int i = threadIdx.x; i < BN; i += 512) {  // (cold lines: requested now, read by the LayerNorm epilogue)
+    sPar[i] = g2.bias ? g2.bias[i] : 0.f;
+    sPar[BN + i] = l.gamma[i];
+    sPar[2 * BN + i] = 0.f;
+  }
+  gemm_bce_tile<T, BN, true>(a, q, smem, red, reinterpret_cast<u32x4*>(smem + OFF2));
+  __syncthreads();  // the kept tile is complete, the staging tile dead
+  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+  int64_t m0, n0;
+  gemm_mainloop<T, BM, BN, WGM, WGN, 64, true, false, true>(g2, smem + OFF2, acc, m0, n0);
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, 2>(g2, l, smem, acc, m0, nullptr, 0, nullptr, 0, sPar);
+}
+
+template <typename T>
+static int launch_gemm_bce_dgrad_ln(const mst_gemm_args& a, const mst_bce_args& q, const mst_gemm_args& g2, const mst_ln_args& l, hipStream_t s) {
+  const size_t lds = (size_t)48 * 1024 + (size_t)2 * (64 + 128) * 64 * 2 + (size_t)3 * 128 * 4;
+  static bool opted = false;
+  if (!opted) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bce_dgrad_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("gemm_bce_dgrad_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+    opted = true;
+  }
+  hipLaunchKernelGGL((gemm_bce_dgrad_ln_kernel<T>), dim3((unsigned)cdiv(a.M, 64)), dim3(512), lds, s, a, q, g2, l);
+  MST_CHECK_LAUNCH("gemm_bce_dgrad_ln_kernel");
+  return MST_OK;
 }
 
 template <typename T, int BN>
@@ -1660,10 +1712,7 @@ extern "C" int mst_ffn_ln_bwd(const mst_gemm_args* ff2_dgrad, const mst_gemm_arg
   return ffn_ln_impl("mst_ffn_ln_bwd", ff2_dgrad, ff1_dgrad, ln, 2, stream);
 }
 
-extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {
-  MST_CHECK_ARG(args != nullptr && ln != nullptr, "mst_gemm_nt_ln: null args");
-  const mst_gemm_args& a = *args;
-  const mst_ln_args& l = *ln;
+static int check_gemm_ln(const mst_gemm_args& a, const mst_ln_args& l) {
   int rc = check_gemm_common(a);
   if (rc) return rc;
   MST_CHECK_ARG(a.N == 256 || a.N == 128, "mst_gemm_nt_ln: the row width N must be 128 or 256 (got %lld): use mst_gemm_nt + "
@@ -1685,6 +1734,15 @@ extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, 
                   "mst_gemm_nt_ln: mask_mode 1 needs out");
     MST_CHECK_ARG(!a.self_resid, "mst_gemm_nt_ln: self_resid belongs to the forward form");
   }
+  return MST_OK;
+}
+
+extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && ln != nullptr, "mst_gemm_nt_ln: null args");
+  const mst_gemm_args& a = *args;
+  const mst_ln_args& l = *ln;
+  int rc = check_gemm_ln(a, l);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
@@ -1694,10 +1752,7 @@ extern "C" int mst_gemm_nt_ln(const mst_gemm_args* args, const mst_ln_args* ln, 
   });
 }
 
-extern "C" int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_args* bce, mst_stream_t stream) {
-  MST_CHECK_ARG(args != nullptr && bce != nullptr, "mst_gemm_sigmoid_bce: null args");
-  const mst_gemm_args& a = *args;
-  const mst_bce_args& q = *bce;
+static int check_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q) {
   MST_CHECK_ARG(a.M > 0 && a.K > 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.A && a.B,
                 "mst_gemm_sigmoid_bce: bad GEMM operands");
   MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0), "mst_gemm_sigmoid_bce: operands must be 16-byte aligned");
@@ -1710,11 +1765,44 @@ extern "C" int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_arg
   MST_CHECK_ARG(!a.C || (a.ldc % 8 == 0 && a.ldc >= a.N && (uintptr_t)a.C % 16 == 0), "mst_gemm_sigmoid_bce: bad dlogits layout");
   MST_CHECK_ARG(!q.probs || (q.ldp % 8 == 0 && q.ldp >= a.N && (uintptr_t)q.probs % 16 == 0), "mst_gemm_sigmoid_bce: bad probs layout");
   MST_CHECK_ARG(!q.logits || (q.ldl % 8 == 0 && q.ldl >= a.N && (uintptr_t)q.logits % 16 == 0), "mst_gemm_sigmoid_bce: bad logits layout");
+  return MST_OK;
+}
+
+extern "C" int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_args* bce, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && bce != nullptr, "mst_gemm_sigmoid_bce: null args");
+  const mst_gemm_args& a = *args;
+  const mst_bce_args& q = *bce;
+  int rc = check_gemm_bce(a, q);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     if (a.N == 256) return launch_gemm_bce<T, 256>(a, q, s);
     return launch_gemm_bce<T, 128>(a, q, s);
+  });
+}
+
+extern "C" int mst_gemm_sigmoid_bce_dgrad_ln(const mst_gemm_args* args, const mst_bce_args* bce, const mst_gemm_args* dgrad,
+                                             const mst_ln_args* ln, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && bce != nullptr && dgrad != nullptr && ln != nullptr, "mst_gemm_sigmoid_bce_dgrad_ln: null args");
+  const mst_gemm_args &a = *args, &g2 = *dgrad;
+  const mst_bce_args& q = *bce;
+  const mst_ln_args& l = *ln;
+  int rc = check_gemm_bce(a, q);
+  if (rc == MST_OK) rc = check_gemm_ln(g2, l);
+  if (rc) return rc;
+  // one launch: 128 pitches, width 128, whole 64-row tiles, and the second GEMM's A operand IS the first one's logit gradient
+  static const bool off = getenv("MST_BCE_DGRAD") && getenv("MST_BCE_DGRAD")[0] == '0';
+  const bool one = !off && a.N == 128 && g2.N == 128 && g2.K == 128 && g2.M == a.M && a.M % 64 == 0 && l.mode == 2 && a.C && g2.A == a.C &&
+                   g2.lda == a.ldc && g2.dtype == a.dtype && g2.a_rows_per_group <= 0 && !g2.a_u8;
+  if (!one) {
+    rc = mst_gemm_sigmoid_bce(args, bce, stream);
+    return rc != MST_OK ? rc : mst_gemm_nt_ln(dgrad, ln, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(a.dtype, [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    return launch_gemm_bce_dgrad_ln<T>(a, q, g2, l, s);
   });
 }
 

@@ -430,7 +430,7 @@ class StepPlan:
         self.be_l = [bwd_bufs(self.Me, De, cfg.e_heads, Se) for _ in range(cfg.e_layers)]
         self.bd_l = [bwd_bufs(self.Md, Dd, cfg.d_heads, Sd) for _ in range(cfg.d_layers)]
         self.be, self.bd = self.be_l[0], self.bd_l[0]
-        self._wgrads = []
+        self._wgrads, self._psums, self._out_dgrad_done = [], [], False
         self.wgrad_scratch = store.wgrad_scratch()
         # LayerNorm parameter gradients: every LayerNorm-backward workgroup leaves one row of column sums here and ONE
         # launch per flush adds them into the bucket (256 workgroups x one atomic per column on the same 2D addresses
@@ -638,6 +638,7 @@ class StepPlan:
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
+        self._wgrads, self._psums, self._outers, self._out_dgrad_done = [], [], [], False  # deferred gradient work of this step
         # one bookkeeping launch: RNG seed of this step, Adam's step count / lr_t, eps, both padding masks
         need_rng = cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps
         begin = dict(rng_state=self.rng_state if need_rng else None,
@@ -693,8 +694,18 @@ class StepPlan:
                          gscale=self.gscale, pre_zeroed=True,
                          tok_parts=self.store.tok_parts if self.track_token_metrics else None)
         elif self.fuse_bce:
-            o.gemm_sigmoid_bce(self.dec_out, self.store.h("decoder.output_layer.weight"), self.labels, self.recon, T, dlogits=dl,
-                               probs=self.probs, label_smoothing=self.ls, downweight=self.nld, gscale=self.gscale, M=B * T,
+            dgrad = None
+            if with_grad and o.ln_bwd_fusion_pays(cfg.d_model) and os.environ.get("MST_BCE_DGRAD", "1") != "0":
+                # the first launch of the backward pass — the output layer's input gradient + the last decoder layer's LayerNorm-3
+                # backward (backward_early) — consumes exactly the logit-gradient tile this launch produces: same workgroup
+                last, Dd, Sd = cfg.d_layers - 1, cfg.d_model, T + 1
+                dgrad = dict(A=self.dlogits, B=self.store.t("decoder.output_layer.weight"), dX_out=self.bd_l[last].dh, M=B * T, N=Dd,
+                             K=self.dlogits.shape[1], c_remap=(T, Sd, 1),
+                             **self._out_ln_bwd("decoder", last, self.dec[last], Dd, cfg.d_dropout, self._site_d(0) + 3 * last,
+                                                self.bd_l[last], B * T))
+                self._out_dgrad_done = True
+            o.gemm_sigmoid_bce(self.dec_out, self.store.h("decoder.output_layer.weight"), self.labels, self.recon, T, dgrad=dgrad,
+                               dlogits=dl, probs=self.probs, label_smoothing=self.ls, downweight=self.nld, gscale=self.gscale, M=B * T,
                                K=cfg.d_model, bias=self.store.p("decoder.output_layer.bias"), a_remap=(T, T + 1, 1))
         else:
             o.sigmoid_bce(self.logits, self.labels, self.recon, B, T, cfg.out_dim, label_smoothing=self.ls,
@@ -916,21 +927,22 @@ class StepPlan:
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
         sq_d = math.sqrt(float(Dd))
-        # (the gradient bucket was cleared by forward()'s step_begin launch)
-        self._wgrads, self._psums, self._outers = [], [], []
+        # (the gradient bucket was cleared by forward()'s bookkeeping, which also emptied the lists of deferred gradient work)
         # ---- output layer (rows 1..T of the decoder output; row 0 of dx_a stays zero)
         ldv = self.dlogits.shape[1]
         fuse_d, fuse_e = o.ln_bwd_fusion_pays(Dd), o.ln_bwd_fusion_pays(De)
         site_d = self._site_d(0)
         last = cfg.d_layers - 1
-        if fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
+        if self._out_dgrad_done:  # (it rode on the loss launch: losses())
+            self._out_dgrad_done = False
+        elif fuse_d:  # output-layer dgrad + the last decoder layer's LayerNorm-3 backward (rows 1..T; row 0 of dh stays 0)
             o.gemm_nt_ln_bwd(self.dlogits, st.t("decoder.output_layer.weight"), self.bd_l[last].dh, M=B * T, N=Dd, K=ldv,
                              c_remap=(T, Sd, 1),
                              **self._out_ln_bwd("decoder", last, self.dec[last], Dd, cfg.d_dropout, site_d + 3 * last, self.bd_l[last], B * T))
         else:
             o.gemm_nt(self.dlogits, st.t("decoder.output_layer.weight"), self.d_dec_out, M=B * T, N=Dd, K=ldv, c_remap=(T, Sd, 1))
-        self._wgrads = [o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
-                                        st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1))]
+        self._wgrads.append(o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
+                                            st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1)))
         dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
         for i in reversed(range(cfg.d_layers)):
             x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d

@@ -142,9 +142,7 @@ def can_fuse_bce(P, T):
     return P in (128, 256) and T % 64 == 0
 
 
-def gemm_sigmoid_bce(A, B, labels, loss, T, dlogits=None, probs=None, logits=None, label_smoothing=0.0, downweight=False, gscale=1.0,
-                     **kw):
-    """loss[b] += BCE(sigmoid(A @ B^T + bias), labels) and dlogits = its gradient, in one launch; **kw: M, K, bias, a_remap"""
+def _gemm_bce_args(A, B, labels, loss, T, dlogits=None, probs=None, logits=None, label_smoothing=0.0, downweight=False, gscale=1.0, **kw):
     g = _gemm_args(A, B, dlogits if dlogits is not None else A, N=B.shape[0], **kw)
     if dlogits is None:
         g.C, g.ldc = None, 0
@@ -153,7 +151,20 @@ def gemm_sigmoid_bce(A, B, labels, loss, T, dlogits=None, probs=None, logits=Non
     q.probs, q.ldp = ptr(probs), (ld(probs) if probs is not None else 0)
     q.logits, q.ldl = ptr(logits), (ld(logits) if logits is not None else 0)
     q.gscale = gscale
-    call("mst_gemm_sigmoid_bce", C.byref(g), C.byref(q), stream())
+    return g, q
+
+
+def gemm_sigmoid_bce(A, B, labels, loss, T, dgrad=None, **kw):
+    """loss[b] += BCE(sigmoid(A @ B^T + bias), labels) and dlogits = its gradient, in one launch; **kw: dlogits, probs, logits,
+    label_smoothing, downweight, gscale and the GEMM's M, K, bias, a_remap.
+    dgrad: keyword arguments of gemm_nt_ln_bwd whose A operand is that dlogits — the output layer's input gradient + LayerNorm
+    backward ride on the same launch where the shapes allow (mst_gemm_sigmoid_bce_dgrad_ln)"""
+    g, q = _gemm_bce_args(A, B, labels, loss, T, **kw)
+    if dgrad is None:
+        call("mst_gemm_sigmoid_bce", C.byref(g), C.byref(q), stream())
+    else:
+        g2, l = _gemm_ln_bwd_args(**dgrad)
+        call("mst_gemm_sigmoid_bce_dgrad_ln", C.byref(g), C.byref(q), C.byref(g2), C.byref(l), stream())
 
 
 def can_fuse_ln(D):
@@ -270,6 +281,11 @@ def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=
     rstd are indexed by dX_out's physical row, dx_masked by the logical row; the dropout fields among **kw are those of
     the LayerNorm-backward mask. partials: [gemm_nt_ln_parts(M), 2N] fp32 -> per-workgroup column sums are stored there
     instead of being added to dgamma / dbeta (finish with partial_sums)"""
+    g, l = _gemm_ln_bwd_args(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked, mask_mode, partials, **kw)
+    call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
+
+
+def _gemm_ln_bwd_args(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):
     g = _gemm_args(A, B, dX_out, **kw)
     l = LnArgs()
     l.mode, l.gamma = 2, ptr(gamma)
@@ -281,7 +297,7 @@ def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=
     l.partials = ptr(partials)
     if partials is not None:
         assert partials.shape[0] >= gemm_nt_ln_parts(g.M) and partials.shape[1] == 2 * g.N and partials.is_contiguous()
-    call("mst_gemm_nt_ln", C.byref(g), C.byref(l), stream())
+    return g, l
 
 
 def gemm_nt_ln_parts(M):

@@ -1231,6 +1231,50 @@ def test_gemm_sigmoid_bce_equals_gemm_then_bce(gpu, B, T, P, D, ls, dw, dtype):
     assert torch.allclose(loss3, loss2, rtol=2e-5, atol=0)
 
 
+@pytest.mark.parametrize("B,T,P,D,drop,dtype", [(64, 256, 128, 128, 0.2, BF), (4, 64, 128, 128, 0.0, torch.float16), (3, 64, 256, 128, 0.0, BF)])
+def test_gemm_sigmoid_bce_dgrad_ln_equals_the_two_launches(gpu, B, T, P, D, drop, dtype):
+    """mst_gemm_sigmoid_bce_dgrad_ln: the loss launch with the output layer's input gradient + the decoder's LayerNorm-3 backward
+    (mask mode 2, row remap into rows 1..T of T+1) in the same workgroup — bit-identical to mst_gemm_sigmoid_bce followed by
+    mst_gemm_nt_ln (mode 2) on the stored logit gradient, also where the form does not apply (256 pitches: two launches inside)"""
+    o = ops()
+    Sd, M = T + 1, B * T
+    x = rnd((B * Sd, D), gpu, 1.0, dtype, seed=31)
+    W = rnd((P, D), gpu, 0.2, dtype, seed=32)
+    Wt = W.t().contiguous()  # [D, P]: the transposed shadow the dgrad reads
+    bias = rnd((P,), gpu, 0.1, torch.float32, seed=33)
+    g = torch.Generator().manual_seed(34)
+    labels = (torch.rand(M, P, generator=g) < 0.05).to(torch.uint8).to(gpu)
+    h2 = rnd((B * Sd, D), gpu, 1.0, dtype, seed=35)
+    gamma = (1 + 0.1 * rnd((D,), gpu, 1.0, torch.float32, seed=36))
+    mean, rstd = h2.float().mean(1), (h2.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    seedp = torch.tensor([77, 0, 0, 0], dtype=torch.int64, device=gpu)
+    outs = []
+    for fused in (True, False):
+        loss = torch.zeros(B, dtype=torch.float32, device=gpu)
+        dl, pr = torch.zeros(M, P, dtype=dtype, device=gpu), torch.zeros(M, P, dtype=dtype, device=gpu)
+        dh = torch.zeros(B * Sd, D, dtype=dtype, device=gpu)
+        parts = torch.zeros(o.gemm_nt_ln_parts(M), 2 * D, device=gpu)
+        dg, db = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+        dgrad = dict(A=dl, B=Wt, dX_out=dh, x=h2, gamma=gamma, mean=mean, rstd=rstd, dgamma=dg, dbeta=db, mask_mode=2, partials=parts,
+                     M=M, N=D, K=P, c_remap=(T, Sd, 1))
+        if drop > 0:
+            dgrad.update(dropout_p=drop, dropout_seed_ptr=seedp, dropout_site=9)
+        kw = dict(dlogits=dl, probs=pr, label_smoothing=0.1, downweight=True, gscale=4.0, M=M, K=D, bias=bias, a_remap=(T, Sd, 1))
+        if fused:
+            o.gemm_sigmoid_bce(x, W, labels, loss, T, dgrad=dgrad, **kw)
+        else:
+            o.gemm_sigmoid_bce(x, W, labels, loss, T, **kw)
+            o.gemm_nt_ln_bwd(**dgrad)
+        torch.cuda.synchronize()
+        outs.append((loss, dl, pr, dh, parts))
+    for a_, b_, name in zip(outs[0], outs[1], ("loss", "dlogits", "probs", "dh", "LayerNorm partials")):
+        if name == "loss":
+            assert torch.allclose(a_, b_, rtol=1e-6, atol=0), name
+        else:
+            assert torch.equal(a_, b_), name
+    assert outs[0][3].abs().sum() > 0 and (outs[0][3].view(B, Sd, D)[:, 0] == 0).all()
+
+
 def test_bce_logit_zero_known_answer(gpu):
     o = ops()
     B, T, P = 2, 4, 8
