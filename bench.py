@@ -28,11 +28,13 @@ The line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -90,6 +92,7 @@ def synthetic_batches(n, B, T, P, seed):
 def cpu_baseline(c, dropout, budget_s=20.0):
     """time the CPU oracle on a bounded sample: training steps of one batch of this configuration's shape, same dropout
     (explicit keep masks, drawn once), until ~budget_s of CPU work"""
+    import torch
     from oracle import vae_oracle as O
     # the GPU box gives one GPU's share of the host (a cgroup quota of 16 cores; asking torch for every core the kernel
     # reports oversubscribes that share and runs ~50x slower)
@@ -130,6 +133,7 @@ def time_launch(o, fn, iters, reps=5):
     """average duration (ms) of one launch of `fn`, HIP events on the launch stream around a captured graph of `iters` back-to-back
     launches — as the step itself runs them —, median of `reps` replays: eager launches measured the host as well (one stall of
     the Python thread between two launches once put 1.9 ms on a 0.05 ms kernel)"""
+    import torch
     fn()
     torch.cuda.synchronize()
     g = o.Graph().capture(lambda: [fn() for _ in range(iters)])
@@ -241,7 +245,7 @@ def roofline(plan, o, config_id):
             "families": [{k: v for k, v in f.items() if k != "pmc_key"} for f in sorted(fams, key=lambda f: -f["share_ms"])]}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -251,7 +255,105 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=DROPOUT)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="default: the configuration's own")
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no launcher: start the N rank processes, have each print its rendezvous environment "
+                         "as one JSON line and exit (no GPU, no torch): a test of the launcher itself")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before the self-launcher gives up on its ranks")
+    return ap.parse_args(argv)
+
+
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the
+    launcher. It makes no GPU call and imports nothing that could (a process that has initialised HIP must not start
+    other programs on this pool): it starts N copies of this script as child processes — one rank per GPU, the same
+    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free
+    MASTER_PORT) —, relays rank 0's stdout (the ONE JSON line) and exits non-zero if any rank does. When one rank fails
+    the others are stopped — exactly the processes started here, by PID."""
+    n = args.gpus
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MST_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0's stdout is the bench line; the other ranks have nothing to say on stdout: send it to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # drain rank 0's pipe as it fills
+    reader.start()
+    deadline = time.monotonic() + args.launch_timeout
+    rc, pending = 0, set(range(n))
+    try:
+        while pending and rc == 0:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py launcher: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+            if rc == 0 and pending:
+                if time.monotonic() > deadline:
+                    rc = 124
+                    print(f"bench.py launcher: ranks {sorted(pending)} still running after {args.launch_timeout:.0f} s", file=sys.stderr)
+                else:
+                    time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    text = (out0 or b"").decode(errors="replace")
+    if rc == 0:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(text)
+    return rc
+
+
+def dry_rank():
+    """--dry-launch inside a rank: print the rendezvous environment, touch nothing else. (MST_BENCH_DRY_FAIL_RANK /
+    MST_BENCH_DRY_SLEEP: the launcher's own tests make one rank fail while the others are still running.)"""
+    if os.environ.get("MST_BENCH_DRY_FAIL_RANK") == os.environ.get("RANK"):
+        return 3
+    time.sleep(float(os.environ.get("MST_BENCH_DRY_SLEEP", "0")))
+    print(json.dumps({k: os.environ.get(k) for k in RANK_ENV + ("HSA_ENABLE_IPC_MODE_LEGACY", "MST_BENCH_SELF_LAUNCHED")}), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    if args.dry_launch:
+        return dry_rank()
+    return run_rank(args)
+
+
+def run_rank(args):
+    import torch
     c = CONFIGS[args.config]
     dtype = args.dtype or c["dtype"]
     B, T, P = c["B"], c["T"], c["P"]
@@ -260,7 +362,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (launch with torch.distributed.run); WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the training step has no CPU fallback")
     # MST_FORCE_DEVICE / MST_DIST_BACKEND exist to rehearse the multi-rank path on a one-GPU box (ranks share the
@@ -283,9 +385,15 @@ def main():
     plan = E.StepPlan(store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B * world, internal_eps=True, seed=1000,
                       sample_offset=rank * B, site_base=64 * rank)
     host = synthetic_batches(4, B, T, P, seed=1234 + rank)
-    reduce_fn = parallel.make_grad_allreduce(dist) if world > 1 else None
+    overlap = world > 1 and os.environ.get("MST_DP_OVERLAP", "1") != "0"
+    group, tune = None, None
+    if world > 1:
+        # which RCCL algorithm carries the step's gradient ranges: measured on this job's own ranks before anything is timed
+        cut = plan.grad_cut() if overlap else 0
+        group, tune = parallel.autotune_allreduce(dist, [store.n - cut, cut], dev)
+    reduce_fn = parallel.make_grad_allreduce(dist, group) if world > 1 else None
     # data parallel: the early part of the gradient bucket is all-reduced while the rest of backward runs
-    reducer = parallel.GradReducer(dist) if world > 1 and os.environ.get("MST_DP_OVERLAP", "1") != "0" else None
+    reducer = parallel.GradReducer(dist, group) if overlap else None
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -310,21 +418,24 @@ def main():
             plan.bind_inputs(buf)
             plan.capture(True, split_optimizer=world > 1, overlap=reducer is not None)
             graphs[buf.data_ptr()] = (plan.graph, plan.graph_late, plan.graph_opt)
+        # data parallel: HIP events on the step's stream around the gap between the end of the backward graph and the
+        # start of the optimizer graph = the part of the gradient all-reduce that nothing hides
+        gaps = [(o.Event(), o.Event()) for _ in range(args.steps)] if world > 1 else None
 
-        def launch(buf):
+        def launch(buf, stamps=None):
             plan.graph, plan.graph_late, plan.graph_opt = graphs[buf.data_ptr()]
-            plan.run(reduce_fn=reduce_fn, reducer=reducer)
+            plan.run(reduce_fn=reduce_fn, reducer=reducer, stamps=stamps)
 
         if args.data == "resident":
-            def one_step(i):
-                launch(blobs[i % len(blobs)])
+            def one_step(i, stamps=None):
+                launch(blobs[i % len(blobs)], stamps)
         else:
             feed = pipe.feed((batches[i % len(batches)] for i in range(args.warmup + args.steps)))
 
-            def one_step(i):
+            def one_step(i, stamps=None):
                 s = next(feed)  # batch i was staged while step i-1 ran; the generator stages batch i+1 at the next call
                 stream.wait_event(s.slot.uploaded)
-                launch(s.slot.dev)
+                launch(s.slot.dev, stamps)
                 s.slot.consumed.record(stream)
 
         for i in range(args.warmup):
@@ -337,7 +448,7 @@ def main():
         t0 = time.perf_counter()
         ev[0].record()
         for i in range(args.steps):
-            one_step(args.warmup + i)
+            one_step(args.warmup + i, gaps[i] if gaps else None)
             ev[i + 1].record()
         torch.cuda.synchronize()
         if dist is not None:
@@ -346,17 +457,28 @@ def main():
         elapsed = time.perf_counter() - t0
         per_step = sorted(ev[i].elapsed_ms(ev[i + 1]) for i in range(args.steps))
         median_ms = per_step[len(per_step) // 2]
+        exposed_us = None
         if dist is not None:
-            t = torch.tensor([elapsed, median_ms], dtype=torch.float64, device=dev)
+            gap = sorted(a.elapsed_ms(b) * 1e3 for a, b in gaps)
+            t = torch.tensor([elapsed, median_ms, gap[len(gap) // 2]], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, median_ms = float(t[0].item()), float(t[1].item())
+            elapsed, median_ms, exposed_us = float(t[0].item()), float(t[1].item()), float(t[2].item())
         m = plan.metrics()
         if args.data == "host":
             plan.bind_inputs(blobs[0])
         roof = roofline(plan, o, args.config) if rank == 0 else None
 
+    rccl = None
+    if dist is not None:
+        cut = plan.grad_cut() if reducer is not None else 0
+        rccl = {"nranks": world, "backend": dist.get_backend(), "bucket_bytes": 4 * store.n,
+                "ranges_bytes": {"overlapped_with_backward": 4 * (store.n - cut), "exposed": 4 * cut} if cut else {"exposed": 4 * store.n},
+                "schedule": "two ranges, the early one on the wire during the rest of backward" if cut else "one all-reduce between backward and Adam",
+                "exposed_allreduce_us": exposed_us, "autotune": tune, "log": parallel.rccl_report()}
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        return
+        return 0
     ms = elapsed / args.steps * 1e3
     frames = B * T * world * args.steps
     step_flops = 3.0 * fwd_flops(md, B, T)
@@ -380,10 +502,13 @@ def main():
         "elbo": m["total_loss"], "kl": m["kl_loss"],
         "roofline": roof,
     }
+    if rccl is not None:
+        out["rccl"] = rccl
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(c, args.dropout)
     print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

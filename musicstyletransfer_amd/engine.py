@@ -1074,9 +1074,11 @@ class StepPlan:
             self.graph_opt = None
         return self
 
-    def run(self, reduce_fn=None, reducer=None):
+    def run(self, reduce_fn=None, reducer=None, stamps=None):
         """Replay the captured step. reduce_fn(flat): blocking-in-stream-order all-reduce of the whole bucket between the
-        two graphs. reducer (parallel.GradReducer): asynchronous per-range all-reduce, used with capture(overlap=True)."""
+        two graphs. reducer (parallel.GradReducer): asynchronous per-range all-reduce, used with capture(overlap=True).
+        stamps: a pair of ops.Event recorded on the step's stream behind the last backward graph and in front of the
+        optimizer graph — the time between them is the part of the gradient exchange that nothing hides."""
         if self.graph is None:
             raise RuntimeError("call capture() first")
         self.graph.launch()
@@ -1084,18 +1086,26 @@ class StepPlan:
             g, cut = self.store.g, self.grad_cut()
             pending = [reducer.start(g[cut:])] if reducer is not None else []
             self.graph_late.launch()  # runs while the early part of the bucket is on the wire
+            if stamps is not None:
+                stamps[0].record()
             if reducer is not None:
                 pending.append(reducer.start(g[:cut]))
                 reducer.finish(pending)
             elif reduce_fn is not None:
                 reduce_fn(g)
+            if stamps is not None:
+                stamps[1].record()
             self.graph_opt.launch()
             return
         if self.graph_opt is not None:
+            if stamps is not None:
+                stamps[0].record()
             if reducer is not None:
                 reducer.finish([reducer.start(self.store.g)])
             elif reduce_fn is not None:
                 reduce_fn(self.store.g)
+            if stamps is not None:
+                stamps[1].record()
             self.graph_opt.launch()
 
     def metrics(self, reset=True):

@@ -14,7 +14,11 @@ The bucket is 7.5 MB (configs[1]); xGMI is point-to-point (7 links x ~153 GB/s p
 collective costs tens of microseconds and is issued as a single call on the step's stream between the
 captured forward/backward graph and the captured optimizer graph.
 """
+import glob
 import os
+import re
+import tempfile
+import time
 
 import numpy as np
 import torch
@@ -31,6 +35,8 @@ def init_process_group(world, rank, backend=None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver
     if backend is None:
         backend = os.environ.get("MST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        rccl_debug_env(rank)
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
@@ -39,12 +45,149 @@ def init_process_group(world, rank, backend=None):
     return dist
 
 
-def make_grad_allreduce(dist):
+def make_grad_allreduce(dist, group=None):
     """returns reduce_fn(flat_grad): in-place SUM over ranks, asynchronous on the current stream (nccl) or
     blocking (gloo, CPU tests)"""
     def reduce_fn(flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return reduce_fn
+
+
+# ------------------------------------------------------------------------------------------------ RCCL: what it does, and which algorithm
+# RCCL keeps NCCL's environment interface. NCCL_DEBUG=INFO with the INIT and TUNING subsystems makes every communicator
+# describe itself when it is created (ranks, channels, transports) and every collective report the algorithm / protocol
+# the tuner chose for its size ("AllReduce: 3302912 Bytes -> Algo 1 proto 2 ..."). The lines go to a per-process file
+# (NCCL_DEBUG_FILE), never to stdout — rank 0's stdout is bench.py's ONE JSON line.
+_ALGOS = {"0": "Tree", "1": "Ring", "2": "CollNetDirect", "3": "CollNetChain", "4": "NVLS", "5": "NVLSTree", "6": "PAT"}
+_ALGO_NAMES = {v.upper(): v for v in _ALGOS.values()}
+_PROTOS = {"0": "LL", "1": "LL128", "2": "Simple", "SIMPLE": "Simple"}
+
+
+def rccl_debug_env(rank):
+    """Ask RCCL (before its first communicator exists) to log its set-up and tuning decisions to a file of this
+    process. MST_RCCL_DEBUG=0 leaves the environment alone; an NCCL_DEBUG the caller exported wins."""
+    if os.environ.get("MST_RCCL_DEBUG", "1") == "0" or "NCCL_DEBUG" in os.environ:
+        return None
+    d = os.environ.get("MST_RCCL_LOG_DIR") or tempfile.mkdtemp(prefix="mst_rccl_")
+    os.makedirs(d, exist_ok=True)
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING,ENV"
+    os.environ["NCCL_DEBUG_FILE"] = os.path.join(d, f"rank{rank}.%p.log")
+    os.environ["MST_RCCL_LOG_DIR"] = d
+    return d
+
+
+def parse_rccl_log(text):
+    """What an NCCL_DEBUG=INFO log says about the communicators and the all-reduces of this process:
+    {'version', 'nranks', 'channels', 'transports': [...], 'allreduce': [{'bytes', 'algo', 'proto', 'calls'}, ...],
+     'env': {NCCL_* / RCCL_* variables RCCL says it read}}. Unknown formats leave fields out rather than guessing."""
+    out = {}
+    m = re.search(r"(?:RCCL|NCCL) version[ :]+([^\s]+)", text)
+    if m:
+        out["version"] = m.group(1)
+    m = re.findall(r"nranks (\d+)", text)
+    if m:
+        out["nranks"] = max(int(v) for v in m)
+    m = re.findall(r"(\d+) coll channels", text)
+    if m:
+        out["channels"] = max(int(v) for v in m)
+    tr = sorted(set(re.findall(r"\bvia ([A-Za-z0-9/_]+)", text)))
+    if tr:
+        out["transports"] = tr
+    calls = {}
+    for size, algo, proto in re.findall(r"AllReduce: (\d+) Bytes -> Algo (\S+) proto (\S+)", text):
+        key = (int(size), _ALGOS.get(algo, _ALGO_NAMES.get(algo.upper(), algo)), _PROTOS.get(proto, proto.upper()))
+        calls[key] = calls.get(key, 0) + 1
+    if calls:
+        out["allreduce"] = [dict(bytes=k[0], algo=k[1], proto=k[2], calls=n) for k, n in sorted(calls.items())]
+    env = dict(re.findall(r"\b((?:NCCL|RCCL)_[A-Z0-9_]+) set by environment to (\S+)", text))
+    if env:
+        out["env"] = env
+    return out
+
+
+def rccl_report():
+    """parse this process's RCCL log(s) (rccl_debug_env); {} when logging is off or nothing was written"""
+    d = os.environ.get("MST_RCCL_LOG_DIR")
+    if not d:
+        return {}
+    text = ""
+    for f in sorted(glob.glob(os.path.join(d, f"rank{os.environ.get('RANK', '0')}.*log*"))):
+        try:
+            with open(f, errors="replace") as fh:
+                text += fh.read()
+        except OSError:
+            pass
+    return parse_rccl_log(text) if text else {}
+
+
+def _time_allreduce(dist, group, tensors, iters, sync):
+    """average microseconds of one round of SUM all-reduces over `tensors` on `group`, wall clock around `iters` rounds
+    bracketed by sync() (a device synchronize for nccl), MAX over ranks so that every rank sees the same number"""
+    for t in tensors:  # warm-up: lazy communicator creation, first-call set-up
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    sync()
+    dist.barrier(group=group)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    sync()
+    us = torch.tensor([(time.perf_counter() - t0) / iters * 1e6], dtype=torch.float64, device=tensors[0].device)
+    dist.all_reduce(us, op=dist.ReduceOp.MAX, group=group)
+    return float(us.item())
+
+
+def autotune_allreduce(dist, range_numels, device, candidates=None, iters=20):
+    """Measure, on this job's own ranks and links, the all-reduce of the step's gradient ranges under each candidate RCCL
+    algorithm and return (group, report): the process group whose communicator was created under the fastest setting
+    (None = the default group) and {'candidates': {name: microseconds per step's worth of all-reduces}, 'chosen': name}.
+
+    RCCL reads NCCL_ALGO when a communicator is created, so each candidate is a dist.new_group() made under that
+    environment value; "default" leaves the choice to RCCL's tuner. xGMI on an MI355X node is a full mesh (7 links per
+    GPU): RCCL's ring set spreads its channels over all links, its tree is a depth-1..3 reduction + broadcast — which of
+    them wins for a 3-4 MB latency-dominated range is a property of the node, hence measured, not assumed.
+    Every rank runs the same sequence and the timings are MAX-reduced, so all ranks choose alike. MST_RCCL_ALGO=<name>
+    pins the choice (no measurement); MST_RCCL_AUTOTUNE=0 keeps the default group."""
+    backend = dist.get_backend()
+    sync = torch.cuda.synchronize if backend == "nccl" else (lambda: None)
+    pinned = os.environ.get("MST_RCCL_ALGO")
+    if candidates is None:
+        candidates = [pinned] if pinned else ["default", "Tree", "Ring"]
+    report = {"candidates": {}, "chosen": "default", "range_bytes": [4 * n for n in range_numels]}
+    if os.environ.get("MST_RCCL_AUTOTUNE", "1") == "0" and not pinned:
+        return None, report
+    bufs = [torch.zeros(n, dtype=torch.float32, device=device) for n in range_numels if n > 0]
+    groups = {}
+    saved = os.environ.get("NCCL_ALGO")
+    try:
+        for name in candidates:
+            if name == "default":
+                os.environ.pop("NCCL_ALGO", None)
+                groups[name] = None if saved is None else dist.new_group()
+            else:
+                os.environ["NCCL_ALGO"] = name
+                groups[name] = dist.new_group()
+            if pinned:
+                report["candidates"][name] = None
+                continue
+            try:
+                report["candidates"][name] = _time_allreduce(dist, groups[name], bufs, iters, sync)
+            except RuntimeError as e:  # an algorithm this RCCL build refuses for all-reduce: drop the candidate, on every rank alike
+                report["candidates"][name] = None
+                report.setdefault("errors", {})[name] = str(e).splitlines()[0][:200]
+    finally:
+        if saved is None:
+            os.environ.pop("NCCL_ALGO", None)
+        else:
+            os.environ["NCCL_ALGO"] = saved
+    timed = {k: v for k, v in report["candidates"].items() if v is not None}
+    if pinned:
+        report["chosen"] = pinned
+    elif timed:
+        report["chosen"] = min(timed, key=timed.get)
+    return groups.get(report["chosen"]), report
 
 
 class GradReducer:
@@ -52,13 +195,15 @@ class GradReducer:
     everything already issued on the current stream (nccl: on RCCL's own stream, so kernels launched afterwards on
     the current stream overlap with it; gloo: a host-side work item), finish() makes the current stream (nccl) or the
     host (gloo) wait for the given handles. This is the comm/compute overlap of the data-parallel step: the part of
-    the bucket that the top of the backward pass completes travels over xGMI while the rest of backward executes."""
+    the bucket that the top of the backward pass completes travels over xGMI while the rest of backward executes.
+    group: the process group (= RCCL communicator) the collectives run on — the one autotune_allreduce() picked, or
+    the default group."""
 
-    def __init__(self, dist):
-        self.dist = dist
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
 
     def start(self, flat_range):
-        return self.dist.all_reduce(flat_range, op=self.dist.ReduceOp.SUM, async_op=True)
+        return self.dist.all_reduce(flat_range, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self, handles):
         for h in handles:
