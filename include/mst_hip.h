@@ -452,7 +452,8 @@ typedef struct mst_row_tail_args {
   float eps;
   float dropout_p; uint64_t dropout_seed; const uint64_t* dropout_seed_ptr; uint32_t site0;
   int64_t phys_stride;
-  uint32_t* sync;
+  uint32_t* sync;    /* THREE zeroed device words: [0] barrier counter (3 * D/16 after a complete launch), [1] claimed XCD + 1, [2] roles */
+  uint32_t* status;  /* optional sticky device word: MST_TAIL_* flags are OR-ed into it when the launch could not do its work */
 } mst_row_tail_args;
 int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
 /* The same rows on the way back: autograd of mst_row_tail_fwd's chain for the gradient `dy` of the layer's output rows —
@@ -482,7 +483,8 @@ typedef struct mst_row_tail_bwd_args {
   float* dg1; float* db1; float* dg2; float* db2;
   float dropout_p; uint64_t dropout_seed; const uint64_t* dropout_seed_ptr; uint32_t site0;
   int64_t phys_stride;
-  uint32_t* sync;
+  uint32_t* sync;    /* three zeroed device words, as above ([0] ends at 2 * D/16) */
+  uint32_t* status;  /* optional, as above */
 } mst_row_tail_bwd_args;
 int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream);
 
@@ -566,12 +568,27 @@ int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_we
  * ------------------------------------------------------------------------ */
 typedef struct mst_step_metrics {
   int64_t B; const float* recon; const float* kl; float kl_weight; float* total; float* metric;
+  /* Step guard (all optional). status: two sticky device words {flags, number of skipped steps}. A step COUNTS only if
+   * status[0] == 0 and every given *expect_ptr holds expect_val (the barrier counters of the one-launch position-0 tails,
+   * mst_row_tail_*: a tail that could not finish leaves its counter short). Otherwise mst_adam_flat leaves parameters,
+   * moments and the step count as they were, the metric sums are not touched, flag MST_STEP_INCOMPLETE is added to
+   * status[0] when an expectation failed and status[1] is incremented: the batch is skipped, not mis-learned. The host reads
+   * the words with the metrics, takes its fallback and clears them. */
+  uint32_t* status; const uint32_t* expect_ptr0; uint32_t expect_val0; const uint32_t* expect_ptr1; uint32_t expect_val1;
 } mst_step_metrics;
+#define MST_TAIL_SPIN_FWD 1u     /* a grid barrier of mst_row_tail_fwd gave up waiting */
+#define MST_TAIL_SPIN_BWD 2u     /* ... of mst_row_tail_bwd */
+#define MST_TAIL_DIRTY_FWD 4u    /* mst_row_tail_fwd found its sync words not zeroed */
+#define MST_TAIL_DIRTY_BWD 8u
+#define MST_STEP_INCOMPLETE 16u  /* an expect_ptr of the step guard did not hold its value at the end of the step */
 int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
                   void* w16, double lr, double beta1, double beta2, float eps, float wd,
                   float rescale, float clip, int32_t* step_state /* device int32[2]: {t, bits(lr_t)} */,
                   int advance_step /* 0: reuse the lr_t of the previous launch (second range of one step) */,
                   const mst_step_metrics* metrics, mst_stream_t stream);
+/* mst_loss_combine with the step guard of mst_step_metrics (validation steps: a step whose position-0 tail failed adds
+ * nothing to the running sums) */
+int mst_loss_combine_v(const mst_step_metrics* metrics, mst_stream_t stream);
 
 /* 16-bit shadow + transposed shadow refresh for a list of matrices.
  * desc: int64 [n_mat, 4] on device = {src_offset, dst_offset, rows, cols}; dst is [cols, ld_t] with

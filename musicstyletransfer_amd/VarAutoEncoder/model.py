@@ -91,7 +91,9 @@ class _Decoder:
         cfg = m.engine_config
         dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
         plan.load_batch(x, seq_lens, classes, dummy, np.zeros((B, cfg.latent_dim), np.float32))  # eps = 0: z = means
-        plan.forward()
+        # outside autograd.record() in the reference (sampler.py:146-148): Dropout is the identity, and the training RNG
+        # stream is not advanced by a sampling hook in the middle of training
+        plan.forward(inference=True)
         row0 = plan.x0_d.view(B, T + 1, -1)[:, 0, :]
         if beam > 1:
             row0 = row0.repeat_interleave(beam, dim=0)
@@ -174,7 +176,10 @@ class Model:
         self._evict_hooks.append(callback)
 
     def __call__(self, tokens, seq_lens, classes, eps=None):
-        """forward only (model.py:287-296): returns (probs, means, vars) as device tensors"""
+        """forward only (model.py:287-296): returns (probs, means, vars) as device tensors. Called directly the reference's
+        Model runs outside autograd.record(), i.e. in predict mode: every Dropout is the identity (the training step —
+        Trainer._step, under record() — is where e_dropout / d_dropout act); an eps that is not given is drawn from the
+        store's inference RNG stream, never the training one."""
         if self.store is None:
             raise RuntimeError("call initialize(ctx) first")
         x = np.asarray(tokens.cpu() if torch.is_tensor(tokens) else tokens)
@@ -183,7 +188,7 @@ class Model:
         cfg = self.engine_config
         dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
         plan.load_batch(x, seq_lens, classes, dummy, eps)
-        plan.forward()
+        plan.forward(inference=True)
         plan.losses(with_grad=False, combine=False)  # (no contribution to the trainer's running metric sums)
         V = cfg.out_dim
         probs = plan.probs[:, :V].float().view(B, T, V)

@@ -86,7 +86,14 @@ class Trainer:
         self._initialize_optimizers()
         self.stream.synchronize()
         self._graphs = {}
+        self._tail_gen = 0
         self.model.on_plan_evicted(self._forget_plan)
+        # a failed one-launch position-0 tail (engine.ParamStore.handle_step_status) switches the store to the five-launch form:
+        # the graphs recorded with the old kernel sequence are dropped and every shape runs one eager step again (lazy module
+        # loads). With more than one rank a skipped update on one rank would let the replicas drift apart: stop instead.
+        self.model.store.on_tail_failure(self._on_tail_failure)
+        if self.world > 1:
+            self.model.store.tail_policy = "raise"
         self.pipeline = PinnedBatchPipeline(self.model.store.device, lambda B, T: self._plan(B, T))
         self.train_state = TrainingState()
         self.summary_writer = utils.ScalarWriter(os.environ.get("MST_LOGDIR", "/tmp/out")) if self.rank == 0 else None
@@ -120,6 +127,10 @@ class Trainer:
             plan._trainer_set = True
         return plan
 
+    def _on_tail_failure(self):
+        self._graphs.clear()
+        self._tail_gen += 1
+
     def _forget_plan(self, plan):
         for k in [k for k in self._graphs if k[0] == id(plan)]:
             del self._graphs[k]
@@ -137,10 +148,10 @@ class Trainer:
         g = self._graphs.get(key)
         ran = False
         warm = plan.__dict__.setdefault("_warm", set())
-        if is_train not in warm:
+        if (is_train, self._tail_gen) not in warm:
             plan.step_kernels(is_train, reduce_fn=self.reduce_fn)
             self.stream.synchronize()
-            warm.add(is_train)
+            warm.add((is_train, self._tail_gen))
             ran = True
         if g is None:
             plan.capture(is_train, split_optimizer=self.world > 1, overlap=self.world > 1)
@@ -206,14 +217,27 @@ class Trainer:
         """the reference's five metrics over every step since the last reset (trainer.py:107-120,181-186): kl_loss /
         total_loss batch means and, for the token ends, masked ppl / acc / topk — all accumulated on the device by the
         steps themselves and read here with one synchronisation"""
+        failure = None
         with torch.cuda.stream(self.stream):  # ordered behind every step launched so far
-            m = self.model.store.read_metrics(reset)
+            try:
+                m = self.model.store.read_metrics(reset)
+            except RuntimeError as e:  # (tail_policy "raise": data parallel) — tell the other ranks before stopping
+                if self.dist is None:
+                    raise
+                failure = e
+                m = self.model.store.read_metrics(reset)
         keys = [k for k in ("kl_sum", "total_sum", "count", "nll_sum", "acc_hits", "topk_hits", "n_tokens") if k in m]
         if self.dist is not None:
             with torch.cuda.stream(self.stream):
-                t = torch.tensor([m[k] for k in keys], dtype=torch.float64, device=self.model.store.device)
+                t = torch.tensor([m[k] for k in keys] + [1.0 if failure is not None else 0.0], dtype=torch.float64,
+                                 device=self.model.store.device)
                 self.dist.all_reduce(t)
-                m = dict(zip(keys, t.tolist()))
+                vals = t.tolist()
+                m = dict(zip(keys, vals[:-1]))
+            if vals[-1] > 0:
+                raise RuntimeError(f"{int(vals[-1])} rank(s) skipped optimizer steps after a failed position-0 tail; the replicas "
+                                   "are no longer identical — restart from the last checkpoint with MST_ROW_TAIL=0"
+                                   + (f" (this rank: {failure})" if failure is not None else ""))
         out = {}
         if "n_tokens" in m:
             n = m["n_tokens"]

@@ -56,7 +56,7 @@ class RowTailArgs(C.Structure):
         ("h1", vp), ("x1", vp), ("h2", vp), ("x2", vp), ("rs_d", c_i64), ("a", vp), ("rs_a", c_i64),
         ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp), ("stat_stride", c_i64),
         ("eps", c_f32), ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_seed_ptr", vp), ("site0", c_u32),
-        ("phys_stride", c_i64), ("sync", vp),
+        ("phys_stride", c_i64), ("sync", vp), ("status", vp),
     ]
 
 
@@ -70,7 +70,7 @@ class RowTailBwdArgs(C.Structure):
         ("dh1", vp), ("rs_dh1", c_i64), ("datt", vp), ("rs_datt", c_i64),
         ("dg1", vp), ("db1", vp), ("dg2", vp), ("db2", vp),
         ("dropout_p", c_f32), ("dropout_seed", c_u64), ("dropout_seed_ptr", vp), ("site0", c_u32),
-        ("phys_stride", c_i64), ("sync", vp),
+        ("phys_stride", c_i64), ("sync", vp), ("status", vp),
     ]
 
 
@@ -100,8 +100,13 @@ class LnBwdIn(C.Structure):
     ]
 
 
+# flags of the sticky step-status word (include/mst_hip.h: MST_TAIL_*, MST_STEP_INCOMPLETE)
+TAIL_SPIN_FWD, TAIL_SPIN_BWD, TAIL_DIRTY_FWD, TAIL_DIRTY_BWD, STEP_INCOMPLETE = 1, 2, 4, 8, 16
+
+
 class StepMetrics(C.Structure):
-    _fields_ = [("B", c_i64), ("recon", vp), ("kl", vp), ("kl_weight", c_f32), ("total", vp), ("metric", vp)]
+    _fields_ = [("B", c_i64), ("recon", vp), ("kl", vp), ("kl_weight", c_f32), ("total", vp), ("metric", vp),
+                ("status", vp), ("expect_ptr0", vp), ("expect_val0", c_u32), ("expect_ptr1", vp), ("expect_val1", c_u32)]
 
 
 class PartialSum(C.Structure):
@@ -210,6 +215,7 @@ SIGNATURES = {
     "mst_sigmoid_bce": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, c_f32, C.c_int, vp, vp, vp, c_i64,
                                   vp, c_i64, c_f32, C.c_int, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
+    "mst_loss_combine_v": (C.c_int, [C.POINTER(StepMetrics), vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
                                 vp, C.c_int, C.POINTER(StepMetrics), vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),

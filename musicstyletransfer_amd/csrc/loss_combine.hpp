@@ -28,4 +28,19 @@ __device__ __forceinline__ void loss_combine_wg(int64_t B, const float* __restri
   }
 }
 
+// the step guard of mst_step_metrics: true when this step must not count (uniform over the launch: every workgroup reads the
+// same words, and the only writer — step_mark_bad — runs when the answer is already `true` for everybody)
+__device__ __forceinline__ bool step_is_bad(const mst_step_metrics& mt, bool& incomplete) {
+  incomplete = false;
+  if (!mt.status) return false;
+  if (mt.expect_ptr0 && __hip_atomic_load(mt.expect_ptr0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mt.expect_val0) incomplete = true;
+  if (mt.expect_ptr1 && __hip_atomic_load(mt.expect_ptr1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mt.expect_val1) incomplete = true;
+  return incomplete || __hip_atomic_load(mt.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+// one thread, once per step
+__device__ __forceinline__ void step_mark_bad(const mst_step_metrics& mt, bool incomplete) {
+  if (incomplete) __hip_atomic_fetch_or(mt.status, MST_STEP_INCOMPLETE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(mt.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace mst

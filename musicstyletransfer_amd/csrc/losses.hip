@@ -382,6 +382,24 @@ extern "C" int mst_reparam_kl_bwd(int64_t B, int64_t Z, const float* mu, const f
   return MST_OK;
 }
 
+__global__ __launch_bounds__(256) void loss_combine_guarded_kernel(mst_step_metrics mt) {
+  __shared__ float red[2][4];
+  bool incomplete;
+  if (step_is_bad(mt, incomplete)) {
+    if (threadIdx.x == 0) step_mark_bad(mt, incomplete);
+    return;
+  }
+  loss_combine_wg(mt.B, mt.recon, mt.kl, mt.kl_weight, mt.total, mt.metric, red);
+}
+
+extern "C" int mst_loss_combine_v(const mst_step_metrics* metrics, mst_stream_t stream) {
+  MST_CHECK_ARG(metrics && metrics->B > 0 && metrics->recon && metrics->kl, "mst_loss_combine_v: bad argument");
+  MST_CHECK_ARG(metrics->status || (!metrics->expect_ptr0 && !metrics->expect_ptr1), "mst_loss_combine_v: expectations need the status words");
+  hipLaunchKernelGGL(loss_combine_guarded_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *metrics);
+  MST_CHECK_LAUNCH("loss_combine_guarded_kernel");
+  return MST_OK;
+}
+
 extern "C" int mst_loss_combine(int64_t B, const float* recon, const float* kl, float kl_weight, float* total,
                                 float* metric_acc, mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && recon && kl, "mst_loss_combine: bad argument");

@@ -29,8 +29,18 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __rest
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         T* __restrict__ w16, const int32_t* __restrict__ state,
                                                         float beta1, float beta2, float eps, float wd, float rescale,
-                                                        float clip, mst_step_metrics mt) {
+                                                        float clip, mst_step_metrics mt, int32_t* state_rw) {
   __shared__ float red[2][4];
+  bool incomplete;
+  if (step_is_bad(mt, incomplete)) {
+    // the step's position-0 tail did not finish (mst_step_metrics): no update, no metric sums, the step count taken back —
+    // by the launch that carries the step's bookkeeping (a second range of the same step only skips)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mt.recon) {
+      step_mark_bad(mt, incomplete);
+      state_rw[0] -= 1;
+    }
+    return;
+  }
   if (blockIdx.x == 0 && mt.recon) loss_combine_wg(mt.B, mt.recon, mt.kl, mt.kl_weight, mt.total, mt.metric, red);  // (uniform branch)
   const float lr_t = reinterpret_cast<const float*>(state)[1];
   const int64_t nvec = n / 4;
@@ -130,9 +140,10 @@ extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, 
                              double beta1, double beta2, float eps, float wd, float rescale, float clip,
                              int32_t* step_state, int advance_step, const mst_step_metrics* metrics, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
-  mst_step_metrics mt = {0, nullptr, nullptr, 0.f, nullptr, nullptr};
+  mst_step_metrics mt = {0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
   if (metrics) {
-    MST_CHECK_ARG(metrics->B > 0 && metrics->recon && metrics->kl, "mst_adam_flat: metrics need B, recon and kl");
+    MST_CHECK_ARG(metrics->recon == nullptr || (metrics->B > 0 && metrics->kl), "mst_adam_flat: metrics need B, recon and kl");
+    MST_CHECK_ARG(metrics->status || (!metrics->expect_ptr0 && !metrics->expect_ptr1), "mst_adam_flat: expectations need the status words");
     mt = *metrics;
   }
   MST_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
@@ -145,7 +156,7 @@ extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, 
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,
-                       (float)beta1, (float)beta2, eps, wd, rescale, clip, mt);
+                       (float)beta1, (float)beta2, eps, wd, rescale, clip, mt, step_state);
     MST_CHECK_LAUNCH("adam_flat_kernel");
     return MST_OK;
   });

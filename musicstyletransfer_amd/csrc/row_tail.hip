@@ -26,17 +26,34 @@
 
 namespace mst {
 
-__device__ __forceinline__ void grid_sync(uint32_t* ctr, uint32_t target) {
+// Status bits left in the caller's sticky device word (mst_row_tail_*_args.status, optional) when a launch could not do its work:
+//   1 / 2   a grid barrier of the forward / backward kernel gave up waiting (fewer than G workgroups of the launch were placed
+//           on the claimed XCD — CU masks, another partition mode, a co-tenant holding the CUs — so the rows behind it are stale)
+//   4 / 8   the sync words of the forward / backward launch were not zero at launch (roles were handed out wrongly or not at all)
+// The optimizer launch of the same step reads the word and leaves parameters, moments and the step count untouched when it is
+// set (mst_step_metrics.status), and the host switches to the five-launch form: a failed tail costs skipped batches, never a
+// silently wrong update.
+// (MST_TAIL_SPIN_FWD / _BWD, MST_TAIL_DIRTY_FWD / _BWD of include/mst_hip.h)
+#ifndef MST_TAIL_SPIN_TICKS
+#define MST_TAIL_SPIN_TICKS 20000000ull /* 0.2 s of the 100 MHz s_memrealtime clock; a healthy barrier waits microseconds */
+#endif
+
+__device__ __forceinline__ void grid_sync(uint32_t* ctr, uint32_t target, uint32_t* status, uint32_t spin_bit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
     // (agent-scope counter operations even though the participants share an XCD: an atomic add without scope bits + sc0 polling
     // loads was tried and is NOT reliable — most launches sat out the spin bound)
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) break;  // never in a correct launch; a bound instead of a hung GPU
+      if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > MST_TAIL_SPIN_TICKS) {
+        // never in a correct launch; a bound instead of a hung GPU — and a flag instead of a silently wrong step
+        if (status) __hip_atomic_fetch_or(status, spin_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
   }
   __syncthreads();
@@ -136,7 +153,7 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok)
 #define MST_TAIL_OVERSUBSCRIBE 12  /* 8 is exact under round-robin dispatch; measured 8 / 10 / 12 / 16: 0.7245 / 0.7234 / 0.7256 / 0.7256 ms per step */
 #endif
 constexpr int TAIL_OVERSUBSCRIBE = MST_TAIL_OVERSUBSCRIBE;
-__device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
+__device__ __forceinline__ int tail_join(uint32_t* sync, int G, uint32_t* status, uint32_t dirty_bit) {
   __shared__ int role;
   if (threadIdx.x == 0) {
     uint32_t xcc;
@@ -149,6 +166,8 @@ __device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
     if (claimed == xcc) {
       const uint32_t k = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k < (uint32_t)G) r = (int)k;
+      // the workgroup that claimed the XCD is the first to ask for a role: anything but role 0 means the words were not zeroed
+      if (seen == 0u && k != 0u && status) __hip_atomic_fetch_or(status, dirty_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     role = r;
   }
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = tail_join(q.sync, G);
+  const int g = tail_join(q.sync, G, q.status, MST_TAIL_DIRTY_FWD);
   if (g < 0) return;
   for (int i = tid; i < D; i += TAIL_WAVES * 64) {
     sPar[i] = q.bp[i]; sPar[D + i] = q.g1[i]; sPar[2 * D + i] = q.be1[i];
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 #pragma unroll
   for (int ks = 0; ks < D / 32; ++ks) w1f[ks] = frag16<T>(W1p + 32 * ks, true);
   TAIL_STAMP(1);
-  grid_sync(q.sync, G);
+  grid_sync(q.sync, G, q.status, MST_TAIL_SPIN_FWD);
   TAIL_STAMP(2);
 
   // ---------------- stage 2: x1 = LN1(h1) for every row (each workgroup, into LDS; the rows' owner also to HBM), then
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
     if (m_ok) finish4(acc, s_b1, n1 + 4 * lq, q.site0 + 1, F, true, nullptr, a + (int64_t)m * q.rs_a);
   }
   TAIL_STAMP(3);
-  grid_sync(q.sync, 2 * G);
+  grid_sync(q.sync, 2 * G, q.status, MST_TAIL_SPIN_FWD);
   TAIL_STAMP(4);
 
   // ---------------- stage 3: h2[:, 16 g ..] = x1 + dropout(a W2^T + b2)        (K = 4 D: the whole hidden row, a quarter per wave)
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
     if (wq == 0 && m_ok) finish4(acc, s_b2, n2 + 4 * lq, q.site0 + 2, D, false, sX1 + m * LDX, h2 + (int64_t)m * q.rs_d);
   }
   TAIL_STAMP(5);
-  grid_sync(q.sync, 3 * G);
+  grid_sync(q.sync, 3 * G, q.status, MST_TAIL_SPIN_FWD);
   TAIL_STAMP(6);
 
   // ---------------- stage 4: x2 = LN2(h2), rows dealt to the workgroups
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = tail_join(q.sync, G);
+  const int g = tail_join(q.sync, G, q.status, MST_TAIL_DIRTY_BWD);
   if (g < 0) return;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
@@ -622,7 +641,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
     }
   }
   TAIL_STAMP(2);
-  grid_sync(q.sync, G);
+  grid_sync(q.sync, G, q.status, MST_TAIL_SPIN_BWD);
   TAIL_STAMP(3);
 
   // ---------------- stage 3: dx1[:, 16 g ..] = d(pre) W1t^T + dh        (K = 4 D, a quarter per wave)
@@ -654,7 +673,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
     }
   }
   TAIL_STAMP(4);
-  grid_sync(q.sync, 2 * G);
+  grid_sync(q.sync, 2 * G, q.status, MST_TAIL_SPIN_BWD);
   TAIL_STAMP(5);
 
   // ---------------- stage 4: LayerNorm-1 backward of every row (operand of stage 5 in LDS)

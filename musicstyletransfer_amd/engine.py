@@ -17,6 +17,7 @@ out by hand below, mirroring the forward line by line.
 """
 import math
 import os
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -189,7 +190,17 @@ class ParamStore:
         # running metric sums of every step since the last read (trainer.py:107-120,181-186), whatever plan ran it:
         #   metric_acc = [sum kl, sum total, count]; tok_parts = per-workgroup partial rows of the masked token metrics
         #   {sum -log p[label], #arg-max hits, #top-k hits, #valid} accumulated by mst_softmax_ce (token ends)
-        self.metric_acc = torch.zeros(3, **f32)
+        # step_status = two sticky int32 words {flags, skipped steps} of the step guard (mst_step_metrics): set on the device when
+        # a one-launch position-0 tail (mst_row_tail_*) could not finish, read with the metrics (same device->host copy)
+        self._metric_buf = torch.zeros(8, **f32)
+        self.metric_acc = self._metric_buf[:3]
+        self.step_status = self._metric_buf[4:6].view(torch.int32)
+        self.tail_fused = os.environ.get("MST_ROW_TAIL", "1") != "0"  # False: the five-launch form of the position-0 tails
+        self.tail_checked = False     # row_tail_selfcheck() ran for this store
+        self.tail_policy = os.environ.get("MST_TAIL_FAILURE", "fallback")  # or "raise"
+        self.tail_failures = []       # (flags, skipped steps) of every failure seen
+        self._tail_listeners = []
+        self._rng_state_infer = None
         self.tok_parts = torch.zeros(_lib_ce_rows(), 4, **f32) if cfg.kind == "token" else None
         if params_np is None:
             params_np = xavier_init(cfg, np.random.default_rng(seed))
@@ -201,11 +212,45 @@ class ParamStore:
             self._rng_state = torch.tensor([0, 0, seed ^ 0x5DEECE66D, 0], dtype=torch.int64, device=self.device)
         return self._rng_state
 
+    def rng_state_inference(self):
+        """the RNG state inference-mode forward passes advance (eps of Model.__call__ when none is given): never the
+        training stream's, so that a sampling hook in the middle of training leaves the steps after it as they were"""
+        if self._rng_state_infer is None:
+            self._rng_state_infer = torch.tensor([0, 0, 0x1F123BB5 ^ 0x5DEECE66D, 0], dtype=torch.int64, device=self.device)
+        return self._rng_state_infer
+
+    def on_tail_failure(self, callback):
+        """callback() after a failed position-0 tail made this store fall back to the five-launch form: holders of captured
+        graphs must drop them (they were recorded with the one-launch kernels)"""
+        self._tail_listeners.append(callback)
+
+    def handle_step_status(self, flags, skipped):
+        """A one-launch position-0 tail could not do its work in `skipped` steps since the last read (flags: _lib.TAIL_* /
+        STEP_INCOMPLETE). The optimizer launches of those steps left the model untouched (step guard), so nothing wrong was
+        learned; from here on the five-launch form runs (policy 'fallback'), or the run stops (policy 'raise')."""
+        o.zero(self._metric_buf[4:8])
+        self.tail_failures.append((int(flags), int(skipped)))
+        self.tail_fused = False
+        msg = (f"the one-launch position-0 tail of the top encoder layer failed (status flags {int(flags):#x}: "
+               f"{'forward barrier timed out; ' if flags & 1 else ''}{'backward barrier timed out; ' if flags & 2 else ''}"
+               f"{'sync words not clean; ' if flags & 12 else ''}{'tail incomplete at the end of a step; ' if flags & 16 else ''}"
+               f"{int(skipped)} step(s) skipped without touching the model)")
+        if self.tail_policy == "raise":
+            raise RuntimeError(msg + " — MST_TAIL_FAILURE=raise")
+        warnings.warn(msg + "; falling back to the five-launch form for the rest of the run", RuntimeWarning)
+        for cb in self._tail_listeners:
+            cb()
+
     def read_metrics(self, reset=True):
         """one device->host read of the running sums: {'kl_sum', 'total_sum', 'count'} and, for the token ends,
-        {'nll_sum', 'acc_hits', 'topk_hits', 'n_tokens'} (the caller orders this after the steps it wants included)"""
-        acc = self.metric_acc.cpu().tolist()
-        out = {"kl_sum": acc[0], "total_sum": acc[1], "count": acc[2]}
+        {'nll_sum', 'acc_hits', 'topk_hits', 'n_tokens'} (the caller orders this after the steps it wants included).
+        The step-status words travel in the same copy: a set flag is handled here (handle_step_status)."""
+        buf = self._metric_buf.cpu()
+        acc = buf[:3].tolist()
+        flags, skipped = buf[4:6].view(torch.int32).tolist()
+        if flags or skipped:
+            self.handle_step_status(flags, skipped)
+        out = {"kl_sum": acc[0], "total_sum": acc[1], "count": acc[2], "skipped_steps": skipped}
         if self.tok_parts is not None:
             t = self.tok_parts.cpu().double().sum(0).tolist()
             out.update(nll_sum=t[0], acc_hits=t[1], topk_hits=t[2], n_tokens=t[3])
@@ -296,6 +341,92 @@ class ParamStore:
 
 class _Layer:
     pass
+
+
+def row_tail_selfcheck(store, B=64, S=2):
+    """One-time start-up check of the one-launch position-0 tails (mst_row_tail_fwd / _bwd) on THIS device, process and
+    partition mode: both are run against the five launches they replace, on random rows and the store's own top-layer
+    weights. Their grid barrier rests on properties no API guarantees (enough workgroups of an oversubscribed launch landing
+    on one XCD, L1 behaviour of write-through lines — csrc/row_tail.hip), so shape alone does not decide whether the fused
+    form is used: a mismatch, an unfinished barrier or a status flag pins the store to the five-launch form."""
+    store.tail_checked = True
+    cfg, dev, adt = store.cfg, store.device, store.act_dtype
+    D, F = cfg.e_model, 4 * cfg.e_model
+    if not (o.can_row_tail(B, D) and store.tail_fused and cfg.e_layers >= 1):
+        return True
+    pre = f"encoder.layer{cfg.e_layers - 1}"
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def rnd(rows, width, site, scale=1.0, relu=False):
+        a = torch.zeros(rows, width, **f32)
+        o.randn(a, seed=0x7A11, site=site)
+        t = torch.zeros(rows, width, dtype=adt, device=dev)
+        o.cast_to_act(a, t)  # (values ~ N(0, 1); `scale` only documents intent: LayerNorm makes the chain scale-free)
+        return t
+
+    row0 = lambda t: t.view(B, S, -1)[:, 0, :]
+    att, xin = rnd(B * S, D, 1), rnd(B * S, D, 2)
+    Wp, W1, W2 = store.h(f"{pre}.att.W_proj.weight"), store.h(f"{pre}.ff1.weight"), store.h(f"{pre}.ff2.weight")
+    par = {k: store.p(f"{pre}.{k}") for k in ("att.W_proj.bias", "ln1.gamma", "ln1.beta", "ff1.bias", "ff2.bias", "ln2.gamma", "ln2.beta")}
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    sync = torch.zeros(8, dtype=torch.int32, device=dev)
+
+    def fbufs():
+        z = lambda w: torch.zeros(B * S, w, dtype=adt, device=dev)
+        return dict(h1=z(D), x1=z(D), a=z(F), h2=z(D), x2=z(D), m1=torch.zeros(B * S, **f32), r1=torch.zeros(B * S, **f32),
+                    m2=torch.zeros(B * S, **f32), r2=torch.zeros(B * S, **f32))
+
+    u, f, rows = fbufs(), fbufs(), (1, S, 0)
+    o.gemm_nt(row0(att), Wp, u["h1"], M=B, N=D, K=D, bias=par["att.W_proj.bias"], resid=row0(xin), c_remap=rows)
+    o.layernorm_fwd(row0(u["h1"]), par["ln1.gamma"], par["ln1.beta"], row0(u["x1"]), u["m1"], u["r1"], D=D, M=B, row_id_stride=S)
+    o.gemm_nt(row0(u["x1"]), W1, u["a"], M=B, K=D, bias=par["ff1.bias"], act=o.ACT_RELU, c_remap=rows)
+    o.gemm_nt(row0(u["a"]), W2, u["h2"], M=B, K=F, bias=par["ff2.bias"], resid=row0(u["x1"]), c_remap=rows)
+    o.layernorm_fwd(row0(u["h2"]), par["ln2.gamma"], par["ln2.beta"], row0(u["x2"]), u["m2"], u["r2"], D=D, M=B, row_id_stride=S)
+    o.row_tail_fwd(row0(att), row0(xin), Wp, par["att.W_proj.bias"], par["ln1.gamma"], par["ln1.beta"], W1, par["ff1.bias"], W2,
+                   par["ff2.bias"], par["ln2.gamma"], par["ln2.beta"], row0(f["h1"]), row0(f["x1"]), row0(f["a"]), row0(f["h2"]),
+                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:3], stat_stride=S, phys_stride=S, status=status[0:1])
+    # backward chain on the forward's own activations
+    dy = rnd(B * S, D, 3)
+    W2t, W1t, Wpt = store.t(f"{pre}.ff2.weight"), store.t(f"{pre}.ff1.weight"), store.t(f"{pre}.att.W_proj.weight")
+
+    def bbufs():
+        z = lambda n, w: torch.zeros(n, w, dtype=adt, device=dev)
+        return dict(dh=z(B, D), dhm=z(B, D), dx1=z(B, D), dh1m=z(B, D), dpre=z(B, F), dh1=z(B * S, D), datt=z(B * S, D),
+                    dg1=torch.zeros(D, **f32), db1=torch.zeros(D, **f32), dg2=torch.zeros(D, **f32), db2=torch.zeros(D, **f32))
+
+    ub, fb = bbufs(), bbufs()
+    g1, g2 = par["ln1.gamma"], par["ln2.gamma"]
+    o.layernorm_bwd(row0(u["h2"]), g2, u["m2"], u["r2"], row0(dy), ub["dh"], ub["dg2"], ub["db2"], D=D, M=B, row_id_stride=S)
+    o.gemm_nt(ub["dh"], W2t, ub["dpre"], N=F, K=D, gate=row0(u["a"]), alpha=1.0)
+    o.gemm_nt(ub["dpre"], W1t, ub["dx1"], N=D, K=F, resid=ub["dh"])
+    o.layernorm_bwd(row0(u["h1"]), g1, u["m1"], u["r1"], ub["dx1"], row0(ub["dh1"]), ub["dg1"], ub["db1"], D=D, M=B, row_id_stride=S)
+    o.gemm_nt(row0(ub["dh1"]), Wpt, ub["datt"], M=B, N=D, K=D, c_remap=(1, S, 0))
+    o.row_tail_bwd(row0(dy), row0(u["h2"]), row0(u["h1"]), row0(u["a"]), u["m1"], u["r1"], u["m2"], u["r2"], g1, g2, W2t, W1t, Wpt,
+                   fb["dh"], fb["dhm"], fb["dx1"], fb["dh1m"], fb["dpre"], row0(fb["dh1"]), row0(fb["datt"]), fb["dg1"], fb["db1"],
+                   fb["dg2"], fb["db2"], sync[4:7], stat_stride=S, phys_stride=S, status=status[0:1])
+    torch.cuda.current_stream().synchronize()
+    G = D // 16
+    sy, stv = sync.cpu().tolist(), status.cpu().tolist()
+    why = []
+    if stv[0]:
+        why.append(f"status flags {stv[0]:#x}")
+    if sy[0] != 3 * G or sy[4] != 2 * G:
+        why.append(f"barrier counters {sy[0]} / {sy[4]} instead of {3 * G} / {2 * G}")
+    ulp = 2.0 ** -7 if adt == torch.bfloat16 else 2.0 ** -10
+    host = lambda t: t.float().cpu().numpy()
+    for k in ("h1", "x1", "a", "h2", "x2"):
+        a, b = host(row0(f[k])), host(row0(u[k]))
+        if not np.all(np.abs(a - b) <= 4 * ulp * np.maximum(np.abs(b), 1.0)):
+            why.append(f"forward {k}: max difference {np.abs(a - b).max():.3g}")
+    for k in ("dh", "dpre", "dx1", "dh1", "datt"):
+        a, b = host(fb[k]), host(ub[k])
+        if not np.abs(a - b).max() <= 4 * ulp * max(float(np.abs(b).max()), 1e-6) + 1e-6:
+            why.append(f"backward {k}: max difference {np.abs(a - b).max():.3g} (scale {np.abs(b).max():.3g})")
+    if why:
+        store.tail_fused = False
+        warnings.warn("the one-launch position-0 tail failed its start-up check on this device (" + "; ".join(why) +
+                      "): using the five-launch form", RuntimeWarning)
+    return not why
 
 
 class StepPlan:
@@ -461,6 +592,33 @@ class StepPlan:
         self.graph_late = None
         self.graph_opt = None
         self._tick_adam = False
+        self._infer = False
+        self._tail_used = dict(fwd=False, bwd=False)  # which one-launch tails the kernel sequence issued last contains
+        if o.can_row_tail(B, De) and store.tail_fused and not store.tail_checked:
+            row_tail_selfcheck(store)
+
+    # dropout probabilities of the current pass: 0 in inference mode (forward(inference=True)), where Dropout is the identity
+    @property
+    def e_p(self):
+        return 0.0 if self._infer else self.cfg.e_dropout
+
+    @property
+    def d_p(self):
+        return 0.0 if self._infer else self.cfg.d_dropout
+
+    def _tail_on(self, D):
+        return o.can_row_tail(self.B, D) and self.store.tail_fused
+
+    def _guard(self):
+        """step guard of the launches that close a step (optimizer / loss_combine): the barrier counters of the one-launch
+        tails issued in this step must have reached their final values (G = D / 16 workgroups: 3 barriers forward, 2 backward)"""
+        G = self.cfg.e_model // 16
+        exp = []
+        if self._tail_used["fwd"]:
+            exp.append((self.sync_words[0:1], 3 * G))
+        if self._tail_used["bwd"]:
+            exp.append((self.sync_words[4:5], 2 * G))
+        return dict(status=self.store.step_status, expect=exp) if exp else {}
 
     # ------------------------------------------------------------------------------ inputs
     def bind_inputs(self, buf):
@@ -569,7 +727,7 @@ class StepPlan:
         normalise over ALL queries) only query 0 is attended and only B rows go through W_proj, LN1, the FFN and LN2.
         The other rows of these buffers are never produced nor read (backward: _top_encoder_layer_bwd)."""
         cfg, st, B, S = self.cfg, self.store, self.B, self.T
-        D, H, p, site0 = cfg.e_model, cfg.e_heads, cfg.e_dropout, self._site_e(i)
+        D, H, p, site0 = cfg.e_model, cfg.e_heads, self.e_p, self._site_e(i)
         pre = f"encoder.layer{i}"
 
         def row0(buf):
@@ -577,13 +735,14 @@ class StepPlan:
 
         o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
         o.attn_fwd(L.qkv, self.keymask_e, L.lse, L.att, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
-        if o.can_row_tail(B, D):  # W_proj, LN1, FFN1, FFN2, LN2 on the B position-0 rows in one launch (mst_row_tail_fwd)
+        self._tail_used["fwd"] = self._tail_on(D)
+        if self._tail_used["fwd"]:  # W_proj, LN1, FFN1, FFN2, LN2 on the B position-0 rows in one launch (mst_row_tail_fwd)
             o.row_tail_fwd(row0(L.att), row0(x_in), st.h(f"{pre}.att.W_proj.weight"), st.p(f"{pre}.att.W_proj.bias"),
                            st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), st.h(f"{pre}.ff1.weight"), st.p(f"{pre}.ff1.bias"),
                            st.h(f"{pre}.ff2.weight"), st.p(f"{pre}.ff2.bias"), st.p(f"{pre}.ln2.gamma"), st.p(f"{pre}.ln2.beta"),
                            row0(L.h1), row0(L.x1), row0(L.a), row0(L.h2), row0(L.x2), L.mean1, L.rstd1, L.mean2, L.rstd2,
                            self.sync_words[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
-                           dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
+                           dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0, status=st.step_status[0:1])
             return L.x2
         rows = (1, S, 0)  # output row b -> physical row b*S
         o.gemm_nt(row0(L.att), st.h(f"{pre}.att.W_proj.weight"), L.h1, M=B, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
@@ -633,20 +792,27 @@ class StepPlan:
         o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
         return L.x2
 
-    def forward(self):
+    def forward(self, inference=False):
+        """inference=True: the forward pass as the reference runs it OUTSIDE autograd.record() (Model(...) called directly, the
+        samplers: sampler.py:146-148) — every Dropout is the identity and the training RNG stream is left alone (an eps the
+        caller did not supply is drawn from the store's inference stream)."""
         cfg, st, B, T = self.cfg, self.store, self.B, self.T
+        self._infer = bool(inference)
+        self._tail_used = dict(fwd=False, bwd=False)
         De, Dd = cfg.e_model, cfg.d_model
         Se, Sd = T, T + 1
         sq_e, sq_d = math.sqrt(float(De)), math.sqrt(float(Dd))
         self._wgrads, self._psums, self._outers, self._out_dgrad_done = [], [], [], False  # deferred gradient work of this step
         # one bookkeeping launch: RNG seed of this step, Adam's step count / lr_t, eps, both padding masks
-        need_rng = cfg.e_dropout > 0 or cfg.d_dropout > 0 or self.internal_eps
-        begin = dict(rng_state=self.rng_state if need_rng else None,
-                     adam_state=st.step_state if self._tick_adam else None, lr=self.lr, beta1=self.opt["beta1"],
+        need_rng = self.e_p > 0 or self.d_p > 0 or self.internal_eps
+        rng = st.rng_state_inference() if self._infer else self.rng_state
+        tick = self._tick_adam and not self._infer
+        begin = dict(rng_state=rng if need_rng else None,
+                     adam_state=st.step_state if tick else None, lr=self.lr, beta1=self.opt["beta1"],
                      beta2=self.opt["beta2"], eps_out=self.eps if self.internal_eps else None,
                      eps_index0=self.sample_offset * cfg.latent_dim, lens=self.seq_lens,
                      mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
-                     zero_a=self._recon_buf, zero_b=st.g if self._tick_adam else None)
+                     zero_a=self._recon_buf, zero_b=st.g if tick else None)
         # (piano-roll ends: nothing in the embedding GEMMs reads what the bookkeeping writes — it rides on their launch)
         ride = cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0"
         if not ride:
@@ -664,7 +830,7 @@ class StepPlan:
                            begin=begin if ride else None)
         x = self.x0_e
         for i, L in enumerate(self.enc):
-            x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, cfg.e_dropout, self._site_e(i))
+            x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, self.e_p, self._site_e(i))
         self.enc_out = x
         # ---- latent block + decoder position 0 (model.py:97-103,292,229-232)
         o.latent_fwd(x.view(B, Se, -1), st.p("encoder.latent_proj.weight"), st.p("encoder.latent_proj.bias"), self.eps,
@@ -677,7 +843,7 @@ class StepPlan:
         x = self.x0_d
         site_d = self._site_d(0)
         for i, L in enumerate(self.dec):
-            x = self._layer_fwd("decoder", i, L, x, self.keymask_d, Dd, cfg.d_heads, Sd, cfg.d_dropout, site_d + 3 * i)
+            x = self._layer_fwd("decoder", i, L, x, self.keymask_d, Dd, cfg.d_heads, Sd, self.d_p, site_d + 3 * i)
         self.dec_out = x
         # ---- output layer on positions 1..T (model.py:253-256); with a whole row of pitches per tile it runs inside the loss
         # launch (losses(): mst_gemm_sigmoid_bce) and the logits never reach HBM
@@ -712,7 +878,7 @@ class StepPlan:
                           downweight=self.nld, npos=self.npos, probs=self.probs, dlogits=dl, gscale=self.gscale,
                           pre_zeroed=True)
         if combine:
-            o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc)
+            o.loss_combine(self.recon, self.kl, self.kl_weight, self.total, self.metric_acc, guard=self._guard())
 
     # ------------------------------------------------------------------------------ backward
     LN_PARTIALS_MIN = 32  # fewer workgroups than this: their atomics are cheaper than a row of partials each
@@ -847,13 +1013,15 @@ class StepPlan:
             return buf.view(B, S, -1)[:, 0, :]
 
         dy = row0(self.d_enc_out)
-        if o.can_row_tail(B, D) and self.fuse_tail_bwd:
+        self._tail_used["bwd"] = self._tail_on(D) and self.fuse_tail_bwd
+        if self._tail_used["bwd"]:
             # LayerNorm-2 backward, both FFN dgrads, LayerNorm-1 backward and the W_proj dgrad of the B rows in one launch
             o.row_tail_bwd(dy, row0(L.h2), row0(L.h1), row0(L.a), L.mean1, L.rstd1, L.mean2, L.rstd2, st.p(f"{pre}.ln1.gamma"),
                            st.p(f"{pre}.ln2.gamma"), st.t(f"{pre}.ff2.weight"), st.t(f"{pre}.ff1.weight"), st.t(f"{pre}.att.W_proj.weight"),
                            c.dh, c.dhm, c.dx1, c.dh1m, c.dpre, row0(self.sp_dh1), row0(self.sp_datt), st.grad(f"{pre}.ln1.gamma"),
                            st.grad(f"{pre}.ln1.beta"), st.grad(f"{pre}.ln2.gamma"), st.grad(f"{pre}.ln2.beta"), self.sync_words[4:7],
-                           stat_stride=S, phys_stride=S, dropout_p=p, dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0)
+                           stat_stride=S, phys_stride=S, dropout_p=p, dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0,
+                           status=st.step_status[0:1])
             dff, dproj = c.dhm, c.dh1m
             return self._top_encoder_layer_bwd_rest(i, L, x_in, dx_in, t, next_ln, dff, dproj)
         if p > 0:
@@ -1018,7 +1186,8 @@ class StepPlan:
         st = self.store
         clip = self.clip if self.clip is not None else -1.0
         # end-of-step bookkeeping (total loss, running metric sums) on the first Adam launch: losses(combine=False)
-        mt = dict(recon=self.recon, kl=self.kl, kl_weight=self.kl_weight, total=self.total, metric=self.metric_acc)
+        guard = self._guard()
+        mt = dict(recon=self.recon, kl=self.kl, kl_weight=self.kl_weight, total=self.total, metric=self.metric_acc, **guard)
         if self.gscale == self.gscale_enc:
             o.adam_flat(st.w, st.g, st.m, st.v, st.w16, st.step_state, lr=self.lr,
                         rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, metrics=mt, **self.opt)
@@ -1029,8 +1198,8 @@ class StepPlan:
             rng = [(0, cut, self.gscale_enc, False), (cut, st.n, self.gscale, False)]
             for a, b, gs, adv in rng:
                 o.adam_flat(st.w[a:b], st.g[a:b], st.m[a:b], st.v[a:b], st.w16[a:b], st.step_state, lr=self.lr,
-                            rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv, metrics=mt if a == 0 else None,
-                            **self.opt)
+                            rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv,
+                            metrics=mt if a == 0 else (guard or None), **self.opt)
         o.transpose_shadows(st.w, st.wt16, st.t_desc, st.t_prefix, len(st.t_specs), st.t_tiles)
 
     # ------------------------------------------------------------------------------ step

@@ -100,9 +100,12 @@ def can_row_tail(B, D):
 
 
 def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a, h2, x2, mean1, rstd1, mean2, rstd2, sync, stat_stride,
-                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0):
+                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None):
     """att / resid / h1 / x1 / a / h2 / x2: [B, width] row views (stride(0) = the row stride in elements) of the layer's
-    buffers; sync: one zeroed int32 device word"""
+    buffers; sync: THREE zeroed int32 device words (barrier counter — 3 * D / 16 after a complete launch —, claimed XCD,
+    roles handed out); status: optional sticky int32 device word the kernel ORs _lib.TAIL_* flags into when it cannot
+    finish"""
+    assert sync.numel() >= 3
     q = _lib.RowTailArgs()
     q.dtype, q.B, q.D = dt(att), att.shape[0], Wp.shape[0]
     q.att, q.rs_att, q.resid, q.rs_res = ptr(att), att.stride(0), ptr(resid), resid.stride(0)
@@ -112,14 +115,16 @@ def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a
     q.h1, q.x1, q.h2, q.x2, q.rs_d, q.a, q.rs_a = ptr(h1), ptr(x1), ptr(h2), ptr(x2), h1.stride(0), ptr(a), a.stride(0)
     q.mean1, q.rstd1, q.mean2, q.rstd2, q.stat_stride = ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2), stat_stride
     q.eps, q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = eps, dropout_p, 0, ptr(dropout_seed_ptr), site0
-    q.phys_stride, q.sync = phys_stride, ptr(sync)
+    q.phys_stride, q.sync, q.status = phys_stride, ptr(sync), ptr(status)
     call("mst_row_tail_fwd", C.byref(q), stream())
 
 
 def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wpt, dh, dhm, dx1, dh1m, dpre, dh1, datt, dg1, db1, dg2, db2,
-                 sync, stat_stride, phys_stride, dropout_p=0.0, dropout_seed_ptr=None, site0=0):
+                 sync, stat_stride, phys_stride, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None):
     """backward of row_tail_fwd's chain in one launch (mst_row_tail_bwd); dy / h2 / h1 / a / dh1 / datt: [B, width] row views,
-    dh / dhm / dx1 / dh1m / dpre: compact [B, width] scratch; sync: one zeroed int32 device word"""
+    dh / dhm / dx1 / dh1m / dpre: compact [B, width] scratch; sync: THREE zeroed int32 device words (the barrier counter
+    ends at 2 * D / 16); status: as row_tail_fwd"""
+    assert sync.numel() >= 3
     q = _lib.RowTailBwdArgs()
     q.dtype, q.B, q.D = dt(dy), dy.shape[0], Wpt.shape[0]
     q.dy, q.rs_dy = ptr(dy), dy.stride(0)
@@ -133,7 +138,7 @@ def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wp
     q.dpre, q.rs_dpre, q.dh1, q.rs_dh1, q.datt, q.rs_datt = ptr(dpre), dpre.stride(0), ptr(dh1), dh1.stride(0), ptr(datt), datt.stride(0)
     q.dg1, q.db1, q.dg2, q.db2 = ptr(dg1), ptr(db1), ptr(dg2), ptr(db2)
     q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = dropout_p, 0, ptr(dropout_seed_ptr), site0
-    q.phys_stride, q.sync = phys_stride, ptr(sync)
+    q.phys_stride, q.sync, q.status = phys_stride, ptr(sync), ptr(status)
     call("mst_row_tail_bwd", C.byref(q), stream())
 
 
@@ -545,19 +550,37 @@ def sigmoid_bce(logits, labels, loss, B, T, P, label_smoothing=0.0, downweight=F
          ptr(dlogits), (ld(dlogits) if dlogits is not None else 0), gscale, 1 if pre_zeroed else 0, stream())
 
 
-def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None):
+def _step_metrics(metrics):
+    """dict(recon, kl, kl_weight, total, metric[, status, expect=[(int32 device word, value), ...]]) -> StepMetrics; without
+    `recon` only the step guard is carried (a second optimizer range of the same step)"""
+    mt = StepMetrics()
+    recon = metrics.get("recon")
+    mt.B, mt.recon, mt.kl = (recon.numel() if recon is not None else 0), ptr(recon), ptr(metrics.get("kl"))
+    mt.kl_weight, mt.total, mt.metric = metrics.get("kl_weight", 0.0), ptr(metrics.get("total")), ptr(metrics.get("metric"))
+    mt.status = ptr(metrics.get("status"))
+    exp = list(metrics.get("expect") or [])
+    assert len(exp) <= 2 and (not exp or metrics.get("status") is not None)
+    for i, (word, val) in enumerate(exp):
+        setattr(mt, f"expect_ptr{i}", ptr(word))
+        setattr(mt, f"expect_val{i}", int(val))
+    return mt
+
+
+def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None, guard=None):
+    """guard: dict(status=, expect=) — the step guard of mst_step_metrics (mst_loss_combine_v)"""
+    if guard:
+        mt = _step_metrics(dict(recon=recon, kl=kl, kl_weight=kl_weight, total=total, metric=metric_acc, **guard))
+        call("mst_loss_combine_v", C.byref(mt), stream())
+        return
     call("mst_loss_combine", recon.shape[0], ptr(recon), ptr(kl), kl_weight, ptr(total), ptr(metric_acc), stream())
 
 
 # --------------------------------------------------------------------------- optimizer / shadows
 def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0,
               advance_step=True, metrics=None):
-    """metrics: dict(recon, kl, kl_weight, total, metric) -> loss_combine's bookkeeping runs in this launch"""
-    mt = None
-    if metrics is not None:
-        mt = StepMetrics()
-        mt.B, mt.recon, mt.kl = metrics["recon"].numel(), ptr(metrics["recon"]), ptr(metrics["kl"])
-        mt.kl_weight, mt.total, mt.metric = metrics["kl_weight"], ptr(metrics.get("total")), ptr(metrics.get("metric"))
+    """metrics: dict(recon, kl, kl_weight, total, metric) -> loss_combine's bookkeeping runs in this launch;
+    + status / expect: the step guard (_step_metrics)"""
+    mt = _step_metrics(metrics) if metrics is not None else None
     call("mst_adam_flat", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd,
          rescale, clip, ptr(step_state), 1 if advance_step else 0, C.byref(mt) if mt is not None else None, stream())
 

@@ -125,3 +125,47 @@ def test_samplers_on_the_toy_model(gpu, tmp_path):
     assert len(files) == 3 + 3 * 3 and all(os.path.getsize(f) > 0 for f in files)
     with pytest.raises(ValueError):
         S.get_sampler("nucleus", None, None, None, A)
+
+
+def test_model_call_and_sampler_state_run_in_inference_mode(gpu):
+    """Model(...) called directly and Decoder.get_initial_state run OUTSIDE autograd.record() in the reference
+    (sampler.py:146-148), where Dropout is the identity — with e_dropout / d_dropout 0.2 (scripts/train-vae.sh) they must be
+    deterministic, agree with the dropout-free oracle, and leave the training RNG stream where it was."""
+    from music_style_transfer.VarAutoEncoder import model
+    from music_style_transfer.VarAutoEncoder.transformer import TransformerConfig
+    from music_style_transfer.VarAutoEncoder.utils import gpu as gpu_ctx
+    from oracle import vae_oracle as O
+    dims = (40, 40, 2, 16, 64, 2, 2, 32, 1, 2)
+    rng = np.random.default_rng(5)
+    ocfg = O.OracleConfig("pianoroll", *dims)
+    params = O.init_params(ocfg, rng)
+    params["encoder.latent_proj.weight"][16:] *= 0.25
+    params["encoder.latent_proj.bias"][16:] += 1.5
+    cfg = model.ModelConfig(model.EncoderConfig(TransformerConfig(64, 0.2, 2, 2, 40), 16, 2, 40),
+                            model.DecoderConfig(TransformerConfig(32, 0.2, 1, 2, 40), 16, 2, 40), kind="pianoroll")
+    m = model.Model(cfg).initialize(gpu_ctx(0), params_np=params)
+    assert m.engine_config.e_dropout == 0.2 and m.engine_config.d_dropout == 0.2
+    B, T = 4, 10
+    batch = O.synthetic_pianoroll_batch(rng, B, T, 40, num_classes=2, density=0.1, ragged=True)
+    eps = rng.standard_normal((B, 16)).astype(np.float32)
+    x, lens, cls = batch["x"].numpy(), batch["seq_lens"].numpy(), batch["classes"].numpy()
+    rng_before = m.store.rng_state(0).clone()
+    p1, mu1, sg1 = (t.clone() for t in m(x, lens, cls, eps=eps))
+    p2, mu2, sg2 = m(x, lens, cls, eps=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(mu1, mu2) and torch.equal(sg1, sg2)  # no dropout noise between two calls
+    P = O.to_torch_params(m.store.as_consumed_numpy(), requires_grad=False)
+    probs, means, stds, _ = O.model_forward(P, ocfg, batch["x"], batch["seq_lens"], batch["classes"], torch.from_numpy(eps), None)
+    assert np.abs(mu1.cpu().numpy() - means.numpy()).max() <= 5e-2 and np.abs(p1.cpu().numpy() - probs.numpy()).mean() <= 3e-3
+    # eps not given: drawn from the inference stream
+    m(x, lens, cls)
+    st1 = m.decoder.get_initial_state(x, lens, cls, t_max=4)
+    first = st1.initial_state.clone()
+    st2 = m.decoder.get_initial_state(x, lens, cls, t_max=4)
+    torch.cuda.synchronize()
+    assert torch.equal(first, st2.initial_state)
+    # decoder row 0 = sqrt(D) * (latent2hid(means) + class2hid) + pos[0] from the dropout-free means (model.py:229-232)
+    init = means.numpy() @ params["decoder.latent2hid.weight"].T + params["decoder.latent2hid.bias"] + params["decoder.class2hid.weight"][cls]
+    want = np.sqrt(32.0) * init + O.positional_encodings(32, 1)[0]
+    assert np.abs(st1.initial_state.float().cpu().numpy() - want).max() <= 0.15
+    assert torch.equal(m.store.rng_state(0), rng_before), "inference must not advance the training RNG stream"

@@ -137,6 +137,86 @@ def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     assert (f["dh1"].view(B, S, -1)[:, 1:] == 0).all() and (f["datt"].view(B, S, -1)[:, 1:] == 0).all()
 
 
+@pytest.mark.parametrize("preset", ["no_roles_left", "one_role_left"])
+def test_row_tail_reports_a_launch_that_cannot_do_its_work(gpu, preset):
+    """The one-launch tails' grid barrier needs G workgroups of the launch on one XCD. When that does not happen the kernel
+    must SAY so (sticky status word, include/mst_hip.h MST_TAIL_*) instead of carrying on silently: forced here by handing
+    out roles before the launch — every role gone (nobody works, the barrier counter stays 0) and all but one gone (the
+    lone participant waits out the 0.2 s bound of each barrier, flags it and returns instead of hanging)."""
+    from musicstyletransfer_amd import _lib
+    o = ops()
+    B, S, D = 16, 2, 256
+    F, G = 4 * D, D // 16
+    g = torch.Generator().manual_seed(3)
+    r = lambda *sh, sc=1.0, dt=BF: (torch.randn(*sh, generator=g) * sc).to(dt).to(gpu)
+    att, xin = r(B * S, D), r(B * S, D)
+    Wp, W1, W2 = r(D, D, sc=0.06), r(F, D, sc=0.06), r(D, F, sc=0.03)
+    v = lambda n: r(n, sc=0.1, dt=torch.float32)
+    row0 = lambda t: t.view(B, S, -1)[:, 0, :]
+    z = lambda w: torch.zeros(B * S, w, dtype=BF, device=gpu)
+    st = lambda: torch.zeros(B * S, device=gpu)
+    h1, x1, a, h2, x2 = z(D), z(D), z(F), z(D), z(D)
+    sync = torch.zeros(8, dtype=torch.int32, device=gpu)
+    status = torch.zeros(2, dtype=torch.int32, device=gpu)
+    sync[2] = G if preset == "no_roles_left" else G - 1
+    o.row_tail_fwd(row0(att), row0(xin), Wp, v(D), 1 + v(D), v(D), W1, v(F), W2, v(D), 1 + v(D), v(D), row0(h1), row0(x1), row0(a),
+                   row0(h2), row0(x2), st(), st(), st(), st(), sync[0:3], stat_stride=S, phys_stride=S, status=status[0:1])
+    torch.cuda.synchronize()
+    flags = int(status[0].item())
+    assert flags & _lib.TAIL_DIRTY_FWD, flags                      # the claimant did not get role 0
+    if preset == "no_roles_left":
+        assert int(sync[0].item()) == 0 and not (flags & _lib.TAIL_SPIN_FWD)
+        assert (x2 == 0).all()                                         # nothing was computed — and the flag says so
+    else:
+        assert flags & _lib.TAIL_SPIN_FWD, flags                    # the lone participant gave up waiting, three times
+        assert int(sync[0].item()) == 3                               # (its own three arrivals; a full launch ends at 3 * G)
+    # the status word is sticky: a healthy launch afterwards does not clear it
+    sync.zero_()
+    o.row_tail_fwd(row0(att), row0(xin), Wp, v(D), 1 + v(D), v(D), W1, v(F), W2, v(D), 1 + v(D), v(D), row0(h1), row0(x1), row0(a),
+                   row0(h2), row0(x2), st(), st(), st(), st(), sync[0:3], stat_stride=S, phys_stride=S, status=status[0:1])
+    torch.cuda.synchronize()
+    assert int(sync[0].item()) == 3 * G and int(status[0].item()) == flags
+
+
+def test_step_guard_skips_the_update_and_the_metric_sums(gpu):
+    """mst_adam_flat / mst_loss_combine_v with the step guard of mst_step_metrics: a set status word or a device word that
+    does not hold its expected value turns the launch into a no-op that counts the skipped step and takes the step count back"""
+    from musicstyletransfer_amd import _lib
+    o = ops()
+    n, B = 4096, 8
+    w0 = torch.randn(n, device=gpu)
+    mk = lambda: dict(w=w0.clone(), g=torch.randn(n, device=gpu), m=torch.zeros(n, device=gpu), v=torch.zeros(n, device=gpu),
+                      w16=torch.zeros(n, dtype=BF, device=gpu))
+    recon, kl = torch.rand(B, device=gpu), torch.rand(B, device=gpu)
+    total, metric = torch.zeros(B, device=gpu), torch.zeros(4, device=gpu)
+    state = torch.tensor([5, 0], dtype=torch.int32, device=gpu)
+    state.view(torch.float32)[1] = 1e-3
+    word = torch.tensor([48], dtype=torch.int32, device=gpu)
+
+    def run(status, expect_val):
+        t = mk()
+        o.adam_flat(t["w"], t["g"], t["m"], t["v"], t["w16"], state, lr=1e-3, advance_step=False,
+                    metrics=dict(recon=recon, kl=kl, kl_weight=1.0, total=total, metric=metric[:3], status=status, expect=[(word, expect_val)]))
+        torch.cuda.synchronize()
+        return t
+
+    status = torch.zeros(2, dtype=torch.int32, device=gpu)
+    t = run(status, 48)                                   # healthy: the update happens, the sums are taken
+    assert not torch.equal(t["w"], w0) and float(metric[2].item()) == B and status.tolist() == [0, 0] and int(state[0].item()) == 5
+    t = run(status, 47)                                   # expectation fails
+    assert torch.equal(t["w"], w0) and (t["m"] == 0).all() and float(metric[2].item()) == B
+    assert status.tolist() == [_lib.STEP_INCOMPLETE, 1] and int(state[0].item()) == 4
+    t = run(status, 48)                                   # sticky: still skipping although the expectation now holds
+    assert torch.equal(t["w"], w0) and status.tolist() == [_lib.STEP_INCOMPLETE, 2] and int(state[0].item()) == 3
+    o.loss_combine(recon, kl, 1.0, total, metric[:3], guard=dict(status=status, expect=[(word, 48)]))
+    torch.cuda.synchronize()
+    assert float(metric[2].item()) == B and status.tolist() == [_lib.STEP_INCOMPLETE, 3]
+    status.zero_()
+    o.loss_combine(recon, kl, 1.0, total, metric[:3], guard=dict(status=status, expect=[(word, 48)]))
+    torch.cuda.synchronize()
+    assert float(metric[2].item()) == 2 * B and status.tolist() == [0, 0]
+
+
 # ------------------------------------------------------------------------------------------ layout
 def test_selftest_layout_maps(gpu):
     flags = ops().selftest()

@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _setup(kind, dims, B, T, seed, ragged=True, sigma_bias=1.5, **hyper):
+def _setup(kind, dims, B, T, seed, ragged=True, sigma_bias=1.5, batch=None, **hyper):
     from oracle import vae_oracle as O
     from musicstyletransfer_amd import engine as E
     rng = np.random.default_rng(seed)
@@ -52,7 +52,9 @@ def _setup(kind, dims, B, T, seed, ragged=True, sigma_bias=1.5, **hyper):
     if sigma_bias:
         params["encoder.latent_proj.weight"][Z:] *= 0.25
         params["encoder.latent_proj.bias"][Z:] += sigma_bias
-    if kind == "token":
+    if batch is not None:
+        pass  # the caller's own batch (real MIDI chunks: test_token_path_script_widths_on_real_midi_chunks)
+    elif kind == "token":
         V = dims[0]
         lens = rng.integers(max(2, T // 2), T + 1, size=B) if ragged else np.full(B, T)
         x = np.zeros((B, T), np.int64)
@@ -83,7 +85,7 @@ def _cos(a, b):
 
 
 def _compare_step(gpu, kind, dims, B, T, seed, steps=2, lr=1e-3, dtype=torch.bfloat16, elbo_tol=1e-3, sigma_bias=1.5, ragged=True,
-                  grad_cos=None, check_grads=True, consumed_weights=False, max_err=None, **hyper):  # noqa: C901
+                  grad_cos=None, check_grads=True, consumed_weights=False, max_err=None, batch=None, **hyper):  # noqa: C901
     """Run `steps` training steps on the oracle and on the HIP engine and collect every out-of-tolerance
     quantity (one assertion at the end lists them all). Before every step the oracle's parameters and
     Adam state are overwritten with the engine's, so each step is compared from an IDENTICAL state at a
@@ -93,7 +95,7 @@ def _compare_step(gpu, kind, dims, B, T, seed, steps=2, lr=1e-3, dtype=torch.bfl
     consumed_weights: the oracle is given the weights AS THE KERNELS READ THEM (ParamStore.as_consumed_numpy: the 16-bit
     shadow of every GEMM weight, fp32 for the rest), which takes weight rounding out of the comparison and leaves the
     kernels' own error (16-bit activations, accumulation order)."""
-    O, E, ocfg, ecfg, params, batch, eps = _setup(kind, dims, B, T, seed, sigma_bias=sigma_bias, ragged=ragged)
+    O, E, ocfg, ecfg, params, batch, eps = _setup(kind, dims, B, T, seed, sigma_bias=sigma_bias, ragged=ragged, batch=batch)
     lat_rms = 1.2e-2 if dtype == torch.bfloat16 else 3e-3
     small = B * T < 4096  # few rows to average 16-bit rounding noise over
     bf = dtype == torch.bfloat16
@@ -258,6 +260,48 @@ def test_token_path_ragged(gpu):
     _compare_step(gpu, "token", (293, 293, 2, 32, 64, 2, 4, 32, 1, 2), B=6, T=23, seed=11)
 
 
+def midi_token_batch(batch_size=8, max_seq_len=64):
+    """one batch of the reference's own training data path: tests/golden/midi (files of work/data/guitar_bass, byte for
+    byte) -> Loader / EventBasedMIDIReader -> MelodyDataset's chunker (data.py:133-173, the EOS-column quirk of :168
+    included) -> the batch protocol of data.py:187-198 (lengths inserted, truncated to the batch's longest row). Most
+    chunks of a melody are full (65 positions), so instead of a batch of the shuffled epoch — one short row at best —
+    the rows are chosen: the ragged tail chunks of the melodies (distinct lengths) plus full chunks, both classes."""
+    from music_style_transfer.VarAutoEncoder import data as D
+    midi = os.path.join(ROOT, "tests", "golden", "midi")
+    ds, _ = D.load_dataset(D.Loader(midi, max_seq_len, 4), batch_size, 0.0)
+    lens = D.count_sequence_length(ds.tokens)
+    order = np.argsort(lens, kind="stable")
+    short = [int(i) for i in order if lens[i] < max_seq_len + 1]
+    picked, seen = [], set()
+    for i in short:  # one chunk per distinct short length
+        if int(lens[i]) not in seen and len(picked) < batch_size - 3:
+            picked.append(i)
+            seen.add(int(lens[i]))
+    for c in (0, 1, 0, 1, 0, 1, 0, 1):  # fill up with full chunks, alternating classes
+        if len(picked) == batch_size:
+            break
+        picked.append(next(int(i) for i in order[::-1] if ds.classes[i] == c and int(i) not in picked))
+    idx = np.asarray(picked)
+    b = D.preprocess_batch(D.Batch([ds.tokens[idx], ds.classes[idx]], [ds.labels[idx]], 0))
+    tokens, lens_b, classes = (np.asarray(a) for a in b.data)
+    return {"x": torch.from_numpy(tokens.astype(np.int64)), "seq_lens": torch.from_numpy(lens_b.astype(np.int64)),
+            "classes": torch.from_numpy(classes.astype(np.int64)), "labels": torch.from_numpy(np.asarray(b.label[0]).astype(np.int64))}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_token_path_script_widths_on_real_midi_chunks(gpu, dtype):
+    """BASELINE configs[0] against the oracle: scripts/train-vae.sh's own widths (:6-29 — encoder 256 x 2 layers x 8 heads,
+    decoder 128 x 1 x 8, latent 256, NUM_EVENTS = 293 tokens, 2 classes, batch 8, chunks of 64) on a batch of REAL MIDI
+    chunks produced by the data path (data.py:133-198): ragged lengths, both padding masks, EOS written into the columns
+    of every distinct length (data.py:168), SoftmaxCrossEntropy divided by the padded length (loss.py:16-23)."""
+    batch = midi_token_batch()
+    B, T = batch["x"].shape
+    assert B == 8 and T <= 65 and int(batch["seq_lens"].max()) == T
+    assert len(set(batch["seq_lens"].tolist())) >= 4 and set(batch["classes"].tolist()) == {0, 1}, "ragged rows of both classes"
+    assert int((batch["labels"] == 2).sum()) >= B  # EOS columns (more than one per row is the reference's quirk)
+    _compare_step(gpu, "token", (293, 293, 2, 256, 256, 2, 8, 128, 1, 8), B=B, T=T, seed=41, dtype=dtype, batch=batch, lr=3e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_pianoroll_small(gpu, dtype):
     _compare_step(gpu, "pianoroll", (40, 40, 2, 16, 64, 2, 2, 32, 1, 2), B=5, T=19, seed=12, dtype=dtype)
@@ -413,3 +457,79 @@ def test_full_size_config2_elbo_fp16(gpu):
     """same configuration on the fp16 MFMA path (loss-scaled gradients): ELBO within 1e-3 relative"""
     _compare_step(gpu, "pianoroll", (128, 128, 2, 64, 256, 2, 8, 128, 1, 8), B=64, T=256, seed=99, steps=1, lr=3e-4,
                   dtype=torch.float16)
+
+
+def test_a_failed_position0_tail_is_flagged_skipped_and_replaced_by_the_five_launches(gpu):
+    """VERDICT r02 item 6 / ADVICE: the one-launch position-0 tail (mst_row_tail_fwd) must not fail silently. Its roles are
+    handed out behind its back in ONE step (sync[2] pre-set between the step's bookkeeping and the tail launch): the kernel
+    flags the launch, the optimizer launch of that step leaves weights / moments / step count untouched and counts a skipped
+    step, ParamStore.read_metrics() finds the flag, warns and pins the store to the five-launch form — and the run then
+    continues to the same weights as a run that used the five launches for those steps in the first place."""
+    import warnings
+    from musicstyletransfer_amd import ops as o
+    from test_parallel_gpu import _close_after_adam
+    dims, B, T, lr = (48, 48, 2, 16, 256, 2, 8, 64, 1, 4), 6, 12, 1e-3
+    O, E, ocfg, ecfg, params, _, _ = _setup("pianoroll", dims, B, T, seed=51)
+    rng = np.random.default_rng(52)
+    batches = [O.synthetic_pianoroll_batch(rng, B, T, dims[0], num_classes=2, density=0.08, ragged=True) for _ in range(3)]
+    epss = [rng.standard_normal((B, dims[3])).astype(np.float32) for _ in range(3)]
+
+    def step(plan, i):
+        b = batches[i]
+        plan.load_batch(b["x"], b["seq_lens"], b["classes"], b["labels"], epss[i])
+        plan.step_kernels(True)
+
+    # reference run: step 0 with the one-launch tails, steps 1 and 2 with the five launches
+    ref_store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+    ref_plan = E.StepPlan(ref_store, B, T, lr=lr, clip_gradient=1.0)
+    assert ref_store.tail_checked and ref_store.tail_fused, "the start-up self-check must pass on this device"
+    step(ref_plan, 0)
+    assert ref_plan._tail_used == dict(fwd=True, bwd=True)
+    ref_store.tail_fused = False
+    step(ref_plan, 1)
+    assert ref_plan._tail_used == dict(fwd=False, bwd=False)
+    step(ref_plan, 2)
+    torch.cuda.synchronize()
+    ref_m = ref_store.read_metrics()
+
+    store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+    plan = E.StepPlan(store, B, T, lr=lr, clip_gradient=1.0)
+    fired = []
+    store.on_tail_failure(lambda: fired.append(1))
+    step(plan, 0)
+    torch.cuda.synchronize()
+    w1, t1 = store.w.clone(), int(store.step_state[0].item())
+    real, G = o.row_tail_fwd, dims[4] // 16
+
+    def sabotaged(*a, **kw):
+        plan.sync_words[2:3].fill_(G)  # every role is gone before the launch asks for one
+        return real(*a, **kw)
+
+    o.row_tail_fwd = sabotaged
+    try:
+        step(plan, 1)
+    finally:
+        o.row_tail_fwd = real
+    torch.cuda.synchronize()
+    assert torch.equal(store.w, w1) and int(store.step_state[0].item()) == t1, "the guarded optimizer must not touch the model"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        m = store.read_metrics()
+    assert any("position-0 tail" in str(c.message) for c in caught)
+    assert fired == [1] and not store.tail_fused and m["skipped_steps"] == 1 and m["count"] == B  # only step 0 was counted
+    flags, skipped = store.tail_failures[-1]
+    assert skipped == 1 and flags & 4 and flags & 16, flags   # MST_TAIL_DIRTY_FWD | MST_STEP_INCOMPLETE
+    assert store.step_status.tolist() == [0, 0]
+    step(plan, 1)  # the batch again, now through the five launches
+    assert plan._tail_used == dict(fwd=False, bwd=False)
+    step(plan, 2)
+    torch.cuda.synchronize()
+    m2 = store.read_metrics()
+    assert int(store.step_state[0].item()) == 3 and m2["count"] == 2 * B and m2["skipped_steps"] == 0
+    assert abs(m["total_sum"] + m2["total_sum"] - ref_m["total_sum"]) <= 1e-4 * abs(ref_m["total_sum"])
+    _close_after_adam(store.w.cpu().numpy(), ref_store.w.cpu().numpy(), lr, 3)
+    # MST_TAIL_FAILURE=raise: the same flag stops the run instead
+    store.tail_policy, store.tail_fused = "raise", True
+    store.step_status[0:1].fill_(1)
+    with pytest.raises(RuntimeError, match="position-0 tail"):
+        store.read_metrics()
