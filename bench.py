@@ -382,6 +382,7 @@ def run_rank(args):
     md = model_dims(c)
     cfg = E.VAEConfig(e_dropout=args.dropout, d_dropout=args.dropout, **md)
     store = E.ParamStore(cfg, dev, adt, seed=1234)  # identical initial weights on every rank
+    store.tail_policy = "raise"  # a step the step guard skipped is work not done: the number would be invalid, so the run fails loudly
     plan = E.StepPlan(store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B * world, internal_eps=True, seed=1000,
                       sample_offset=rank * B, site_base=64 * rank)
     host = synthetic_batches(4, B, T, P, seed=1234 + rank)

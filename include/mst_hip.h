@@ -578,8 +578,6 @@ typedef struct mst_step_metrics {
 } mst_step_metrics;
 #define MST_TAIL_SPIN_FWD 1u     /* a grid barrier of mst_row_tail_fwd gave up waiting */
 #define MST_TAIL_SPIN_BWD 2u     /* ... of mst_row_tail_bwd */
-#define MST_TAIL_DIRTY_FWD 4u    /* mst_row_tail_fwd found its sync words not zeroed */
-#define MST_TAIL_DIRTY_BWD 8u
 #define MST_STEP_INCOMPLETE 16u  /* an expect_ptr of the step guard did not hold its value at the end of the step */
 int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v,
                   void* w16, double lr, double beta1, double beta2, float eps, float wd,

@@ -100,8 +100,8 @@ class LnBwdIn(C.Structure):
     ]
 
 
-# flags of the sticky step-status word (include/mst_hip.h: MST_TAIL_*, MST_STEP_INCOMPLETE)
-TAIL_SPIN_FWD, TAIL_SPIN_BWD, TAIL_DIRTY_FWD, TAIL_DIRTY_BWD, STEP_INCOMPLETE = 1, 2, 4, 8, 16
+# flags of the sticky step-status word (include/mst_hip.h: MST_TAIL_SPIN_*, MST_STEP_INCOMPLETE)
+TAIL_SPIN_FWD, TAIL_SPIN_BWD, STEP_INCOMPLETE = 1, 2, 16
 
 
 class StepMetrics(C.Structure):

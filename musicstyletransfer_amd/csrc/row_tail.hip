@@ -29,11 +29,12 @@ namespace mst {
 // Status bits left in the caller's sticky device word (mst_row_tail_*_args.status, optional) when a launch could not do its work:
 //   1 / 2   a grid barrier of the forward / backward kernel gave up waiting (fewer than G workgroups of the launch were placed
 //           on the claimed XCD — CU masks, another partition mode, a co-tenant holding the CUs — so the rows behind it are stale)
-//   4 / 8   the sync words of the forward / backward launch were not zero at launch (roles were handed out wrongly or not at all)
+// A launch in which NOBODY got a role (sync words not zeroed) cannot flag itself; it leaves its barrier counter short, which is
+// what the step guard of the optimizer launch checks (mst_step_metrics.expect_ptr: MST_STEP_INCOMPLETE).
 // The optimizer launch of the same step reads the word and leaves parameters, moments and the step count untouched when it is
 // set (mst_step_metrics.status), and the host switches to the five-launch form: a failed tail costs skipped batches, never a
 // silently wrong update.
-// (MST_TAIL_SPIN_FWD / _BWD, MST_TAIL_DIRTY_FWD / _BWD of include/mst_hip.h)
+// (MST_TAIL_SPIN_FWD / _BWD of include/mst_hip.h)
 #ifndef MST_TAIL_SPIN_TICKS
 #define MST_TAIL_SPIN_TICKS 20000000ull /* 0.2 s of the 100 MHz s_memrealtime clock; a healthy barrier waits microseconds */
 #endif
@@ -153,7 +154,7 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok)
 #define MST_TAIL_OVERSUBSCRIBE 12  /* 8 is exact under round-robin dispatch; measured 8 / 10 / 12 / 16: 0.7245 / 0.7234 / 0.7256 / 0.7256 ms per step */
 #endif
 constexpr int TAIL_OVERSUBSCRIBE = MST_TAIL_OVERSUBSCRIBE;
-__device__ __forceinline__ int tail_join(uint32_t* sync, int G, uint32_t* status, uint32_t dirty_bit) {
+__device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
   __shared__ int role;
   if (threadIdx.x == 0) {
     uint32_t xcc;
@@ -166,8 +167,6 @@ __device__ __forceinline__ int tail_join(uint32_t* sync, int G, uint32_t* status
     if (claimed == xcc) {
       const uint32_t k = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k < (uint32_t)G) r = (int)k;
-      // the workgroup that claimed the XCD is the first to ask for a role: anything but role 0 means the words were not zeroed
-      if (seen == 0u && k != 0u && status) __hip_atomic_fetch_or(status, dirty_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     role = r;
   }
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = tail_join(q.sync, G, q.status, MST_TAIL_DIRTY_FWD);
+  const int g = tail_join(q.sync, G);
   if (g < 0) return;
   for (int i = tid; i < D; i += TAIL_WAVES * 64) {
     sPar[i] = q.bp[i]; sPar[D + i] = q.g1[i]; sPar[2 * D + i] = q.be1[i];
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   typedef typename std::conditional<E == 4, u32x2, uint32_t>::type raw_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
-  const int g = tail_join(q.sync, G, q.status, MST_TAIL_DIRTY_BWD);
+  const int g = tail_join(q.sync, G);
   if (g < 0) return;
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;

@@ -233,7 +233,7 @@ class ParamStore:
         self.tail_fused = False
         msg = (f"the one-launch position-0 tail of the top encoder layer failed (status flags {int(flags):#x}: "
                f"{'forward barrier timed out; ' if flags & 1 else ''}{'backward barrier timed out; ' if flags & 2 else ''}"
-               f"{'sync words not clean; ' if flags & 12 else ''}{'tail incomplete at the end of a step; ' if flags & 16 else ''}"
+               f"{'tail incomplete at the end of a step; ' if flags & 16 else ''}"
                f"{int(skipped)} step(s) skipped without touching the model)")
         if self.tail_policy == "raise":
             raise RuntimeError(msg + " — MST_TAIL_FAILURE=raise")
