@@ -10,6 +10,9 @@ the analogue of tokens=[SOS,data], labels=[data,PAD], data.py:160-168); the star
 
 `PinnedBatchPipeline` is the pinned-host -> HBM leg: batches are packed into persistent page-locked ring buffers and
 copied on a side HIP stream while the previous step computes; Trainer.fit drives it."""
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -188,12 +191,16 @@ class PinnedBatchPipeline:
     on that device blob (StepPlan.bind_inputs: no device-to-device hop). feed(dataset) runs one batch ahead: batch i+1 is
     packed and uploaded while the graph of step i executes."""
 
-    def __init__(self, device, plan_for, n_slots=3):
+    DEFAULT_SLOTS = int(os.environ.get("MST_RING_SLOTS", "3"))
+
+    def __init__(self, device, plan_for, n_slots=None):
         """plan_for(B, T) -> StepPlan (shapes change from batch to batch on the token path)"""
+        n_slots = n_slots or self.DEFAULT_SLOTS
         assert n_slots >= 2
         self.device, self.plan_for, self.n_slots = device, plan_for, n_slots
         self.stream = torch.cuda.Stream(device=device)
         self.rings = {}
+        self.stamps = None  # set to [] to collect (wait for the slot, pack, enqueue the copy) seconds per stage() call
 
     def stage(self, batch, shard=None):
         """pack + upload one batch; shard = (lo, hi) rows of the global batch this rank keeps (data parallel)"""
@@ -210,15 +217,20 @@ class PinnedBatchPipeline:
                                            "plan": plan}
         slot = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % self.n_slots
+        t0 = time.perf_counter() if self.stamps is not None else 0.0
         if slot.used:
             slot.uploaded.synchronize()  # the previous copy OUT of this host blob has finished (long ago, normally)
+        t1 = time.perf_counter() if self.stamps is not None else 0.0
         plan.pack_into(slot.host, x, seq_lens, classes, labels)
+        t2 = time.perf_counter() if self.stamps is not None else 0.0
         with torch.cuda.stream(self.stream):
             if slot.used:
                 self.stream.wait_event(slot.consumed)  # the step that read the device blob is done with it
             slot.dev.copy_(slot.host, non_blocking=True)
             slot.uploaded.record(self.stream)
         slot.used = True
+        if self.stamps is not None:
+            self.stamps.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         return StagedBatch(plan, slot, batch)
 
     def feed(self, dataset, shard_of=None):
