@@ -179,15 +179,14 @@ def kernel_families(plan, o, iters=30):
                                     resid=t.dh, partials=plan._ln_part[f"{pre}.ln1"]),
             flops=2.0 * 2.0 * M * 4 * De * De, bytes=2.0 * (M * De + 8 * De * De + 2 * M * 4 * De + 3 * M * De),
             launches_per_step=full_e, pmc_key="ffn_ln_kernel<256,2,4,2>@%d" % (((M + 63) // 64) * 512)))
+    # the K | Q | V projection runs inside the attention forward launch (mst_attn_qkv_fwd): x and the weights in, qkv (kept for the
+    # backward pass) and the attention output out
     fams.append(dict(
-        kernel=f"gemm_nt [K,Q,V projection, M={M}, N={3 * De}, K={De}]",
-        fn=lambda: o.gemm_nt(plan.x0_e, st.fused(st.w16, pre, "weight"), L.qkv, K=De, bias=st.fused(st.w, pre, "bias")),
-        flops=2.0 * M * 3 * De * De, bytes=2.0 * (M * De + 3 * De * De + M * 3 * De), launches_per_step=cfg.e_layers, pmc_key=None))
-    fams.append(dict(
-        kernel=f"attention fwd [B*H={B * H}, S={T}, dh={De // H}]",
-        fn=lambda: o.attn_fwd(L.qkv, plan.keymask_e, L.lse, L.att, B, T, H, De // H, 0, De, 2 * De),
-        flops=4.0 * B * T * T * De, bytes=2.0 * M * (3 * De + De), launches_per_step=full_e,
-        pmc_key="attn_fwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
+        kernel=f"attention fwd with the K,Q,V projection inside [B*H={B * H}, S={T}, dh={De // H}, D={De}]",
+        fn=lambda: o.attn_qkv_fwd(plan.x0_e, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, plan.keymask_e, L.lse, L.att,
+                                  B, T, H, De // H, 0, De, 2 * De),
+        flops=4.0 * B * T * T * De + 2.0 * M * 3 * De * De, bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + M * De),
+        launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
     fams.append(dict(
         kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
         fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),

@@ -339,6 +339,15 @@ int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t 
                             mst_stream_t stream);
 
 /* dqkv has the same layout as qkv; delta is fp32 scratch [B, H, S]. */
+/* The layer's K | Q | V projection AND its attention in one call (transformer.py:88-104): qkv = x W^T + bias with
+ * W [3 D, ld_w] (row c = output column c of the qkv layout, D = H * dh) and bias fp32 [3 D] is computed, written to `qkv`
+ * (the backward pass reads it) and attended to as mst_attn_keysoftmax_fwd does. For head size 32 and sequences that take the
+ * resident attention kernel the projection runs INSIDE the attention launch — every (batch, head) workgroup forms its own
+ * [S, 3 * 32] tile of the product — which saves a launch and the re-read of qkv; other shapes run mst_gemm_nt followed by
+ * mst_attn_keysoftmax_fwd. Same results either way up to the summation order of the fp32 accumulation. */
+int mst_attn_qkv_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* x, int64_t ld_x, const void* w,
+                     int64_t ld_w, const float* bias, void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                     const uint8_t* keymask, float* lse, void* out, int64_t ld_out, int64_t q_limit, mst_stream_t stream);
 int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh,
                             const void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
                             const uint8_t* keymask, const float* lse,

@@ -196,6 +196,8 @@ SIGNATURES = {
     "mst_mask_from_lengths": (C.c_int, [c_i64, c_i64, vp, c_i32, vp, vp]),
     "mst_attn_keysoftmax_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64,
                                           vp, vp, vp, c_i64, c_i64, vp]),
+    "mst_attn_qkv_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, vp, vp, vp,
+                                   c_i64, c_i64, vp]),
     "mst_attn_keysoftmax_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64,
                                           vp, vp, vp, c_i64, vp, c_i64, vp, c_i64, vp]),
     "mst_attn_decode": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_i64, c_i64, c_i64, c_i64, C.c_int, vp, c_i64, vp]),

@@ -20,6 +20,7 @@
 // staged row-major in LDS and read with ds_read_tr16_b64.
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace mst {
@@ -230,6 +231,10 @@ struct AttnArgs {
   float* delta;
   float scale;
   int64_t q_limit;  // forward: only queries [0, q_limit) are produced (the top encoder layer needs query 0 alone)
+  // fused K | Q | V projection (attn_fwd_res_kernel<.., QKV = true>): qkv = x W^T + bias is COMPUTED here (and written to
+  // `qkv` for the backward pass) instead of read. x: [B*S, ld_x] layer input; w: [3 Dm, ld_w] 16-bit weights whose row c is
+  // output column c of the qkv layout; bias: fp32 [3 Dm]
+  const void* x; int64_t ld_x; const void* w; int64_t ld_w; const float* bias; int64_t Dm;
 };
 
 // Online softmax statistics of one 32-query x 32-key tile, key on the lane.
@@ -848,7 +853,156 @@ __device__ __forceinline__ int64_t res_wg_bh(int64_t B, int64_t H) {
   return (xcd + 8 * (j / H)) * H + j % H;
 }
 
-template <typename T, int DH>
+// ---- the K | Q | V projection of ONE (batch, head) inside the attention launch (head size 32). The Dense layers' GEMM
+// (transformer.py:88-93: three Dense(D -> D) on the same input, run as one [3 D, D] product) has exactly this workgroup's
+// operands as one of its tiles: rows = the sample's S positions, columns = the head's 32 columns of K, of Q and of V. As a
+// launch of its own it cost 17.6 us and wrote 25 MB that the attention launch read straight back; here every wave forms the
+// three 32 x 32 tiles of its 32 rows (x fragments straight from global, the head's 96 weight rows staged through LDS in
+// 32-deep slices shared by the waves), adds the bias, rounds once to the activation type and leaves the SAME bits in the
+// staged LDS tiles and in `qkv` (the backward pass recomputes the probabilities from what is stored).
+// Accumulators are [feature, row-on-lane] (weights = A operand, x = B operand): owner_store's layout.
+// diagnostic build only (-DMST_ATT_STAMPS): realtime stamps (100 MHz) of the forward kernel's phases, per workgroup
+#ifdef MST_ATT_STAMPS
+__device__ uint64_t g_att_stamps[1024 * 8];
+#define ATT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_att_stamps[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ uint64_t g_att_loop[4 * 64];  // workgroups 0, 100, 300, 500: s_memtime stamps inside the projection loop
+#define LOOP_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 300 || blockIdx.x == 500) && (k) < 64) \
+    g_att_loop[(blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 300 ? 2 : 3) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATT_STAMP(k) do { } while (0)
+#define LOOP_STAMP(k) do { } while (0)
+#endif
+// Workgroup barrier that orders LDS traffic ONLY. __syncthreads() is a fence + barrier: hipcc emits s_waitcnt vmcnt(0) in front
+// of it, which drains every global load AND store in flight — stamps of the fused projection showed each of its 16 barriers
+// paying the full latency of the slices it had just requested (10.9 us for 0.6 us of MFMAs per wave) and the barrier behind its
+// epilogue waiting 6.9 us for the qkv stores to be acknowledged. Here only the LDS counter is waited for; registers that
+// global loads are still filling are tracked by the compiler's own counted waits at their first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int QKV_KC = 64;                         // contraction slice staged per step
+constexpr int QKV_LDS = QKV_KC + 8;                // row stride (elements) of the staged slices: 144-byte rows, conflict-free fragments
+constexpr int QKV_WROWS = 3 * 32;                  // the head's weight rows: 32 of K, of Q and of V
+// The slices are staged in the LDS the attention phases use afterwards for the Q / K / V tiles themselves (free until the
+// projection's epilogue writes them): x slice [SP][72] over the Q and K tiles, weight slice [96][72] over the V tile. Both are
+// fetched with whole-line loads (8 lanes x 16 bytes per row) through registers one slice ahead. A first form read every wave's x
+// fragments straight from global — 32 rows x 32 bytes per instruction, i.e. 32 cache lines touched per load — and its 8-slice
+// loop took 10.9 us per workgroup for 0.6 us of MFMAs per wave, bound by the CU's address / tag pipeline.
+template <typename T>
+__device__ __forceinline__ void qkv_prologue(const AttnArgs& a, T* sQ, T* sK, T* sV, int64_t b, int64_t hd, int NB) {
+  constexpr int DH = 32, LD = LdsLd<DH>::V;
+  static_assert(2 * LD >= QKV_LDS && QKV_WROWS * QKV_LDS <= 256 * LD, "the staged slices must fit the tiles they borrow");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int64_t S = a.S;
+  const int SP = NB * 32;
+  T* const sX = sQ;   // [SP][72]: spans the Q and K tiles (contiguous)
+  T* const sW = sV;   // [96][72]
+  const T* xg = reinterpret_cast<const T*>(a.x) + b * S * a.ld_x;
+  const T* wg = reinterpret_cast<const T*>(a.w);
+  const int nch = (int)(a.Dm / QKV_KC);
+  const int64_t sec_off[3] = {a.k_off, a.q_off, a.v_off};
+  const bool active = wave < NB;
+  const int64_t row = (int64_t)wave * 32 + (lane & 31);
+  // accumulators start at the bias: feature (8 g + 4 h + e) of the section on the register axis (owner_store's layout)
+  const int h4 = 4 * (lane >> 5);
+  f32x16 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + sec_off[c] + hd * DH + 8 * g + h4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][4 * g + e] = bv[e];
+    }
+  // staging pieces of 16 bytes: x piece p = (row p / 8, chunk p % 8) for p < SP * 8, four per thread at most (512 threads, SP <= 256);
+  // weight piece p < 768 likewise, two per thread. Rows beyond the sequence read the last row (their products are dropped below);
+  // every load is unconditional (a conditional load costs a vmcnt(0) drain at the join): surplus pieces re-read piece 0.
+  constexpr int XP = 4, WP = 2;
+  const T* xsrc[XP]; T* xdst[XP]; bool xok[XP];
+  const T* wsrc[WP]; T* wdst[WP]; bool wok[WP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int p = tid + i * nthr;
+    xok[i] = p < SP * 8;
+    const int r = xok[i] ? p >> 3 : 0, ch = xok[i] ? p & 7 : 0;
+    xsrc[i] = xg + (int64_t)(r < S ? r : S - 1) * a.ld_x + ch * 8;
+    xdst[i] = sX + r * QKV_LDS + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int p = tid + i * nthr;
+    wok[i] = p < QKV_WROWS * 8;
+    const int r = wok[i] ? p >> 3 : 0, ch = wok[i] ? p & 7 : 0;
+    wsrc[i] = wg + (sec_off[r >> 5] + hd * DH + (r & 31)) * a.ld_w + ch * 8;
+    wdst[i] = sW + r * QKV_LDS + ch * 8;
+  }
+  u32x4 xr[XP], wr[WP];
+  auto load_slice = [&](int kc) {
+    const int k = (kc < nch ? kc : nch - 1) * QKV_KC;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + k);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wr[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + k);
+  };
+  auto store_slice = [&]() {
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      if (xok[i]) *reinterpret_cast<u32x4*>(xdst[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+      if (wok[i]) *reinterpret_cast<u32x4*>(wdst[i]) = wr[i];
+  };
+  LOOP_STAMP(0);
+  load_slice(0);
+  store_slice();
+  lds_barrier();
+  LOOP_STAMP(1);
+  const T* const fx = sX + (wave * 32 + (lane & 31)) * QKV_LDS + 8 * (lane >> 5);
+  const T* const fw = sW + (lane & 31) * QKV_LDS + 8 * (lane >> 5);
+  // (Measured and not kept: the next slice's loads interleaved between the MFMAs — the loop is bound by LDS fragment traffic,
+  // 16 KB per wave and slice of which 12 are the weight fragments every wave re-reads, next to 44 KB per slice through the CU's
+  // 64-byte-per-clock load path: 9.3 -> 9.5 us either way for 3.4 us of MFMAs per SIMD.)
+  for (int kc = 0; kc < nch; ++kc) {
+    load_slice(kc + 1);  // (past the end: the last slice again)
+    LOOP_STAMP(2 + 5 * kc);
+#pragma unroll
+    for (int s4 = 0; s4 < QKV_KC / 16; ++s4) {
+      const typename Act<T>::vec8 xv = __builtin_bit_cast(typename Act<T>::vec8, *reinterpret_cast<const u32x4*>(fx + 16 * s4));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(fw + c * 32 * QKV_LDS + 16 * s4);
+        acc[c] = Act<T>::mfma32(__builtin_bit_cast(typename Act<T>::vec8, v), xv, acc[c]);
+      }
+    }
+    LOOP_STAMP(3 + 5 * kc);
+    lds_barrier();  // every wave has read this slice
+    LOOP_STAMP(4 + 5 * kc);
+    store_slice();
+    LOOP_STAMP(5 + 5 * kc);
+    lds_barrier();
+    LOOP_STAMP(6 + 5 * kc);
+  }
+  ATT_STAMP(1);
+  if (!active) return;
+  // epilogue: one rounding, the same bits to the LDS tiles and to HBM. (The stores need no wait: the barrier behind the prologue
+  // orders LDS only and the qkv rows drain under the statistics phase.)
+  const bool in = row < S;
+  T* const tiles[3] = {sK, sQ, sV};
+  T* qrow = reinterpret_cast<T*>(const_cast<void*>(a.qkv)) + (b * S + row) * a.ld_qkv + hd * DH;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x2 o = {0u, 0u};
+      if (in) {
+        o[0] = (uint32_t)f32_to_bits<T>(acc[c][4 * g]) | ((uint32_t)f32_to_bits<T>(acc[c][4 * g + 1]) << 16);
+        o[1] = (uint32_t)f32_to_bits<T>(acc[c][4 * g + 2]) | ((uint32_t)f32_to_bits<T>(acc[c][4 * g + 3]) << 16);
+        *reinterpret_cast<u32x2*>(qrow + sec_off[c] + 8 * g + h4) = o;
+      }
+      *reinterpret_cast<u32x2*>(tiles[c] + row * LD + 8 * g + h4) = o;  // (rows beyond the sequence: zeros, as stage_all leaves them)
+    }
+  }
+}
+
+template <typename T, int DH, bool QKV = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_FWD : 4))) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
@@ -866,10 +1020,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   const bool lone = lone_row_shape(S, DH) && a.q_limit >= S;  // the last row is handled apart (above)
   const int NBo = lone ? NB - 1 : NB;                            // owner blocks swept with MFMA tiles
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
-  stage_all<T, DH>(sQ, base + a.q_off, a.ld_qkv, S, SP, tid, nthr);
-  stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
-  stage_all<T, DH>(sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
-  __syncthreads();
+  ATT_STAMP(0);
+  if constexpr (QKV) {
+    static_assert(DH == 32, "the fused projection is built for head size 32");
+    qkv_prologue<T>(a, sQ, sK, sV, b, hd, NB);
+  } else {
+    stage_all<T, DH>(sQ, base + a.q_off, a.ld_qkv, S, SP, tid, nthr);
+    stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
+    stage_all<T, DH>(sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
+  }
+  if constexpr (QKV) lds_barrier();  // (the qkv stores of the projection's epilogue drain under the statistics phase)
+  else __syncthreads();
+  ATT_STAMP(2);
 
   // ---- phase A: softmax statistics of every key row (the arithmetic of attn_fwd_stats_kernel)
   int padded = 0;
@@ -929,6 +1091,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     }
   }
   const bool exact = __syncthreads_or(padded);  // does this sequence hold a padded key?
+  ATT_STAMP(3);
 
   // ---- phase B: O = P^T V for the owned queries (attn_fwd_out_kernel's tiles)
   for (int ob = wave; ob < NBo; ob += NW) {
@@ -954,6 +1117,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     const int64_t q_lane = ob * 32 + (lane & 31);
     owner_store<T, DH>((q_lane < S && q_lane < a.q_limit) ? og + q_lane * a.ld_out : nullptr, o, lane);
   }
+  ATT_STAMP(4);
   if constexpr (DH <= 16) {
     if (lone) {  // O[e] = sum_k P[k,e] V[k]: keys on the lanes (P stays fp32 here; the MFMA form rounds it to the activation type)
       const int64_t e = S - 1;
@@ -1256,6 +1420,31 @@ static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, i
   return MST_OK;
 }
 
+// the fused-projection launch: 1 when it ran, 0 when this shape does not take it (the caller then runs the projection GEMM and the
+// plain launch), negative on error
+template <typename T>
+static int launch_fwd_qkv(const AttnArgs& a, hipStream_t s) {
+  constexpr int DH = 32;
+  const char* off = getenv("MST_ATTN_QKV");
+  if (off && off[0] == '0') return 0;
+  const size_t lds = res_lds_fwd<DH>(a.S);  // (the projection's slices borrow the Q / K / V tiles)
+  const int NB = (int)cdiv(a.S, 32);
+  const int nw = choose_resident(a.S, a.B * a.H, lds, 16, false);
+  // every owner block needs its own wave (one pass over the weight slices); the staging pattern is laid out for 512 threads
+  // (four x pieces and two weight pieces per thread; the weight slice must fit the V tile: NB >= 6)
+  if (nw < NB || nw < 6 || a.Dm % QKV_KC != 0 || a.Dm != a.H * DH) return 0;
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("attn_fwd_res_kernel (fused projection): LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((attn_fwd_res_kernel<T, DH, true>), dim3((unsigned)(a.B * a.H)), dim3(nw * 64), lds, s, a);
+  MST_CHECK_LAUNCH("attn_fwd_res_kernel (fused projection)");
+  return 1;
+}
+
 template <typename T, int DH>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_fwd<DH>(a.S);
@@ -1384,6 +1573,47 @@ extern "C" int mst_attn_keysoftmax_fwd(int dtype, int64_t B, int64_t S, int64_t 
     if (dh == 32) return launch_fwd<T, 32>(a, s);
     return launch_fwd<T, 64>(a, s);
   });
+}
+
+#ifdef MST_ATT_STAMPS
+extern "C" int mst_debug_att_loop(uint64_t* host_out) {  // diagnostic builds only
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_att_loop), sizeof(uint64_t) * 256) == hipSuccess ? 0 : -1;
+}
+extern "C" int mst_debug_att_stamps(uint64_t* host_out) {  // diagnostic builds only: 1024 x 8 realtime stamps
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_att_stamps), sizeof(uint64_t) * 8192) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int mst_attn_qkv_fwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* x, int64_t ld_x, const void* w,
+                                int64_t ld_w, const float* bias, void* qkv, int64_t ld_qkv, int64_t k_off, int64_t q_off, int64_t v_off,
+                                const uint8_t* keymask, float* lse, void* out, int64_t ld_out, int64_t q_limit, mst_stream_t stream) {
+  int rc = attn_check(B, S, H, dh, ld_qkv, k_off, q_off, v_off);
+  if (rc) return rc;
+  const int64_t Dm = H * dh;
+  MST_CHECK_ARG(x && w && bias && qkv && keymask && lse && out, "mst_attn_qkv_fwd: null pointer");
+  MST_CHECK_ARG(ld_x % 8 == 0 && ld_x >= Dm && ld_w % 8 == 0 && ld_w >= Dm && ld_qkv >= 3 * Dm && ld_out >= Dm,
+                "mst_attn_qkv_fwd: leading dimensions must be multiples of 8 and cover the model width");
+  MST_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)bias % 16 == 0) && ((uintptr_t)qkv % 16 == 0),
+                "mst_attn_qkv_fwd: operands must be 16-byte aligned");
+  MST_CHECK_ARG(k_off + Dm <= 3 * Dm && q_off + Dm <= 3 * Dm && v_off + Dm <= 3 * Dm, "mst_attn_qkv_fwd: section offsets beyond the 3 D weight rows");
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 32) {
+    AttnArgs a = {};
+    a.B = B; a.S = S; a.H = H; a.qkv = qkv; a.ld_qkv = ld_qkv; a.k_off = k_off; a.q_off = q_off; a.v_off = v_off;
+    a.keymask = keymask; a.lse = lse; a.out = out; a.ld_out = ld_out;
+    a.q_limit = (q_limit > 0 && q_limit < S) ? q_limit : S;
+    a.scale = 1.f / sqrtf((float)dh);
+    a.x = x; a.ld_x = ld_x; a.w = w; a.ld_w = ld_w; a.bias = bias; a.Dm = Dm;
+    rc = dispatch_act(dtype, [&](auto tag) -> int { return launch_fwd_qkv<decltype(tag)>(a, s); });
+    if (rc != 0) return rc < 0 ? rc : MST_OK;
+  }
+  // shapes the fused form does not take: the projection as the GEMM it is, then the plain attention launch
+  mst_gemm_args g = {};
+  g.dtype = dtype; g.M = B * S; g.N = 3 * Dm; g.K = Dm;
+  g.A = x; g.lda = ld_x; g.B = w; g.ldb = ld_w; g.C = qkv; g.ldc = ld_qkv; g.bias = bias; g.alpha = 1.f;
+  rc = mst_gemm_nt(&g, stream);
+  if (rc) return rc;
+  return mst_attn_keysoftmax_fwd(dtype, B, S, H, dh, qkv, ld_qkv, k_off, q_off, v_off, keymask, lse, out, ld_out, q_limit, stream);
 }
 
 extern "C" int mst_attn_keysoftmax_bwd(int dtype, int64_t B, int64_t S, int64_t H, int64_t dh, const void* qkv,

@@ -733,8 +733,9 @@ class StepPlan:
         def row0(buf):
             return buf.view(B, S, -1)[:, 0, :]
 
-        o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
-        o.attn_fwd(L.qkv, self.keymask_e, L.lse, L.att, B, S, H, D // H, 0, D, 2 * D, q_limit=1)
+        # (the K | Q | V projection runs inside the attention launch where the shape allows: mst_attn_qkv_fwd)
+        o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, self.keymask_e, L.lse, L.att, B, S, H,
+                       D // H, 0, D, 2 * D, q_limit=1)
         self._tail_used["fwd"] = self._tail_on(D)
         if self._tail_used["fwd"]:  # W_proj, LN1, FFN1, FFN2, LN2 on the B position-0 rows in one launch (mst_row_tail_fwd)
             o.row_tail_fwd(row0(L.att), row0(x_in), st.h(f"{pre}.att.W_proj.weight"), st.p(f"{pre}.att.W_proj.bias"),
@@ -763,8 +764,8 @@ class StepPlan:
         dh = D // H
         if side == "encoder" and i == self.cfg.e_layers - 1:
             return self._top_encoder_layer_fwd(i, L, x_in)
-        o.gemm_nt(x_in, st.fused(st.w16, pre, "weight"), L.qkv, K=D, bias=st.fused(st.w, pre, "bias"))
-        o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
+        o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
+                       0, D, 2 * D)
         # (Dense + LayerNorm in one launch, ops.gemm_nt_ln_fwd, does not pay in the forward pass: graph-replay timings at
         # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
         # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM

@@ -409,6 +409,13 @@ def attn_fwd(qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off, q_limit=0
          ptr(lse), ptr(out), ld(out), q_limit, stream())
 
 
+def attn_qkv_fwd(x, W, bias, qkv, keymask, lse, out, B, S, H, dh, k_off, q_off, v_off, q_limit=0):
+    """qkv = x W^T + bias (written: the backward pass reads it) and attn_fwd on it, the projection inside the attention launch
+    where the shape allows (mst_attn_qkv_fwd)"""
+    call("mst_attn_qkv_fwd", dt(qkv), B, S, H, dh, ptr(x), ld(x), ptr(W), ld(W), ptr(bias), ptr(qkv), ld(qkv), k_off, q_off, v_off,
+         ptr(keymask), ptr(lse), ptr(out), ld(out), q_limit, stream())
+
+
 def attn_bwd(qkv, keymask, lse, dout, dqkv, delta, B, S, H, dh, k_off, q_off, v_off, q_limit=0):
     """q_limit > 0: rows [q_limit, S) of every sample of dout are zero (see the header)"""
     call("mst_attn_keysoftmax_bwd", dt(qkv), B, S, H, dh, ptr(qkv), ld(qkv), k_off, q_off, v_off, ptr(keymask),

@@ -831,6 +831,47 @@ def attn_reference(qkv, keymask, B, S, H, dh, k_off, q_off, v_off):
     return O.permute(0, 2, 1, 3).reshape(B * S, D), torch.logsumexp(logits, dim=-1)
 
 
+@pytest.mark.parametrize("B,S,H,dh,q_limit,dtype", [(8, 256, 8, 32, 0, BF), (3, 200, 4, 32, 0, BF), (8, 256, 8, 32, 1, BF), (5, 96, 2, 32, 0, torch.float16),
+                                                   (4, 64, 4, 16, 0, BF), (2, 640, 2, 32, 0, BF)])
+def test_attention_with_fused_projection_equals_gemm_then_attention(gpu, B, S, H, dh, q_limit, dtype):
+    """mst_attn_qkv_fwd: the K | Q | V projection inside the attention launch (head size 32, resident sequences) against the GEMM
+    launch followed by the attention launch — same qkv to a rounding of the activation type (another fp32 summation order), same
+    statistics and output to the tolerance that leaves; ragged lengths take the padded-key path. Head size 16 and sequences beyond
+    the resident kernel run the two launches inside the call and must agree exactly."""
+    o = ops()
+    D = H * dh
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B * S, D, generator=g)).to(dtype).to(gpu)
+    W = (torch.randn(3 * D, D, generator=g) * (1.5 / D ** 0.5)).to(dtype).to(gpu)
+    bias = (torch.randn(3 * D, generator=g) * 0.2).to(gpu)
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    lens[0] = S
+    keymask = (torch.arange(S).view(1, S) < lens.view(B, 1)).to(torch.uint8).to(gpu)
+
+    def bufs():
+        return (torch.zeros(B * S, 3 * D, dtype=dtype, device=gpu), torch.zeros(2, B, H, S, device=gpu), torch.zeros(B * S, D, dtype=dtype, device=gpu))
+
+    qkv_a, lse_a, out_a = bufs()
+    o.gemm_nt(x, W, qkv_a, K=D, bias=bias)
+    o.attn_fwd(qkv_a, keymask, lse_a, out_a, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
+    qkv_b, lse_b, out_b = bufs()
+    o.attn_qkv_fwd(x, W, bias, qkv_b, keymask, lse_b, out_b, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
+    torch.cuda.synchronize()
+    fused_shape = dh == 32 and S <= 256
+    if not fused_shape:
+        assert torch.equal(qkv_a, qkv_b) and torch.equal(out_a, out_b) and torch.equal(lse_a, lse_b)
+        return
+    ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
+    d = (qkv_b.float() - qkv_a.float()).abs()
+    assert (d <= ulp * qkv_a.float().abs().clamp(min=1.0)).all(), d.max().item()
+    assert (qkv_a != qkv_b).float().mean().item() < 0.02
+    ref = x.float() @ W.float().t() + bias
+    close(qkv_b, ref, 2 * ulp, 2 * ulp, "fused projection vs fp32")
+    rows = slice(None) if q_limit == 0 else slice(0, None, S)  # (q_limit = 1: only position 0 of every sample is produced)
+    close(out_b[rows], out_a[rows], 3e-2, 3e-2, "attention output")
+    close(lse_b.sum(0), lse_a.sum(0), 1e-3, 2e-2, "log-sum-exp of the key rows")
+
+
 @pytest.mark.parametrize("B,S,H,dh", [(2, 64, 2, 32), (3, 5, 2, 16), (2, 257, 8, 16), (2, 256, 8, 32), (1, 100, 1, 64),
                                      (1, 1024, 2, 32)])
 @pytest.mark.parametrize("path", ["auto", "stream"])
