@@ -7,7 +7,10 @@ As in the reference, `pred` is what `Model(...)` returns:
   BinaryCrossEntropy(from_sigmoid=False)(pred, labels)     pre-sigmoid outputs; loss.py:40-42 applies the sigmoid
 so `loss(Model(...)[0], labels)` means what it means there. The training step does not go through these classes:
 engine.StepPlan fuses softmax / sigmoid, the loss and its gradient over the 16-bit output-layer result in one pass. That
-fused form is reachable here as an explicit extra, `from_logits=True` (pre-activation input, 16-bit)."""
+fused form is reachable here as an explicit extra, `pre_activation=True` (pre-softmax input in the 16-bit activation type).
+The extra is NOT spelled `from_logits`: in gluon's SoftmaxCrossEntropyLoss, which the reference subclasses (loss.py:15),
+from_logits=True means the input already holds LOG-probabilities — a caller passing that flag would silently get another
+function, so it is rejected."""
 import torch
 
 from .. import ops as o
@@ -21,11 +24,13 @@ def _rows(pred):
 
 
 def _padded_logits(pred):
-    """the fused kernels read 16-bit rows whose leading dimension is a multiple of 8 elements"""
+    """the fused kernels read 16-bit rows whose leading dimension is a multiple of 8 elements; an fp32 input would have to be
+    rounded to 16 bits first, which changes the result — the caller decides that, not this helper"""
     B, T, V = pred.shape
     ld = o.roundup(V, 8)
     if pred.dtype not in (torch.bfloat16, torch.float16):
-        pred = pred.to(torch.bfloat16)
+        raise TypeError(f"pre-activation inputs must be bfloat16 or float16 (what the output layer produces), got {pred.dtype}: "
+                        "round them explicitly (pred.to(torch.bfloat16)) or pass probabilities")
     if ld == V and pred.is_contiguous():
         return pred.view(B * T, V)
     logits = torch.zeros(B * T, ld, dtype=pred.dtype, device=pred.device)
@@ -43,15 +48,18 @@ class VariationalKLLoss:
 
 
 class SoftmaxCrossEntropy:
-    def __init__(self, axis=-1, batch_axis=0, from_logits=False):
+    def __init__(self, axis=-1, batch_axis=0, pre_activation=False, from_logits=False, **unused):
         assert axis in (-1, 2) and batch_axis == 0
-        self.from_logits = from_logits
+        if from_logits:
+            raise ValueError("from_logits=True (gluon: the input holds log-probabilities) is not what this path computes; the "
+                             "reference calls the loss on probabilities (loss.py:21). For pre-softmax inputs use pre_activation=True")
+        self.pre_activation = pre_activation
 
     def __call__(self, pred, label):
         B, T, V = pred.shape
         loss = torch.zeros(B, dtype=torch.float32, device=pred.device)
         labels = label.to(torch.int32).contiguous().view(-1)
-        if self.from_logits:
+        if self.pre_activation:
             o.softmax_ce(_padded_logits(pred), labels, loss, B, T, V)
         else:
             o.ce_from_probs(_rows(pred), labels, loss, B, T, V)

@@ -151,6 +151,10 @@ class Model:
     # padded keys are not excluded (transformer.py:100,111-125), so extra padded positions change the result — hence a
     # least-recently-used cache with a byte cap instead (MST_PLAN_CACHE_GB, default 64 of the 288 GB).
     PLAN_CACHE_BYTES = int(float(os.environ.get("MST_PLAN_CACHE_GB", "64")) * (1 << 30))
+    # ... and a cap on the NUMBER of cached shapes: what hangs off a plan besides its own buffers — the trainer's captured graphs
+    # (one per input ring slot and mode), the batcher's ring of page-locked host blobs and their device twins (plan.extra_bytes,
+    # reported by PinnedBatchPipeline) — is not all visible as device bytes
+    PLAN_CACHE_MAX = int(os.environ.get("MST_PLAN_CACHE_MAX", "48"))
 
     def plan(self, B, T, **hyper):
         key = (B, T, tuple(sorted(hyper.items())))
@@ -160,12 +164,13 @@ class Model:
             before = torch.cuda.memory_allocated(dev)
             plan = E.StepPlan(self.store, B, T, **hyper)
             plan.cache_bytes = max(0, torch.cuda.memory_allocated(dev) - before)
-            total = plan.cache_bytes + sum(p.cache_bytes for p in self._plans.values())
-            while self._plans and total > self.PLAN_CACHE_BYTES:
+            plan.extra_bytes = 0  # input rings etc. created for this plan later (PinnedBatchPipeline.stage)
+            total = plan.cache_bytes + sum(p.cache_bytes + getattr(p, "extra_bytes", 0) for p in self._plans.values())
+            while self._plans and (total > self.PLAN_CACHE_BYTES or len(self._plans) >= self.PLAN_CACHE_MAX):
                 old_key = next(iter(self._plans))  # least recently used first
                 old = self._plans.pop(old_key)
                 torch.cuda.synchronize(dev)  # nothing in flight may still read its buffers / graphs
-                total -= old.cache_bytes
+                total -= old.cache_bytes + getattr(old, "extra_bytes", 0)
                 for cb in self._evict_hooks:
                     cb(old)
         self._plans[key] = plan  # most recently used last

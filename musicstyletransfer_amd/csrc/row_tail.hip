@@ -127,9 +127,12 @@ __device__ __forceinline__ typename Act<T>::vec8 frag16_sc1(const T* p, bool ok)
   return __builtin_bit_cast(typename Act<T>::vec8, v);
 }
 
-// diagnostic build only (-DMST_TAIL_STAMPS): workgroup 0 leaves s_memrealtime stamps (100 MHz) in sync[8 + i]
+// diagnostic build only (-DMST_TAIL_STAMPS): workgroup 0 leaves s_memrealtime stamps (100 MHz) in a device array of its own, read
+// back with mst_debug_tail_stamps (they used to go behind the caller's three sync words, i.e. out of bounds for any caller but
+// the stamp tools)
 #ifdef MST_TAIL_STAMPS
-#define TAIL_STAMP(i) do { if (g == 0 && threadIdx.x == 0) q.sync[8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ uint32_t g_tail_stamps[32];
+#define TAIL_STAMP(i) do { if (g == 0 && threadIdx.x == 0 && (i) < 32) g_tail_stamps[(i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TAIL_STAMP(i) do { } while (0)
 #endif
@@ -712,6 +715,12 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
 }  // namespace mst
 
 using namespace mst;
+
+#ifdef MST_TAIL_STAMPS
+extern "C" int mst_debug_tail_stamps(uint32_t* host_out) {  // diagnostic builds only: 32 realtime stamps of the last tail launch
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mst::g_tail_stamps), sizeof(uint32_t) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr, "mst_row_tail_fwd: null args");

@@ -215,6 +215,8 @@ class PinnedBatchPipeline:
         if ring is None:
             ring = self.rings[id(plan)] = {"slots": [_Slot(plan.own_inbuf.numel(), self.device) for _ in range(self.n_slots)], "next": 0,
                                            "plan": plan}
+            # (page-locked host blob + device twin per slot: counted against the plan cache's byte budget, model.Model.plan)
+            plan.extra_bytes = getattr(plan, "extra_bytes", 0) + 2 * self.n_slots * plan.own_inbuf.numel()
         slot = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % self.n_slots
         t0 = time.perf_counter() if self.stamps is not None else 0.0

@@ -94,7 +94,7 @@ def test_model_call_matches_committed_oracle_fixture(gpu):
 def test_loss_classes_keep_the_reference_call_semantics(gpu):
     """loss.py:16-23,40-56: the losses take what Model(...) returns — PROBABILITIES for SoftmaxCrossEntropy and for
     BinaryCrossEntropy(from_sigmoid=True), pre-sigmoid outputs for from_sigmoid=False; the fused logit form of the
-    training step is the explicit extra from_logits=True"""
+    training step is the explicit extra pre_activation=True"""
     from music_style_transfer.VarAutoEncoder import loss
     from oracle import vae_oracle as O
     g = torch.Generator().manual_seed(0)
@@ -107,8 +107,12 @@ def test_loss_classes_keep_the_reference_call_semantics(gpu):
         ce = loss.SoftmaxCrossEntropy(axis=-1, batch_axis=0)(p_in.cuda(), labels.cuda())
         want = O.softmax_cross_entropy(p_in.float(), labels)
         assert torch.allclose(ce.cpu(), want, rtol=1e-5, atol=1e-6)
-    ce_l = loss.SoftmaxCrossEntropy(from_logits=True)(logits.cuda(), labels.cuda())
+    ce_l = loss.SoftmaxCrossEntropy(pre_activation=True)(logits.cuda(), labels.cuda())
     assert torch.allclose(ce_l.cpu(), ref, rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError, match="log-probabilities"):  # gluon's meaning of from_logits is not what is computed here
+        loss.SoftmaxCrossEntropy(from_logits=True)
+    with pytest.raises(TypeError, match="bfloat16 or float16"):  # no silent rounding of fp32 pre-activations
+        loss.SoftmaxCrossEntropy(pre_activation=True)(logits.float().cuda(), labels.cuda())
     y = (torch.rand(B, T, V, generator=g) < 0.2).to(torch.uint8)
     for ls, dw in ((0.1, True), (0.0, False)):
         sig = torch.sigmoid(logits.float())

@@ -19,6 +19,16 @@ z = lambda n, w: torch.zeros(n, w, dtype=BF, device=dev)
 dh, dhm, dx1, dh1m, dpre, dh1, datt = z(B, D), z(B, D), z(B, D), z(B, D), z(B, F), z(B * S, D), z(B * S, D)
 dg = [torch.zeros(D, device=dev) for _ in range(4)]
 sync = torch.zeros(32, dtype=torch.int32, device=dev)
+
+
+def tail_stamps():
+    """the stamps the -DMST_TAIL_STAMPS build keeps in a device array of its own (mst_debug_tail_stamps)"""
+    import ctypes as C
+    from musicstyletransfer_amd import _lib
+    buf = (C.c_uint32 * 32)()
+    assert _lib.load().mst_debug_tail_stamps(buf) == 0
+    return np.array(list(buf), dtype=np.int64)
+
 flush = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
 names = ["LN2 bwd (+W2t to LDS)", "FFN2 dgrad slice", "barrier 1", "FFN1 dgrad slice", "barrier 2", "LN1 bwd", "W_proj dgrad"]  # q.sync = sync[0:]: stamps at sync[8 + i]
 for it in range(10):
@@ -28,7 +38,7 @@ for it in range(10):
     o.row_tail_bwd(row0(dy), row0(h2), row0(h1), row0(a), m1, r1, m2, r2, g1, g2, W2t, W1t, Wpt, dh, dhm, dx1, dh1m, dpre, row0(dh1), row0(datt),
                    dg[0], dg[1], dg[2], dg[3], sync[0:3], stat_stride=S, phys_stride=S, dropout_p=0.2, dropout_seed_ptr=seedp, site0=6)
     e1.record(); torch.cuda.synchronize()
-    t = sync[8:16].cpu().numpy().astype(np.int64)
+    t = tail_stamps()[:8]
     d = (np.diff(t) & 0xffffffff) / 100.0  # stamps 0..7: stage 1 | stage 2 | barrier 1 | stage 3 | barrier 2 | stage 4 | stage 5
     if it >= 3:
         print("event %.1f us | " % (e0.elapsed_time(e1) * 1e3) + " ".join("%s %.1f" % (n, v) for n, v in zip(names, d)) + " | sum %.1f" % d.sum())

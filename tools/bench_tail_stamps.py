@@ -17,6 +17,16 @@ z = lambda w: torch.zeros(B * S, w, dtype=BF, device=dev)
 h1, x1, a, h2, x2 = z(D), z(D), z(F), z(D), z(D)
 st = [torch.zeros(B * S, device=dev) for _ in range(4)]
 sync = torch.zeros(32, dtype=torch.int32, device=dev)
+
+
+def tail_stamps():
+    """the stamps the -DMST_TAIL_STAMPS build keeps in a device array of its own (mst_debug_tail_stamps)"""
+    import ctypes as C
+    from musicstyletransfer_amd import _lib
+    buf = (C.c_uint32 * 32)()
+    assert _lib.load().mst_debug_tail_stamps(buf) == 0
+    return np.array(list(buf), dtype=np.int64)
+
 flush = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
 rows = []
 for it in range(12):
@@ -27,7 +37,7 @@ for it in range(12):
     o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(h1), row0(x1), row0(a), row0(h2), row0(x2),
                    st[0], st[1], st[2], st[3], sync[0:3], stat_stride=S, phys_stride=S, dropout_p=0.2, dropout_seed_ptr=seedp, site0=6)
     e1.record(); torch.cuda.synchronize()
-    t = sync[8:20].cpu().numpy().astype(np.int64)
+    t = tail_stamps()[:12]
     inner = [((t[16 - 8] - t[2]) & 0xffffffff) / 100.0, ((t[17 - 8] - t[16 - 8]) & 0xffffffff) / 100.0, ((t[18 - 8] - t[17 - 8]) & 0xffffffff) / 100.0,
              ((t[19 - 8] - t[18 - 8]) & 0xffffffff) / 100.0, ((t[3] - t[19 - 8]) & 0xffffffff) / 100.0]
     rows.append((e0.elapsed_time(e1) * 1e3, (np.diff(t[:8]) & 0xffffffff) / 100.0, inner))
