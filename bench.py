@@ -255,6 +255,9 @@ def parse_args(argv=None):
     ap.add_argument("--dropout", type=float, default=DROPOUT)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="default: the configuration's own")
     ap.add_argument("--ring-slots", type=int, default=None, help="--data host: slots of the pinned ring (default: MST_RING_SLOTS or the pipeline's own)")
+    ap.add_argument("--decode", action="store_true",
+                    help="instead of the training step: beam-search decoding with the per-layer K|Q|V caches (SURVEY §8f rank 4), "
+                         "token ends at scripts/train-vae.sh's widths, batch 64 x beam 4 hypotheses; prints ONE JSON line (tokens/s)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no launcher: start the N rank processes, have each print its rendezvous environment "
                          "as one JSON line and exit (no GPU, no torch): a test of the launcher itself")
@@ -349,7 +352,81 @@ def main(argv=None):
         return launch_ranks(args, argv)
     if args.dry_launch:
         return dry_rank()
+    if args.decode:
+        return run_decode(args)
     return run_rank(args)
+
+
+def run_decode(args):
+    """Beam-search decoding throughput (reference sampler.py:198-257 over model.py:259-272): B = 64 melodies x beam 4 = 256
+    hypotheses, each position = one captured graph of the decoder's incremental step (decode.DecodePlan) + the host's
+    top-k over beam x V. A "step" here is one decoded position of all hypotheses; --steps positions are timed after
+    --warmup positions (which also capture the graphs). Random-initialised weights, synthetic token batch."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decode step has no CPU fallback")
+    torch.cuda.set_device(0)
+    from musicstyletransfer_amd import ops as o
+    from musicstyletransfer_amd.MIDIUtil.defaults import NUM_EVENTS
+    from musicstyletransfer_amd.VarAutoEncoder import model as M, sampler as S
+    from musicstyletransfer_amd.VarAutoEncoder.data import Batch
+    from musicstyletransfer_amd.VarAutoEncoder.transformer import TransformerConfig
+    from musicstyletransfer_amd.VarAutoEncoder.utils import gpu, limit_host_threads
+    limit_host_threads()
+    B, K, T, Z = 64, 4, 64, 256  # scripts/train-vae.sh: --max-seq-len 64, --latent-dim 256
+    cfg = M.ModelConfig(M.EncoderConfig(TransformerConfig(256, 0.2, 2, 8, NUM_EVENTS), Z, 2, NUM_EVENTS),
+                        M.DecoderConfig(TransformerConfig(128, 0.2, 1, 8, NUM_EVENTS), Z, 2, NUM_EVENTS))
+    m = M.Model(cfg).initialize(gpu(0), seed=1234)
+    rng = np.random.default_rng(1234)
+    tokens = rng.integers(3, NUM_EVENTS, size=(B, T + 1))
+    tokens[:, 0] = 1
+    batch = Batch([tokens, np.full(B, T + 1), rng.integers(0, 2, size=B)], [np.zeros_like(tokens)])
+    positions = max(8, min(args.steps, 2 * (T + 1) - 2))
+    warm = max(2, min(args.warmup, 8))
+
+    class A:
+        verbose, beam_size = False, K
+
+    smp = S.get_sampler("beam-search", None, None, None, A)
+    smp.update_parameters(m)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(warm):  # (captures every position's graph on the first pass; the second replays)
+            smp.sample(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 0
+        n_pos = 0
+        while reps < 3 or n_pos < positions:
+            smp.sample(batch)
+            n_pos += smp.positions_decoded
+            reps += 1
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # the device part alone: replay the captured positions of the plan back to back (no host top-k, no copies)
+        plan = m.decode_plan(B * K, 2 * (T + 1) + 1, "query")
+        plan.reset()
+        with torch.cuda.stream(plan.stream):
+            ts = sorted(plan._graphs)
+            e0, e1 = o.Event(), o.Event()
+            e0.record()
+            for t in ts:
+                plan._graphs[t].launch()
+            e1.record()
+            e1.sync()
+            dev_us = e0.elapsed_ms(e1) * 1e3 / max(len(ts), 1)
+    tok_s = B * K * n_pos / elapsed
+    out = {"metric": "decoded tokens/s (beam search, KV-cache decode step)", "value": tok_s, "unit": "tokens/s", "n_gpus": 1,
+           "steps": n_pos, "warmup": warm, "ms_per_step": elapsed / n_pos * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"beam search over the incremental decoder (sampler.py:198-257): {B} melodies x beam {K} = {B * K} hypotheses, "
+                                  f"input length {T + 1}, up to {2 * (T + 1)} positions, token ends V={NUM_EVENTS}, decoder 128x1x8h, latent {Z}; "
+                                  "a step = one position of all hypotheses (captured graph + host top-k over beam x V)",
+                      "hypotheses": B * K, "beam": K, "positions_per_sequence": smp.positions_decoded},
+           "device_us_per_position": dev_us, "host_share": 1.0 - dev_us * 1e-6 * n_pos / elapsed,
+           "graphs_captured": len(plan._graphs)}
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def run_rank(args):

@@ -97,7 +97,7 @@ class _Decoder:
         row0 = plan.x0_d.view(B, T + 1, -1)[:, 0, :]
         if beam > 1:
             row0 = row0.repeat_interleave(beam, dim=0)
-        dplan = decode.DecodePlan(m.store, B * beam, t_max, attention=attention)
+        dplan = m.decode_plan(B * beam, t_max, attention)
         dplan.start(row0.contiguous())
         return DecoderState(B * beam, cfg.d_layers, row0, dplan)
 
@@ -174,6 +174,25 @@ class Model:
                 for cb in self._evict_hooks:
                     cb(old)
         self._plans[key] = plan  # most recently used last
+        return plan
+
+    DECODE_PLAN_MAX = 8
+
+    def decode_plan(self, n_hyp, t_max, attention="query"):
+        """the DecodePlan (caches + one captured graph per position) of this many hypotheses / positions, kept across
+        batches: a sampler that decodes batch after batch of one shape captures its graphs once"""
+        from .. import decode
+        if not hasattr(self, "_decode_plans") or getattr(self, "_decode_store", None) is not self.store:
+            self._decode_plans, self._decode_store = OrderedDict(), self.store
+        key = (n_hyp, t_max, attention)
+        plan = self._decode_plans.pop(key, None)
+        if plan is None:
+            plan = decode.DecodePlan(self.store, n_hyp, t_max, attention=attention)
+            while len(self._decode_plans) >= self.DECODE_PLAN_MAX:
+                torch.cuda.synchronize(self.store.device)
+                self._decode_plans.popitem(last=False)
+        plan.reset()
+        self._decode_plans[key] = plan
         return plan
 
     def on_plan_evicted(self, callback):

@@ -147,6 +147,7 @@ class BeamSearchSampler(SamplerBase):
             state.plan.reorder(hyp)
             if ((seqs[:, i] == EOS_ID) | (seqs[:, i] == PAD_ID)).all():
                 break
+        self.positions_decoded = i  # (bench.py --decode)
         self.scores = scores.reshape(B, K)
         self.hypotheses = seqs.reshape(B, K, -1)
         return self.hypotheses[:, 0]  # best hypothesis of every sample

@@ -15,8 +15,13 @@ oracle/vae_oracle.py::decode_incremental and implemented here on the same kernel
     step holds the single new query — every weight is 1 and the head output is the sum of the cached value rows
     (mode 'query'); the conventional softmax over the cached keys is offered as mode 'key';
   * dropout layers are identities outside autograd.record() (inference).
-Everything is one row per sample: the GEMMs are launch-bound M = B problems of the same mst_gemm_nt used in training."""
+Everything is one row per sample: the GEMMs are launch-bound M = B problems of the same mst_gemm_nt used in training, so a
+position is ~8 launches per layer of a few microseconds each. Every position is therefore captured ONCE as a hipGraph (its
+kernel arguments — the cache row written, the number of keys attended to, the positional row — are host scalars that differ
+per position, hence one graph per position, captured the first time a plan reaches it) and replayed from then on; plans are
+kept per (hypotheses, positions, attention mode) by the model, so beam search over many batches captures nothing twice."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -57,6 +62,11 @@ class DecodePlan:
             self.frames = torch.zeros(B, roundup(cfg.in_dim, 8), dtype=torch.uint8, device=dev)
             self.zero_labels = torch.zeros(B, cfg.out_dim, dtype=torch.uint8, device=dev)
         self.t = -1  # position of the last row fed
+        # one captured graph per position (MST_DECODE_GRAPHS=0: eager launches); capture needs a stream of its own
+        self.use_graphs = os.environ.get("MST_DECODE_GRAPHS", "1") != "0"
+        self.stream = torch.cuda.Stream(device=dev)
+        self._graphs = {}
+        self._warm = False
 
     # ------------------------------------------------------------------ one position through the decoder layers
     def _layers(self, x, t):
@@ -84,28 +94,37 @@ class DecodePlan:
         return self.x
 
     # ------------------------------------------------------------------ API
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.stream)
+
+    def _leave(self):
+        torch.cuda.current_stream().wait_stream(self.stream)  # the caller reads the results on its own stream
+
+    def reset(self):
+        """forget the positions fed so far (the caches are overwritten from row 0 on); captured graphs stay valid"""
+        self.t = -1
+
     def start(self, row0):
         """position 0: the initial state rows [B, >= D] (16-bit), ALREADY scaled and positioned as the training step's
         decoder row 0 (engine.StepPlan.x0_d[:, 0]); fills row 0 of every layer's cache"""
-        self.x.copy_(row0[:, : self.x.shape[1]])
-        self._layers(self.x, 0)
+        with self._enter():
+            self.x.copy_(row0[:, : self.x.shape[1]])
+            self._run_position(0)
+        self._leave()
         self.t = 0
 
-    def step(self, prev):
-        """position t = previous + 1: `prev` is the token fed at this position ([B] ids, token ends) or the frame ([B, P]
-        {0,1}); returns the output distribution of this position, [B, V] fp32 probabilities (token ends) or [B, P] 16-bit
-        per-pitch probabilities (piano-roll ends)"""
+    def _position(self, t):
+        """the kernel sequence of position t >= 0 on inputs already in self.x (t = 0) / self.tokens / self.frames"""
         cfg, st, B = self.cfg, self.store, self.B
-        t = self.t + 1
-        if t >= self.t_max:
-            raise RuntimeError(f"decode buffers hold {self.t_max} positions")
         D = cfg.d_model
+        if t == 0:
+            self._layers(self.x, 0)
+            return
         sq = math.sqrt(float(D))
         if cfg.kind == "token":
-            self.tokens.copy_(torch.as_tensor(np.asarray(prev.cpu() if torch.is_tensor(prev) else prev)).to(torch.int32).view(B, 1))
             o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos[t:], self.x.view(B, 1, -1), 0, sq)
         else:
-            self.frames[:, : cfg.in_dim].copy_(torch.as_tensor(np.asarray(prev.cpu() if torch.is_tensor(prev) else prev)).to(torch.uint8))
             o.gemm_nt(self.frames, st.t("decoder.embedding.weight"), self.x, N=D, alpha=sq, rowadd=self.pos[t:], rowadd_period=1)
         x = self._layers(self.x, t)
         o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, K=D, bias=st.p("decoder.output_layer.bias"))
@@ -113,6 +132,35 @@ class DecodePlan:
             o.softmax_ce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, probs=self.probs)
         else:
             o.sigmoid_bce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, npos=self.npos, probs=self.probs)
+
+    def _run_position(self, t):
+        """replay position t's graph (captured at first use; the very first position of a plan runs eagerly: HIP modules
+        load lazily and cannot be loaded inside a capture)"""
+        if not self.use_graphs or not self._warm:
+            self._position(t)
+            self._warm = self._warm or t >= 1  # (position 1 has touched every kernel of a later position)
+            return
+        g = self._graphs.get(t)
+        if g is None:
+            g = self._graphs[t] = o.Graph().capture(lambda: self._position(t))
+        g.launch()
+
+    def step(self, prev):
+        """position t = previous + 1: `prev` is the token fed at this position ([B] ids, token ends) or the frame ([B, P]
+        {0,1}); returns the output distribution of this position, [B, V] fp32 probabilities (token ends) or [B, P] 16-bit
+        per-pitch probabilities (piano-roll ends)"""
+        cfg, B = self.cfg, self.B
+        t = self.t + 1
+        if t >= self.t_max:
+            raise RuntimeError(f"decode buffers hold {self.t_max} positions")
+        host = torch.as_tensor(np.asarray(prev.cpu() if torch.is_tensor(prev) else prev))
+        with self._enter():
+            if cfg.kind == "token":
+                self.tokens.copy_(host.to(torch.int32).view(B, 1))
+            else:
+                self.frames[:, : cfg.in_dim].copy_(host.to(torch.uint8))
+            self._run_position(t)
+        self._leave()
         self.t = t
         return self.probs[:, : cfg.out_dim]
 
@@ -120,5 +168,7 @@ class DecodePlan:
         """beam search: hypothesis j continues hypothesis index[j] — gather the caches' rows (sampler.py:236-238)"""
         idx = torch.as_tensor(np.asarray(index), dtype=torch.int64, device=self.store.device)
         n = self.t + 1
-        for i, c in enumerate(self.cache):
-            c[:, :n] = c[:, :n].index_select(0, idx)
+        with self._enter():
+            for i, c in enumerate(self.cache):
+                c[:, :n] = c[:, :n].index_select(0, idx)
+        self._leave()

@@ -54,6 +54,14 @@ def test_decode_step_matches_the_oracle(gpu, kind, dims, attention):
     if kind == "token":
         np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-3)
     assert plan.t == n
+    # every position from the second on was captured as a hipGraph at first use; a second pass over the same plan REPLAYS them
+    # (position 0 and 1 are captured now) and must reproduce the first pass bit for bit
+    assert plan.use_graphs and sorted(plan._graphs) == list(range(2, n + 1))
+    plan.reset()
+    plan.start(row0)
+    again = np.stack([plan.step(fed[:, t]).float().cpu().numpy() for t in range(n)], 1)
+    assert sorted(plan._graphs) == list(range(0, n + 1))
+    assert np.array_equal(again, got)
 
 
 def test_query_axis_softmax_of_one_query_sums_the_cached_values(gpu):

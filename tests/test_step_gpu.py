@@ -164,6 +164,12 @@ def _compare_step(gpu, kind, dims, B, T, seed, steps=2, lr=1e-3, dtype=torch.bfl
                     c = _cos(gg, rg)
                     if not c >= (noisy_cos if noisy(name) else grad_cos):
                         bad.append(f"step {s} gradient of {name}: cosine {c:.4f} (|ref| {np.abs(rg).max():.3g})")
+                    # ... and a direction check alone would let a SCALE error through (a wrong 1/sqrt(dh), a dropped factor of the
+                    # score scale in dK / dQ): the norm must agree too — to the part the cosine allows for noise, sqrt(1 - c^2) of it
+                    ratio = float(np.linalg.norm(gg.astype(np.float64)) / max(np.linalg.norm(rg.astype(np.float64)), 1e-300))
+                    slack = 0.25 + (math.sqrt(max(0.0, 1.0 - min(c, 1.0) ** 2)) if noisy(name) else 0.0)
+                    if not (1.0 / (1.0 + slack) <= ratio <= 1.0 + slack):
+                        bad.append(f"step {s} gradient of {name}: norm ratio {ratio:.3f} (cosine {c:.3f})")
                     scale = float(np.abs(rg).max())
                     if not noisy(name) and not np.abs(gg - rg).max() <= max_err * scale:
                         bad.append(f"step {s} gradient of {name}: max err {np.abs(gg - rg).max():.3g} vs scale {scale:.3g}")
