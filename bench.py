@@ -359,8 +359,8 @@ def main(argv=None):
 
 def run_decode(args):
     """Beam-search decoding throughput (reference sampler.py:198-257 over model.py:259-272): B = 64 melodies x beam 4 = 256
-    hypotheses, each position = one captured graph of the decoder's incremental step (decode.DecodePlan) + the host's
-    top-k over beam x V. A "step" here is one decoded position of all hypotheses; --steps positions are timed after
+    hypotheses, each position = one captured graph of the decoder's incremental step, the ranking of the beam x V continuations
+    and the gather of the caches (decode.BeamSearch). A "step" here is one decoded position of all hypotheses; --steps positions are timed after
     --warmup positions (which also capture the graphs). Random-initialised weights, synthetic token batch."""
     import torch
     if not torch.cuda.is_available():
@@ -403,15 +403,14 @@ def run_decode(args):
             reps += 1
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        # the device part alone: replay the captured positions of the plan back to back (no host top-k, no copies)
-        plan = m.decode_plan(B * K, 2 * (T + 1) + 1, "query")
-        plan.reset()
-        with torch.cuda.stream(plan.stream):
-            ts = sorted(plan._graphs)
+        # the device part alone: the captured positions (decode step + ranking + cache gather) replayed back to back
+        bs = m.beam_search_plan(B, K, 2 * (T + 1), "query")
+        with torch.cuda.stream(bs.plan.stream):
+            ts = sorted(bs._graphs)
             e0, e1 = o.Event(), o.Event()
             e0.record()
             for t in ts:
-                plan._graphs[t].launch()
+                bs._graphs[t].launch()
             e1.record()
             e1.sync()
             dev_us = e0.elapsed_ms(e1) * 1e3 / max(len(ts), 1)
@@ -421,10 +420,11 @@ def run_decode(args):
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"beam search over the incremental decoder (sampler.py:198-257): {B} melodies x beam {K} = {B * K} hypotheses, "
                                   f"input length {T + 1}, up to {2 * (T + 1)} positions, token ends V={NUM_EVENTS}, decoder 128x1x8h, latent {Z}; "
-                                  "a step = one position of all hypotheses (captured graph + host top-k over beam x V)",
+                                  "a step = one position of all hypotheses = ONE captured graph: decode step, ranking (mst_beam_step) and cache gather "
+                                  "(mst_beam_gather) on the device; the host launches graphs and polls a device counter every 8 positions",
                       "hypotheses": B * K, "beam": K, "positions_per_sequence": smp.positions_decoded},
            "device_us_per_position": dev_us, "host_share": 1.0 - dev_us * 1e-6 * n_pos / elapsed,
-           "graphs_captured": len(plan._graphs)}
+           "graphs_captured": len(bs._graphs), "ranking": "device" if smp.on_device else "host"}
     print(json.dumps(out), flush=True)
     return 0
 

@@ -509,6 +509,23 @@ int mst_attn_decode(int dtype, int64_t B, int64_t H, int64_t dh, int64_t n_keys,
                     mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Beam search on the device (sampler.py:198-257, token ends), one position per call pair — capturable with the decode step.
+ * mst_beam_step: B samples x K hypotheses (K <= 16); probs fp32 [B*K, ldp] = the decoder's distribution of position i; a
+ *   hypothesis whose last token (seqs_in[., i-1]) is EOS — or PAD from position 2 on — is finished and continues with PAD only,
+ *   at no cost (sampler.py:218-221); every other continuation costs -log max(p, 1e-30). Per sample the K candidates with the
+ *   smallest (score, hypothesis * V + word) are kept: new hypothesis r of sample b gets scores_out, its source hypothesis in
+ *   hyp_src (a row index into the B*K hypotheses), its word in word[] (int32, the next position's input) and its token row
+ *   seqs_out[., 0..i] (int32 rows of L). active[i] (optional, zeroed by the caller) += hypotheses still running after position i.
+ * mst_beam_gather: out[j, r, :] = in[src[j], r, :] for r < n_rows — the K | Q | V cache rows ([N, t_max, row_bytes]) of the
+ *   re-ranked hypotheses (sampler.py:236-238); in and out are distinct buffers (the decode plan alternates between two).
+ * ------------------------------------------------------------------------ */
+int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t L, const float* probs, int64_t ldp, const float* scores_in,
+                  float* scores_out, const int32_t* seqs_in, int32_t* seqs_out, int32_t* hyp_src, int32_t* word, int32_t* active,
+                  int32_t eos, int32_t pad, mst_stream_t stream);
+int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
+                    mst_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * K12/K13: softmax over V + SoftmaxCrossEntropy (model.py:256; loss.py:15-23).
  *   logits : act dtype [M = B*T, ld]; labels int32 [M]
  *   loss[b] = (1/T) * sum_t -log p[b,t,label] * (label != 0)     (fp32 [B], written)

@@ -79,6 +79,19 @@ class _Decoder:
         st = self._model.store
         return {n: st.p(n) for n in st.shapes if n.startswith("decoder.")}
 
+    def initial_rows(self, tokens, seq_lens, classes, beam=1):
+        """position 0 of the decoder input for a batch: z = the latent MEANS (sampler.py:146-148), rows repeated `beam` times"""
+        m = self._model
+        x = np.asarray(tokens.cpu() if torch.is_tensor(tokens) else tokens)
+        B, T = x.shape[0], x.shape[1]
+        plan = m.plan(B, T, want_probs=False, internal_eps=False)
+        cfg = m.engine_config
+        dummy = np.zeros((B, T), np.int64) if cfg.kind == "token" else np.zeros((B, T, cfg.out_dim), np.uint8)
+        plan.load_batch(x, seq_lens, classes, dummy, np.zeros((B, cfg.latent_dim), np.float32))  # eps = 0: z = means
+        plan.forward(inference=True)  # outside autograd.record() in the reference: Dropout is the identity
+        row0 = plan.x0_d.view(B, T + 1, -1)[:, 0, :]
+        return (row0.repeat_interleave(beam, dim=0) if beam > 1 else row0).contiguous()
+
     def get_initial_state(self, tokens, seq_lens, classes, t_max, attention="query", beam=1):
         """encode the batch, take z = the latent MEANS (sampler.py:146-148: latent_vector = means), build position 0 of the
         decoder input from it (model.py:229-232) and feed it: returns a DecoderState whose caches hold row 0.
@@ -194,6 +207,21 @@ class Model:
         plan.reset()
         self._decode_plans[key] = plan
         return plan
+
+    def beam_search_plan(self, B, K, i_max, attention="query"):
+        """decode.BeamSearch of this shape (caches, token rows, one captured graph per position), kept across batches"""
+        from .. import decode
+        if not hasattr(self, "_beam_plans") or getattr(self, "_beam_store", None) is not self.store:
+            self._beam_plans, self._beam_store = OrderedDict(), self.store
+        key = (B, K, i_max, attention)
+        bs = self._beam_plans.pop(key, None)
+        if bs is None:
+            bs = decode.BeamSearch(self.store, B, K, i_max, attention=attention)
+            while len(self._beam_plans) >= self.DECODE_PLAN_MAX:
+                torch.cuda.synchronize(self.store.device)
+                self._beam_plans.popitem(last=False)
+        self._beam_plans[key] = bs
+        return bs
 
     def on_plan_evicted(self, callback):
         """callback(plan) when the cache drops a plan (holders of per-plan state — graphs, input rings — forget it)"""

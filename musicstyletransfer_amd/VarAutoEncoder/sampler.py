@@ -110,10 +110,13 @@ class BeamSearchSampler(SamplerBase):
     """beam search (sampler.py:193-257), token ends: `beam_size` hypotheses per sample, scores = summed -log p, finished
     hypotheses (EOS / PAD) are extended by PAD at no cost; the caches are re-gathered as hypotheses are re-ranked."""
 
-    def __init__(self, *args, beam_size=4, **kw):
+    def __init__(self, *args, beam_size=4, on_device=None, **kw):
+        """on_device (default: MST_BEAM_DEVICE != 0): ranking and cache reorder as device kernels inside each position's captured
+        graph (decode.BeamSearch); False: the host loop below, one device->host copy of the distributions per position"""
         super().__init__(*args, **kw)
         self.beam_size = beam_size
         self.max_length_factor = 2.0
+        self.on_device = (os.environ.get("MST_BEAM_DEVICE", "1") != "0") if on_device is None else bool(on_device)
 
     def sample(self, batch):
         tokens, seq_lens, classes = batch.data
@@ -124,6 +127,13 @@ class BeamSearchSampler(SamplerBase):
         V = self.model.engine_config.out_dim
         i_max = int(tokens.shape[1] * self.max_length_factor)
         dec = self.model.decoder
+        if self.on_device and K <= 16:
+            bs = self.model.beam_search_plan(B, K, i_max, self.attention)
+            seqs, scores = bs.run(dec.initial_rows(tokens, seq_lens, classes, beam=K))
+            self.positions_decoded = bs.positions
+            self.scores = scores.astype(np.float64).reshape(B, K)
+            self.hypotheses = seqs.astype(np.int64).reshape(B, K, -1)
+            return self.hypotheses[:, 0]
         state = dec.get_initial_state(tokens, seq_lens, classes, t_max=i_max + 1, attention=self.attention, beam=K)
         seqs = np.full((B * K, i_max), PAD_ID, np.int64)
         seqs[:, 0] = SOS_ID

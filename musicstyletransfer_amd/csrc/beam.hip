@@ -1,0 +1,131 @@
+// beam.hip — one position of beam search on the device (reference VarAutoEncoder/sampler.py:198-257, token ends):
+//   mst_beam_step   : per sample, the K best of its K x V continuations (score = summed -log p; a finished hypothesis continues
+//                     with PAD only, at no cost: sampler.py:218-221), the re-ranked token rows, the words fed to the next position
+//   mst_beam_gather : the decoder layers' K | Q | V cache rows of the re-ranked hypotheses (sampler.py:236-238)
+// With these two the whole position — decoder step, ranking, cache reorder — is device work inside ONE captured graph; the host
+// version spent 98 % of a position in its own top-k over beam x V and the copies around it (2.6 ms against 55 us of device time).
+// Ranking is deterministic: candidates are ordered by (score, hypothesis * V + word), i.e. the stable argsort of the host form.
+#include <math.h>
+#include "common.hpp"
+
+namespace mst {
+
+struct BeamArgs {
+  int64_t B, K, V, i, L;
+  const float* probs; int64_t ldp;
+  const float* scores_in; float* scores_out;
+  const int32_t* seqs_in; int32_t* seqs_out;
+  int32_t* hyp_src; int32_t* word; int32_t* active;
+  int32_t eos, pad;
+};
+
+constexpr int BEAM_MAXK = 16;
+
+// one 256-thread workgroup per sample
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs q) {
+  __shared__ float s_score[BEAM_MAXK];
+  __shared__ int s_fin[BEAM_MAXK];
+  __shared__ float s_val[BEAM_MAXK];
+  __shared__ int s_idx[BEAM_MAXK];
+  __shared__ float r_val[4];
+  __shared__ int r_idx[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x;
+  const int K = (int)q.K, V = (int)q.V;
+  if (tid < K) {
+    const int64_t h = b * K + tid;
+    s_score[tid] = q.scores_in[h];
+    const int32_t last = q.seqs_in[h * q.L + q.i - 1];
+    s_fin[tid] = (last == q.eos) || (last == q.pad && q.i > 1);
+  }
+  __syncthreads();
+  const int n_cand = K * V;
+  for (int r = 0; r < K; ++r) {
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+    for (int c = tid; c < n_cand; c += 256) {
+      bool taken = false;
+      for (int u = 0; u < r; ++u) taken |= (s_idx[u] == c);
+      if (taken) continue;
+      const int k = c / V, w = c - k * V;
+      float val;
+      if (s_fin[k]) val = (w == q.pad) ? s_score[k] : INFINITY;
+      else val = s_score[k] - logf(fmaxf(q.probs[(b * K + k) * q.ldp + w], 1e-30f));
+      if (val < best || (val == best && c < best_i)) { best = val; best_i = c; }
+    }
+    // workgroup argmin by (value, index)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(best_i, off, 64);
+      if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if (lane == 0) { r_val[wave] = best; r_idx[wave] = best_i; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = r_val[0]; int bi = r_idx[0];
+      for (int wv = 1; wv < 4; ++wv)
+        if (r_val[wv] < bv || (r_val[wv] == bv && r_idx[wv] < bi)) { bv = r_val[wv]; bi = r_idx[wv]; }
+      s_val[r] = bv; s_idx[r] = bi;
+    }
+    __syncthreads();
+  }
+  // the re-ranked rows: new hypothesis r continues hypothesis s_idx[r] / V with word s_idx[r] % V
+  int alive = 0;
+  for (int r = 0; r < K; ++r) {
+    const int c = s_idx[r];
+    const int k = c / V, w = c - k * V;
+    const int64_t dst = b * K + r, src = b * K + k;
+    for (int64_t col = tid; col < q.i; col += 256) q.seqs_out[dst * q.L + col] = q.seqs_in[src * q.L + col];
+    if (tid == 0) {
+      q.seqs_out[dst * q.L + q.i] = w;
+      q.scores_out[dst] = s_val[r];
+      q.hyp_src[dst] = (int32_t)src;
+      q.word[dst] = w;
+      alive += (w != q.eos && w != q.pad) ? 1 : 0;
+    }
+  }
+  if (tid == 0 && q.active && alive) atomicAdd(q.active + q.i, alive);
+}
+
+// out[j, r, :] = in[src[j], r, :] for r < n_rows; rows of row_bytes bytes (a multiple of 16), t_max rows per hypothesis
+__global__ __launch_bounds__(256) void beam_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int32_t* __restrict__ src,
+                                                          int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max) {
+  const int64_t pieces = row_bytes / 16, total = N * n_rows * pieces;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int64_t pc = p % pieces, rr = (p / pieces) % n_rows, j = p / (pieces * n_rows);
+    const int64_t s = src[j];
+    reinterpret_cast<u32x4*>(out + (j * t_max + rr) * row_bytes)[pc] = reinterpret_cast<const u32x4*>(in + (s * t_max + rr) * row_bytes)[pc];
+  }
+}
+
+}  // namespace mst
+
+using namespace mst;
+
+extern "C" int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t L, const float* probs, int64_t ldp, const float* scores_in,
+                             float* scores_out, const int32_t* seqs_in, int32_t* seqs_out, int32_t* hyp_src, int32_t* word, int32_t* active,
+                             int32_t eos, int32_t pad, mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && K > 0 && K <= BEAM_MAXK && V > 0 && i >= 1 && i < L && K * V < (1ll << 30), "mst_beam_step: bad sizes (beam <= %d)", BEAM_MAXK);
+  MST_CHECK_ARG(probs && scores_in && scores_out && seqs_in && seqs_out && hyp_src && word && ldp >= V, "mst_beam_step: null pointer or ldp < V");
+  MST_CHECK_ARG(seqs_in != seqs_out && scores_in != scores_out, "mst_beam_step: the re-ranked rows need buffers of their own");
+  BeamArgs q = {B, K, V, i, L, probs, ldp, scores_in, scores_out, seqs_in, seqs_out, hyp_src, word, active, eos, pad};
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, q);
+  MST_CHECK_LAUNCH("beam_step_kernel");
+  return MST_OK;
+}
+
+extern "C" int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
+                               mst_stream_t stream) {
+  MST_CHECK_ARG(in && out && src && in != out && N > 0 && n_rows > 0 && n_rows <= t_max && row_bytes > 0 && row_bytes % 16 == 0,
+                "mst_beam_gather: bad argument (rows of a multiple of 16 bytes, distinct buffers)");
+  MST_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0), "mst_beam_gather: buffers must be 16-byte aligned");
+  const int64_t total = N * n_rows * (row_bytes / 16);
+  int64_t grid = cdiv(total, 256 * 4);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(beam_gather_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)in, (uint8_t*)out, src, N,
+                     n_rows, row_bytes, t_max);
+  MST_CHECK_LAUNCH("beam_gather_kernel");
+  return MST_OK;
+}

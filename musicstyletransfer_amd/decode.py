@@ -35,9 +35,12 @@ class DecodePlan:
 
     MODES = {"query": 0, "key": 1}
 
-    def __init__(self, store, B, t_max, attention="query"):
+    def __init__(self, store, B, t_max, attention="query", pingpong=False):
+        """pingpong: two sets of caches, position t working on set t & 1 — beam search on the device re-ranks the hypotheses
+        after every position by gathering the cache rows from one set into the other (BeamSearch below)"""
         cfg = store.cfg
         self.store, self.cfg, self.B, self.t_max = store, cfg, B, t_max
+        self.pingpong = pingpong
         self.mode = self.MODES[attention]
         dev, adt = store.device, store.act_dtype
         D = cfg.d_model
@@ -46,7 +49,8 @@ class DecodePlan:
         def act(rows, width):
             return torch.zeros(rows, roundup(width, 8), dtype=adt, device=dev)
 
-        self.cache = [torch.zeros(B, t_max, 3 * D, dtype=adt, device=dev) for _ in range(cfg.d_layers)]
+        self.cache_sets = [[torch.zeros(B, t_max, 3 * D, dtype=adt, device=dev) for _ in range(cfg.d_layers)] for _ in range(2 if pingpong else 1)]
+        self.cache = self.cache_sets[0]
         self.x, self.att, self.h1, self.x1, self.h2, self.x2 = (act(B, D) for _ in range(6))
         self.a = act(B, 4 * D)
         self.mean, self.rstd = torch.zeros(B, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.float32, device=dev)
@@ -74,7 +78,7 @@ class DecodePlan:
         D, H = cfg.d_model, cfg.d_heads
         for i in range(cfg.d_layers):
             pre = f"decoder.layer{i}"
-            cache = self.cache[i]
+            cache = self.cache_sets[(t & 1) if self.pingpong else 0][i]
             # K | Q | V of the new row, written to row t of every sample's cache (C row remap: logical row b -> b * t_max + t)
             o.gemm_nt(x, st.fused(st.w16, pre, "weight"), cache.view(B * self.t_max, 3 * D), M=B, K=D, bias=st.fused(st.w, pre, "bias"),
                       c_remap=(1, self.t_max, t))
@@ -165,10 +169,81 @@ class DecodePlan:
         return self.probs[:, : cfg.out_dim]
 
     def reorder(self, index):
-        """beam search: hypothesis j continues hypothesis index[j] — gather the caches' rows (sampler.py:236-238)"""
+        """beam search driven from the host: hypothesis j continues hypothesis index[j] — gather the caches' rows
+        (sampler.py:236-238)"""
+        assert not self.pingpong
         idx = torch.as_tensor(np.asarray(index), dtype=torch.int64, device=self.store.device)
         n = self.t + 1
         with self._enter():
             for i, c in enumerate(self.cache):
                 c[:, :n] = c[:, :n].index_select(0, idx)
         self._leave()
+
+
+class BeamSearch:
+    """Beam search with everything of a position on the device (reference sampler.py:198-257): the decode step of the B x K
+    hypotheses, their re-ranking (mst_beam_step: scores, token rows, the words fed next) and the gather of the layers' cache
+    rows (mst_beam_gather) are ONE captured graph per position; the host launches graphs and looks at a device counter of
+    running hypotheses every few positions. Token rows, scores and caches alternate between two buffers by position parity."""
+
+    def __init__(self, store, B, K, i_max, attention="query"):
+        from .MIDIUtil.defaults import EOS_ID, PAD_ID, SOS_ID
+        self.B, self.K, self.i_max = B, K, i_max
+        self.eos, self.pad, self.sos = EOS_ID, PAD_ID, SOS_ID
+        self.plan = DecodePlan(store, B * K, i_max + 1, attention=attention, pingpong=True)
+        dev, N = store.device, B * K
+        self.seqs = [torch.zeros(N, i_max, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.scores = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.hyp = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ident = torch.arange(N, dtype=torch.int32, device=dev)
+        self.active = torch.zeros(i_max + 1, dtype=torch.int32, device=dev)
+        first = torch.full((B, K), float("inf"))
+        first[:, 0] = 0.0  # the K copies of a sample start identical: only the first one may expand
+        self.first_scores = first.reshape(-1).to(dev)
+        self._graphs, self._warm = {}, False
+        self.positions = 0
+
+    def _position(self, i):
+        p = self.plan
+        cur, nxt = i & 1, (i + 1) & 1
+        p._position(i)
+        o.beam_step(p.probs, self.scores[cur], self.scores[nxt], self.seqs[cur], self.seqs[nxt], self.hyp, p.tokens, i, self.K, self.eos,
+                    self.pad, active=self.active)
+        for cin, cout in zip(p.cache_sets[cur], p.cache_sets[nxt]):
+            o.beam_gather(cin, cout, self.hyp, i + 1)
+
+    def run(self, row0, check_every=8):
+        """row0: [B * K, >= D] initial decoder rows (every sample's row repeated K times). Returns (token rows [B*K, n] int32,
+        scores [B*K] fp32) as host arrays, hypotheses of a sample best first."""
+        p = self.plan
+        p.reset()
+        with p._enter():
+            p.x.copy_(row0[:, : p.x.shape[1]])
+            p._run_position(0)                      # cache set 0, row 0 ...
+            for cin, cout in zip(p.cache_sets[0], p.cache_sets[1]):
+                o.beam_gather(cin, cout, self.ident, 1)  # ... which position 1 expects in set 1
+            p.t = 0
+            self.seqs[1].fill_(self.pad)
+            self.seqs[1][:, 0] = self.sos
+            self.scores[1].copy_(self.first_scores)
+            p.tokens.fill_(self.sos)
+            o.zero(self.active)
+            last = 0
+            for i in range(1, self.i_max):
+                if not p.use_graphs or not self._warm:
+                    self._position(i)               # (the first position ever runs eagerly: lazy HIP module loads)
+                    self._warm = True
+                else:
+                    g = self._graphs.get(i)
+                    if g is None:
+                        g = self._graphs[i] = o.Graph().capture(lambda: self._position(i))
+                    g.launch()
+                p.t = last = i
+                if i % check_every == 0 and int(self.active[i].item()) == 0:
+                    break                            # every hypothesis has ended (sampler.py: the loop's exit test)
+            res = (last + 1) & 1
+            seqs = self.seqs[res][:, : last + 1].cpu().numpy()
+            scores = self.scores[res].cpu().numpy()
+        p._leave()
+        self.positions = last
+        return seqs, scores

@@ -431,6 +431,19 @@ def attn_decode(cache3, n_keys, H, dh, k_off, q_off, v_off, out, mode=0):
 
 
 # --------------------------------------------------------------------------- LayerNorm
+def beam_step(probs, scores_in, scores_out, seqs_in, seqs_out, hyp_src, word, i, K, eos, pad, active=None):
+    """one position of beam search (mst_beam_step): probs fp32 [B*K, >= V]; seqs int32 [B*K, L]; word int32 [B*K(, 1)]"""
+    N, V = probs.shape[0], probs.shape[1]
+    call("mst_beam_step", N // K, K, V, i, seqs_in.shape[1], ptr(probs), probs.stride(0), ptr(scores_in), ptr(scores_out), ptr(seqs_in),
+         ptr(seqs_out), ptr(hyp_src), ptr(word), ptr(active), eos, pad, stream())
+
+
+def beam_gather(cache_in, cache_out, src, n_rows):
+    """cache_out[j, :n_rows] = cache_in[src[j], :n_rows] for [N, t_max, width] caches (mst_beam_gather)"""
+    N, t_max, width = cache_in.shape
+    call("mst_beam_gather", ptr(cache_in), ptr(cache_out), ptr(src), N, n_rows, width * cache_in.element_size(), t_max, stream())
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5, M=None, row_id_stride=1):
     M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D

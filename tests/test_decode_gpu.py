@@ -129,6 +129,19 @@ def test_samplers_on_the_toy_model(gpu, tmp_path):
     assert b3.hypotheses.shape[:2] == (3, 3)
     assert (np.diff(b3.scores, axis=1) >= -1e-9).all()               # hypotheses come out best first
     assert (b3.scores[:, 0] <= b1.scores[:, 0] + 1e-6).all()           # a wider beam never does worse than greedy
+    # beam search ranked on the DEVICE (decode.BeamSearch: mst_beam_step + mst_beam_gather inside every position's graph, the
+    # default) against the host loop over the same decode step: the same hypotheses, best first, the same scores
+    for K in (1, 3, 4):
+        dev_s, host_s = S.BeamSearchSampler(beam_size=K, on_device=True), S.BeamSearchSampler(beam_size=K, on_device=False)
+        for smp_k in (dev_s, host_s):
+            smp_k.update_parameters(t.model)
+            smp_k.sample(batch)
+        n = min(dev_s.hypotheses.shape[2], host_s.hypotheses.shape[2])
+        np.testing.assert_allclose(dev_s.scores, host_s.scores, rtol=2e-4, atol=2e-4)
+        assert np.array_equal(dev_s.hypotheses[:, :, :n], host_s.hypotheses[:, :, :n]), K
+        assert (dev_s.hypotheses[:, :, n:] == PAD_ID).all() and (host_s.hypotheses[:, :, n:] == PAD_ID).all()
+    dev_s.sample(batch)  # a second batch of the same shape replays the captured positions
+    assert len(t.model.beam_search_plan(3, 4, 10)._graphs) >= 1
     files = smp.process_batch(batch, str(tmp_path / "samples"), 3)
     assert len(files) == 3 + 3 * 3 and all(os.path.getsize(f) > 0 for f in files)
     with pytest.raises(ValueError):
