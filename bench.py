@@ -170,7 +170,7 @@ def kernel_families(plan, o, iters=30):
                                     ff1=dict(K=De, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU, **plan._drop(cfg.e_dropout, 1)),
                                     ff2=dict(K=4 * De, bias=st.p(f"{pre}.ff2.bias"), resid=L.x1, **plan._drop(cfg.e_dropout, 2))),
             flops=2.0 * 2.0 * M * 4 * De * De, bytes=ffn_bytes, launches_per_step=full_e,
-            pmc_key="ffn_ln_kernel<256,2,4,1>@%d" % (((M + 63) // 64) * 512)))
+            pmc_key="ffn_ln_kernel<%d,2,4,1,@%d" % (De, ((M + 63) // 64) * 512)))
         # backward form: dff in, a (gate) in, dpre out, h1 in, dh1 (+ masked copy) out
         fams.append(dict(
             kernel=f"ffn_ln_kernel bwd [FFN dgrads + LayerNorm backward, M={M}, width {De}]",
@@ -178,7 +178,7 @@ def kernel_families(plan, o, iters=30):
                                     st.p(f"{pre}.ln1.gamma"), L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"),
                                     resid=t.dh, partials=plan._ln_part[f"{pre}.ln1"]),
             flops=2.0 * 2.0 * M * 4 * De * De, bytes=2.0 * (M * De + 8 * De * De + 2 * M * 4 * De + 3 * M * De),
-            launches_per_step=full_e, pmc_key="ffn_ln_kernel<256,2,4,2>@%d" % (((M + 63) // 64) * 512)))
+            launches_per_step=full_e, pmc_key="ffn_ln_kernel<%d,2,4,2,@%d" % (De, ((M + 63) // 64) * 512)))
     # the K | Q | V projection runs inside the attention forward launch (mst_attn_qkv_fwd): x and the weights in, qkv (kept for the
     # backward pass) and the attention output out
     fams.append(dict(
@@ -186,12 +186,12 @@ def kernel_families(plan, o, iters=30):
         fn=lambda: o.attn_qkv_fwd(plan.x0_e, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, plan.keymask_e, L.lse, L.att,
                                   B, T, H, De // H, 0, De, 2 * De),
         flops=4.0 * B * T * T * De + 2.0 * M * 3 * De * De, bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + M * De),
-        launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
+        launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
     fams.append(dict(
         kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
         fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),
         flops=2.0 * 4 * B * T * T * De, bytes=2.0 * M * (3 * De + De + 3 * De), launches_per_step=full_e,
-        pmc_key="attn_bwd_res_kernel<%d>@%d" % (De // H, B * H * 512)))
+        pmc_key="attn_bwd_res_kernel<%d,0>@%d" % (De // H, B * H * 512)))
     wg, ps = plan.last_wgrad_launch
     if wg:
         fl = sum(2.0 * w.M * w.N * w.K for w in wg)
@@ -223,10 +223,12 @@ def roofline(plan, o, config_id):
         if config_id == 1 and best["pmc_key"]:
             table, src = j["bytes_per_launch"], j.get("source")
 
-            def lookup(key):  # "name@grid", or "name@*" for the entry of that kernel whatever its grid
-                if not key.endswith("@*"):
-                    return table.get(key)
-                hits = [v for k, v in table.items() if k.startswith(key[:-1])]
+            def lookup(key):  # "name<args>@grid"; "@*": whatever the grid; a template list may be a prefix ("kernel<256,2,4,1")
+                if key in table:
+                    return table[key]
+                name, grid = key.rsplit("@", 1)
+                stem = name[:-1] if name.endswith(">") else name
+                hits = [v for k, v in table.items() if k.rsplit("@", 1)[0].startswith(stem) and (grid == "*" or k.endswith("@" + grid))]
                 return max(hits) if hits else None
 
             parts = [lookup(k) for k in best["pmc_key"].split("+")]

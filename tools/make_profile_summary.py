@@ -27,9 +27,11 @@ def short(name):
     m = re.match(r"_ZN3mst\d+(\w+?)I(DF16b|DF16_|f)?", name)
     if m:
         base = re.match(r"_ZN3mst\d+([a-z_0-9]+?_kernel)", name)
-        tmpl = re.findall(r"Li(\d+)E", name)
-        if "gemm_nt_kernel" in name:
-            tmpl = tmpl[:5]  # BM, BN, WGM, WGN, BK (the epilogue switches that follow do not change the traffic key)
+        # integer AND bool template arguments: the bool ones are kernel VARIANTS with their own traffic (attn_bwd_res_kernel<32,0> dense
+        # vs <32,1> position-0-sparse; attn_fwd_res_kernel<32,1> with the K|Q|V projection inside)
+        tmpl = re.findall(r"L[ib](\d+)E", name)
+        if "gemm_nt_kernel" in name or "gemm_nt_pair_kernel" in name:
+            tmpl = re.findall(r"Li(\d+)E", name)[:5]  # BM, BN, WGM, WGN, BK (the epilogue switches do not change the traffic key)
         return (base.group(1) if base else m.group(1)) + ("<" + ",".join(tmpl) + ">" if tmpl else "")
     return re.sub(r"\(.*", "", name.replace("mst::", ""))[:70]
 
