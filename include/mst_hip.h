@@ -524,6 +524,13 @@ int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t L, const f
                   int32_t eos, int32_t pad, mst_stream_t stream);
 int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
                     mst_stream_t stream);
+/* Ancestral sampling on the device (sampler.py:155-190): every sequence n of N draws token i from probs[n, :V] (fp32, need not be
+ * normalised) by inverse CDF with u = counter hash of (seed, i, n); written to seqs[n, i] (int32 rows of L) and word[n] (the next
+ * position's input); scores[n] += -log p; a finished sequence (EOS, or PAD from position 2 on) continues with PAD at no cost;
+ * active[i] (optional, zeroed by the caller) += sequences still running. Capturable: the draw depends on device data and on the
+ * host constants (seed, i) only. */
+int mst_sample_step(int64_t N, int64_t V, int64_t i, int64_t L, const float* probs, int64_t ldp, int32_t* seqs, float* scores,
+                    int32_t* word, int32_t* active, uint64_t seed, int32_t eos, int32_t pad, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * K12/K13: softmax over V + SoftmaxCrossEntropy (model.py:256; loss.py:15-23).

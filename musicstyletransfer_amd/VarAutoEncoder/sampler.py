@@ -79,9 +79,18 @@ class Sampling(SamplerBase):
         B = tokens.shape[0]
         i_max = tokens.shape[1] * 2  # sampler.py:163
         dec = self.model.decoder
-        state = dec.get_initial_state(tokens, seq_lens, classes, t_max=i_max + 1, attention=self.attention)
         kind = self.model.engine_config.kind
         self.scores = np.zeros(B)
+        if kind == "token" and os.environ.get("MST_SAMPLE_DEVICE", "1") != "0":
+            # the draw on the device (decode.AncestralSampling): no distribution crosses to the host
+            from ..decode import AncestralSampling
+            key = (B, i_max, self.attention)
+            if getattr(self, "_dev_key", None) != (key, id(self.model.store)):
+                self._dev, self._dev_key = AncestralSampling(self.model.store, B, i_max, self.attention, seed=int(self.rng.integers(1 << 62))), (key, id(self.model.store))
+            seqs, scores = self._dev.run(dec.initial_rows(tokens, seq_lens, classes))
+            self.scores = scores.astype(np.float64)
+            return seqs.astype(np.int64)
+        state = dec.get_initial_state(tokens, seq_lens, classes, t_max=i_max + 1, attention=self.attention)
         if kind == "token":
             done = np.zeros(B, bool)
             for _ in range(1, i_max):

@@ -99,9 +99,69 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(const uint8_t* __restr
   }
 }
 
+// Ancestral sampling (sampler.py:155-190): one wave per sequence draws the next token from its distribution by inverse CDF —
+// u = counter hash of (seed, position, sequence) in (0, 1] times the row sum; lane l owns the contiguous chunk of ceil(V / 64)
+// tokens, a wave scan of the chunk sums finds the owning lane, which walks its chunk. A finished sequence (last token EOS, or
+// PAD from position 2 on) continues with PAD at no cost. score += -log max(p[token], 1e-30); active[i] counts running sequences.
+__global__ __launch_bounds__(256) void sample_step_kernel(int64_t N, int64_t V, int64_t i, int64_t L, const float* __restrict__ probs, int64_t ldp,
+                                                          int32_t* __restrict__ seqs, float* __restrict__ scores, int32_t* __restrict__ word,
+                                                          int32_t* __restrict__ active, uint64_t seed, int32_t eos, int32_t pad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int32_t last = seqs[n * L + i - 1];
+  const bool fin = (last == eos) || (last == pad && i > 1);
+  const float* row = probs + n * ldp;
+  const int chunk = (int)((V + 63) / 64);
+  const int lo = lane * chunk, hi = (lo + chunk < V) ? lo + chunk : (int)V;
+  float part = 0.f;
+  for (int w = lo; w < hi; ++w) part += row[w];
+  float incl = part;  // inclusive scan over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  const float total = __shfl(incl, 63, 64);
+  const uint32_t h = dropout_hash(seed, (uint32_t)i, (uint64_t)n);
+  const float target = ((float)(h >> 8) + 1.0f) * (1.0f / 16777216.0f) * total;  // in (0, total]
+  const bool mine = (incl >= target) && (incl - part < target);
+  int tok = -1;
+  if (mine) {
+    float acc = incl - part;
+    tok = hi - 1;
+    for (int w = lo; w < hi; ++w) {
+      acc += row[w];
+      if (acc >= target) { tok = w; break; }
+    }
+  }
+  // exactly one lane owns the draw (rounding at a chunk boundary could leave none: the last token with mass then takes it)
+  const unsigned long long owners = __ballot(mine && tok >= 0);
+  int chosen = tok;
+  if (owners == 0ull) chosen = (int)V - 1;
+  const int src_lane = owners ? (int)__builtin_ctzll(owners) : 0;
+  chosen = __shfl(chosen, src_lane, 64);
+  if (lane == 0) {
+    const int32_t w = fin ? pad : chosen;
+    seqs[n * L + i] = w;
+    word[n] = w;
+    if (!fin) scores[n] += -logf(fmaxf(row[chosen] / fmaxf(total, 1e-30f), 1e-30f));
+    if (active && w != eos && w != pad) atomicAdd(active + i, 1);
+  }
+}
+
 }  // namespace mst
 
 using namespace mst;
+
+extern "C" int mst_sample_step(int64_t N, int64_t V, int64_t i, int64_t L, const float* probs, int64_t ldp, int32_t* seqs, float* scores,
+                               int32_t* word, int32_t* active, uint64_t seed, int32_t eos, int32_t pad, mst_stream_t stream) {
+  MST_CHECK_ARG(N > 0 && V > 0 && i >= 1 && i < L && probs && seqs && scores && word && ldp >= V, "mst_sample_step: bad argument");
+  hipLaunchKernelGGL(sample_step_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, N, V, i, L, probs, ldp, seqs, scores, word,
+                     active, seed, eos, pad);
+  MST_CHECK_LAUNCH("sample_step_kernel");
+  return MST_OK;
+}
 
 extern "C" int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t L, const float* probs, int64_t ldp, const float* scores_in,
                              float* scores_out, const int32_t* seqs_in, int32_t* seqs_out, int32_t* hyp_src, int32_t* word, int32_t* active,

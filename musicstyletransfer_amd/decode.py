@@ -247,3 +247,50 @@ class BeamSearch:
         p._leave()
         self.positions = last
         return seqs, scores
+
+
+class AncestralSampling:
+    """Ancestral sampling (sampler.py:155-190, token ends) with the draw on the device (mst_sample_step): the host neither
+    sees the distributions nor feeds the tokens — it launches a position's kernels and polls a device counter of running
+    sequences every few positions."""
+
+    def __init__(self, store, B, i_max, attention="query", seed=0):
+        from .MIDIUtil.defaults import EOS_ID, PAD_ID, SOS_ID
+        self.B, self.i_max = B, i_max
+        self.eos, self.pad, self.sos = EOS_ID, PAD_ID, SOS_ID
+        self.plan = DecodePlan(store, B, i_max + 1, attention=attention)
+        dev = store.device
+        self.seqs = torch.zeros(B, i_max, dtype=torch.int32, device=dev)
+        self.scores = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.active = torch.zeros(i_max + 1, dtype=torch.int32, device=dev)
+        self.seed, self.runs = int(seed), 0
+        self.positions = 0
+
+    def run(self, row0, check_every=8):
+        """-> (token rows [B, n] int32, scores [B]) as host arrays. (Eager launches: the draw's seed changes from run to run and
+        is a kernel argument; a position is the decode step's ~10 launches + one draw, with no host round trip in between.)"""
+        p = self.plan
+        p.reset()
+        self.runs += 1
+        seed = (self.seed * 0x9E3779B97F4A7C15 + self.runs) & 0xFFFFFFFFFFFFFFFF
+        with p._enter():
+            p.x.copy_(row0[:, : p.x.shape[1]])
+            p._position(0)
+            p.t = 0
+            self.seqs.fill_(self.pad)
+            self.seqs[:, 0] = self.sos
+            o.zero(self.scores)
+            o.zero(self.active)
+            p.tokens.fill_(self.sos)
+            last = 0
+            for i in range(1, self.i_max):
+                p._position(i)
+                o.sample_step(p.probs, self.seqs, self.scores, p.tokens, i, seed, self.eos, self.pad, active=self.active)
+                p.t = last = i
+                if i % check_every == 0 and int(self.active[i].item()) == 0:
+                    break
+            seqs = self.seqs[:, : last + 1].cpu().numpy()
+            scores = self.scores.cpu().numpy()
+        p._leave()
+        self.positions = last
+        return seqs, scores

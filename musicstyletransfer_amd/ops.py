@@ -438,6 +438,12 @@ def beam_step(probs, scores_in, scores_out, seqs_in, seqs_out, hyp_src, word, i,
          ptr(seqs_out), ptr(hyp_src), ptr(word), ptr(active), eos, pad, stream())
 
 
+def sample_step(probs, seqs, scores, word, i, seed, eos, pad, active=None):
+    """ancestral sampling of position i for every sequence (mst_sample_step)"""
+    call("mst_sample_step", probs.shape[0], probs.shape[1], i, seqs.shape[1], ptr(probs), probs.stride(0), ptr(seqs), ptr(scores), ptr(word),
+         ptr(active), seed, eos, pad, stream())
+
+
 def beam_gather(cache_in, cache_out, src, n_rows):
     """cache_out[j, :n_rows] = cache_in[src[j], :n_rows] for [N, t_max, width] caches (mst_beam_gather)"""
     N, t_max, width = cache_in.shape

@@ -190,3 +190,42 @@ def test_model_call_and_sampler_state_run_in_inference_mode(gpu):
     want = np.sqrt(32.0) * init + O.positional_encodings(32, 1)[0]
     assert np.abs(st1.initial_state.float().cpu().numpy() - want).max() <= 0.15
     assert torch.equal(m.store.rng_state(0), rng_before), "inference must not advance the training RNG stream"
+
+
+def test_device_sampling_draws_from_the_distribution(gpu):
+    """mst_sample_step: inverse-CDF draws by counter hash — frequencies follow the distribution (N = 16384 sequences sharing one
+    unnormalised distribution, 6 sigma per token), the score picks up -log p of the drawn token, finished sequences continue with
+    PAD at no cost, draws are a function of (seed, position, sequence) alone"""
+    from musicstyletransfer_amd import ops as o
+    from music_style_transfer.MIDIUtil.defaults import EOS_ID, PAD_ID
+    N, V, L = 16384, 37, 6
+    g = torch.Generator().manual_seed(2)
+    p = torch.rand(V, generator=g) ** 3
+    p[5] = 0.0                                                   # a token that must never be drawn
+    probs = (3.0 * p).view(1, V).repeat(N, 1).contiguous().to(gpu)  # (unnormalised on purpose)
+    pn = (p / p.sum()).numpy().astype(np.float64)
+    seqs = torch.full((N, L), 7, dtype=torch.int32, device=gpu)
+    seqs[: N // 8, 1] = EOS_ID                                   # these sequences ended at position 1
+    scores = torch.zeros(N, device=gpu)
+    word = torch.zeros(N, dtype=torch.int32, device=gpu)
+    active = torch.zeros(L + 1, dtype=torch.int32, device=gpu)
+    o.sample_step(probs, seqs, scores, word, 2, 1234, EOS_ID, PAD_ID, active=active)
+    torch.cuda.synchronize()
+    tok = seqs[:, 2].cpu().numpy()
+    assert (tok[: N // 8] == PAD_ID).all() and (scores[: N // 8] == 0).all()
+    live = tok[N // 8:]
+    n = len(live)
+    counts = np.bincount(live, minlength=V).astype(np.float64)
+    assert counts[5] == 0
+    sigma = np.sqrt(n * pn * (1 - pn)) + 1.0
+    assert (np.abs(counts - n * pn) <= 6 * sigma).all(), np.abs(counts - n * pn).max()
+    np.testing.assert_allclose(scores[N // 8:].cpu().numpy(), -np.log(pn[live]), rtol=1e-4, atol=1e-5)
+    assert np.array_equal(word.cpu().numpy(), tok)
+    assert int(active[2].item()) == int(((live != EOS_ID) & (live != PAD_ID)).sum())
+    # same (seed, position, sequence) -> same draw; another seed -> another sample
+    seqs2 = seqs.clone(); scores2 = torch.zeros(N, device=gpu)
+    o.sample_step(probs, seqs2, scores2, word, 2, 1234, EOS_ID, PAD_ID)
+    seqs3 = seqs.clone()
+    o.sample_step(probs, seqs3, scores2, word, 2, 99, EOS_ID, PAD_ID)
+    torch.cuda.synchronize()
+    assert torch.equal(seqs2[:, 2], seqs[:, 2]) and not torch.equal(seqs3[:, 2], seqs[:, 2])
