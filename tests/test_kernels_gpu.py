@@ -832,6 +832,7 @@ def attn_reference(qkv, keymask, B, S, H, dh, k_off, q_off, v_off):
 
 
 @pytest.mark.parametrize("B,S,H,dh,q_limit,dtype", [(8, 256, 8, 32, 0, BF), (3, 200, 4, 32, 0, BF), (8, 256, 8, 32, 1, BF), (5, 96, 2, 32, 0, torch.float16),
+                                                   (8, 224, 4, 32, 0, torch.float16), (2, 512, 2, 32, 0, BF),
                                                    (4, 64, 4, 16, 0, BF), (2, 640, 2, 32, 0, BF)])
 def test_attention_with_fused_projection_equals_gemm_then_attention(gpu, B, S, H, dh, q_limit, dtype):
     """mst_attn_qkv_fwd: the K | Q | V projection inside the attention launch (head size 32, resident sequences) against the GEMM
@@ -857,7 +858,7 @@ def test_attention_with_fused_projection_equals_gemm_then_attention(gpu, B, S, H
     qkv_b, lse_b, out_b = bufs()
     o.attn_qkv_fwd(x, W, bias, qkv_b, keymask, lse_b, out_b, B, S, H, dh, 0, D, 2 * D, q_limit=q_limit)
     torch.cuda.synchronize()
-    fused_shape = dh == 32 and S <= 256
+    fused_shape = dh == 32 and S <= 512
     if not fused_shape:
         assert torch.equal(qkv_a, qkv_b) and torch.equal(out_a, out_b) and torch.equal(lse_a, lse_b)
         return
