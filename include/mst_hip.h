@@ -621,6 +621,14 @@ int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, f
  * nothing to the running sums) */
 int mst_loss_combine_v(const mst_step_metrics* metrics, mst_stream_t stream);
 
+/* mst_adam_flat that also keeps the transposed 16-bit shadow of up to two matrices current (the piano-roll embedding tables,
+ * which the step's first launch reads): for an element of matrix j — emb[4j..4j+3] = {source offset in the flat bucket, offset
+ * in wt16, rows, cols}, host array — the new weight is also stored at wt16[dst + c * roundup8(rows) + r]. `base` is the flat
+ * offset of `w` itself (a launch over a sub-range of the bucket). Everything else as mst_adam_flat with advance_step = 0. */
+int mst_adam_flat_emb(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr, double beta1,
+                      double beta2, float eps, float wd, float rescale, float clip, int32_t* step_state,
+                      const mst_step_metrics* metrics, int64_t base, const int64_t* emb, int64_t n_emb, void* wt16, mst_stream_t stream);
+
 /* 16-bit shadow + transposed shadow refresh for a list of matrices.
  * desc: int64 [n_mat, 4] on device = {src_offset, dst_offset, rows, cols}; dst is [cols, ld_t] with
  * ld_t = roundup8(rows), pad columns zeroed. tiles: int64 prefix sums [n_mat+1] of 32x32 tile counts. */
@@ -662,6 +670,11 @@ typedef struct mst_step_begin_args {
   float* eps_out; int64_t n_eps; uint32_t eps_site; int64_t eps_index0;
   const int32_t* lens; int64_t B; uint8_t* mask_e; int64_t Se; int32_t add_e; uint8_t* mask_d; int64_t Sd; int32_t add_d;
   void* zero_a; int64_t zero_a_bytes; void* zero_b; int64_t zero_b_bytes;
+  /* Optional transposed-shadow refresh riding on the same launch (mst_transpose_shadows' arguments; sh_w == NULL: none): the
+   * 16-bit transposed copies of matrices that only the BACKWARD pass reads can be rebuilt from the fp32 weights at the start
+   * of the next step instead of in a launch of their own behind the optimizer. Matrices the launch itself reads (the
+   * piano-roll embedding tables of mst_gemm_nt_pair_begin) must not be listed: mst_adam_flat_emb keeps those current. */
+  int32_t sh_dtype; const float* sh_w; void* sh_wt16; const int64_t* sh_desc; const int64_t* sh_prefix; int64_t sh_n_mat, sh_tiles;
 } mst_step_begin_args;
 int mst_step_begin_v(const mst_step_begin_args* args, mst_stream_t stream);
 /* mst_step_begin and mst_gemm_nt_pair in ONE launch: nothing in the piano-roll ends' embedding GEMMs (the first arithmetic of the

@@ -122,6 +122,7 @@ class StepBeginArgs(C.Structure):
         ("eps_out", vp), ("n_eps", c_i64), ("eps_site", c_u32), ("eps_index0", c_i64),
         ("lens", vp), ("B", c_i64), ("mask_e", vp), ("Se", c_i64), ("add_e", c_i32), ("mask_d", vp), ("Sd", c_i64), ("add_d", c_i32),
         ("zero_a", vp), ("zero_a_bytes", c_i64), ("zero_b", vp), ("zero_b_bytes", c_i64),
+        ("sh_dtype", c_i32), ("sh_w", vp), ("sh_wt16", vp), ("sh_desc", vp), ("sh_prefix", vp), ("sh_n_mat", c_i64), ("sh_tiles", c_i64),
     ]
 
 
@@ -223,6 +224,8 @@ SIGNATURES = {
     "mst_loss_combine_v": (C.c_int, [C.POINTER(StepMetrics), vp]),
     "mst_adam_flat": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32,
                                 vp, C.c_int, C.POINTER(StepMetrics), vp]),
+    "mst_adam_flat_emb": (C.c_int, [C.c_int, c_i64, vp, vp, vp, vp, vp, c_f64, c_f64, c_f64, c_f32, c_f32, c_f32, c_f32, vp,
+                                    C.POINTER(StepMetrics), c_i64, C.POINTER(c_i64), c_i64, vp, vp]),
     "mst_transpose_shadows": (C.c_int, [C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
     "mst_segment_sumsq": (C.c_int, [vp, vp, c_i64, vp, vp]),
     "mst_cast_f32_to_act": (C.c_int, [C.c_int, c_i64, vp, vp, vp]),

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "step_begin.hpp"
+#include "shadows.hpp"
 
 namespace mst {
 
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
 // encoder's and the decoder's table) — small launches whose cost is mostly the launch.
 // n_begin > 0 (mst_gemm_nt_pair_begin): the first n_begin workgroups of the grid are the step's bookkeeping (step_begin.hpp).
 template <typename T, int BM, int BN, int WGM, int WGN, int BK, int PATH>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_args a0, mst_gemm_args a1, int tiles0, StepBegin sb, int n_begin) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_args a0, mst_gemm_args a1, int tiles0, int tiles1, StepBegin sb,
+                                                                       int n_begin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if ((int)blockIdx.x < n_begin) {
     step_begin_wg<WGM * WGN * 64>(sb, (int)blockIdx.x, n_begin);
@@ -531,6 +533,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_a
   int64_t m0, n0;
   float bias_pre[8];
   const int64_t tile = (int64_t)blockIdx.x - n_begin;  // (n_begin is a multiple of 8: a tile keeps its XCD)
+  if (tile >= tiles0 + tiles1) {
+    // behind the GEMM tiles: the transposed 16-bit shadows of the matrices only the backward pass reads, rebuilt from the weights the
+    // previous step's optimizer left (mst_step_begin_args.sh_*) — as a launch of their own behind the optimizer they cost 6.5 us
+    shadow_tile_wg<T>(sb.sh_w, reinterpret_cast<T*>(sb.sh_wt16), sb.sh_desc, sb.sh_prefix, sb.sh_n_mat, tile - tiles0 - tiles1,
+                      reinterpret_cast<float(*)[33]>(smem));
+    return;
+  }
   // (two straight-line copies of the tile, each reading its own argument block from the kernel arguments)
   if (tile < tiles0) {
     gemm_bias_preload<BM, BN>(a0, bias_pre, tile);
@@ -1871,8 +1880,8 @@ extern "C" int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm
            (!a.grpadd || a.grp_index) && gemm_fast_form<64, 64>(a) && cdiv(a.M, 64) * cdiv(a.N, 64) < (1 << 20);
   };
   static const bool off = getenv("MST_GEMM_PAIR") && getenv("MST_GEMM_PAIR")[0] == '0';
-  if (off || a0.dtype != a1.dtype || !plain(a0) || !plain(a1)) {
-    int rc = begin ? mst_step_begin_v(begin, stream) : MST_OK;
+  if (off || a0.dtype != a1.dtype || !plain(a0) || !plain(a1) || (begin && begin->sh_w && begin->sh_dtype != a0.dtype)) {
+    int rc = begin ? mst_step_begin_v(begin, stream) : MST_OK;  // (runs the shadow refresh as a launch of its own)
     if (rc == MST_OK) rc = mst_gemm_nt(args0, stream);
     return rc != MST_OK ? rc : mst_gemm_nt(args1, stream);
   }
@@ -1889,8 +1898,9 @@ extern "C" int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm
     typedef decltype(tag) T;
     const int tiles0 = (int)((a0.M / 64) * (a0.N / 64)), tiles1 = (int)((a1.M / 64) * (a1.N / 64));
     const size_t lds = (size_t)2 * (64 + 64) * 64 * 2;  // K-loop stages; the 64 x 68 fp32 epilogue staging is smaller
-    hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(n_begin + tiles0 + tiles1)), dim3(256), lds, s, a0, a1,
-                       tiles0, sb, n_begin);
+    const int64_t sh_tiles = sb.sh_w ? sb.sh_tiles : 0;
+    hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(n_begin + tiles0 + tiles1 + sh_tiles)), dim3(256), lds, s, a0,
+                       a1, tiles0, tiles1, sb, n_begin);
     MST_CHECK_LAUNCH("gemm_nt_pair_kernel");
     return MST_OK;
   });

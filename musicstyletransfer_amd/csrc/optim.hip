@@ -12,6 +12,7 @@
 #include <math.h>
 #include "common.hpp"
 #include "loss_combine.hpp"
+#include "shadows.hpp"
 
 namespace mst {
 
@@ -24,12 +25,32 @@ __global__ void adam_tick_kernel(int32_t* state, double lr, double beta1, double
   reinterpret_cast<float*>(state)[1] = (float)(lr * sqrt(c2) / c1);
 }
 
+// transposed shadows kept current by the optimizer itself (mst_adam_flat_emb): up to two matrices, flat offsets relative to the
+// launch's own `w`
+struct AdamEmb {
+  int n;
+  int64_t lo[2], hi[2], dst[2];
+  int32_t rows[2], cols[2];
+  void* wt16;
+};
+template <typename T>
+__device__ __forceinline__ void adam_emb_store(const AdamEmb& e, int64_t i, float wnew) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (j < e.n && i >= e.lo[j] && i < e.hi[j]) {
+      const uint32_t k = (uint32_t)(i - e.lo[j]);
+      const uint32_t r = k / (uint32_t)e.cols[j], c = k - r * (uint32_t)e.cols[j];
+      const int64_t ld_t = ((int64_t)e.rows[j] + 7) / 8 * 8;
+      reinterpret_cast<T*>(e.wt16)[e.dst[j] + (int64_t)c * ld_t + r] = from_f32<T>(wnew);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ grad,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         T* __restrict__ w16, const int32_t* __restrict__ state,
                                                         float beta1, float beta2, float eps, float wd, float rescale,
-                                                        float clip, mst_step_metrics mt, int32_t* state_rw) {
+                                                        float clip, mst_step_metrics mt, int32_t* state_rw, AdamEmb emb) {
   __shared__ float red[2][4];
   bool incomplete;
   if (step_is_bad(mt, incomplete)) {
@@ -66,6 +87,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __rest
       o[1] = (uint32_t)f32_to_bits<T>(wv[2]) | ((uint32_t)f32_to_bits<T>(wv[3]) << 16);
       reinterpret_cast<u32x2*>(w16)[i] = o;
     }
+    if (emb.n > 0 && ((4 * i + 3 >= emb.lo[0] && 4 * i < emb.hi[0]) || (emb.n > 1 && 4 * i + 3 >= emb.lo[1] && 4 * i < emb.hi[1]))) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) adam_emb_store<T>(emb, 4 * i + e, wv[e]);
+    }
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0) {
@@ -77,6 +102,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __rest
       const float ww = w[i] - lr_t * mm / (sqrtf(vv) + eps);
       m[i] = mm; v[i] = vv; w[i] = ww;
       if (w16) w16[i] = from_f32<T>(ww);
+      adam_emb_store<T>(emb, i, ww);
     }
   }
 }
@@ -88,25 +114,7 @@ __global__ __launch_bounds__(256) void transpose_shadows_kernel(const float* __r
                                                                 const int64_t* __restrict__ desc,
                                                                 const int64_t* __restrict__ tile_prefix, int n_mat) {
   __shared__ float tile[32][33];
-  const int64_t tb = blockIdx.x;
-  int mi = 0;
-  for (int i = 1; i < n_mat; ++i)
-    if (tb >= tile_prefix[i]) mi = i;
-  const int64_t src_off = desc[4 * mi], dst_off = desc[4 * mi + 1], rows = desc[4 * mi + 2], cols = desc[4 * mi + 3];
-  const int64_t ld_t = (rows + 7) / 8 * 8;
-  const int64_t local = tb - tile_prefix[mi];
-  const int64_t tiles_c = (cols + 31) / 32;
-  const int64_t r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int j = ty; j < 32; j += 8) {
-    const int64_t r = r0 + j, c = c0 + tx;
-    tile[j][tx] = (r < rows && c < cols) ? w[src_off + r * cols + c] : 0.f;
-  }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    const int64_t c = c0 + j, r = r0 + tx;  // dst row = c, dst col = r
-    if (c < cols && r < ld_t) wt16[dst_off + c * ld_t + r] = from_f32<T>(tile[tx][j]);
-  }
+  shadow_tile_wg<T>(w, wt16, desc, tile_prefix, n_mat, (int64_t)blockIdx.x, tile);
 }
 
 template <typename T>
@@ -136,9 +144,9 @@ static unsigned grid_for(int64_t n, int per_thread) {
   return (unsigned)g;
 }
 
-extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr,
-                             double beta1, double beta2, float eps, float wd, float rescale, float clip,
-                             int32_t* step_state, int advance_step, const mst_step_metrics* metrics, mst_stream_t stream) {
+static int adam_flat_impl(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr,
+                          double beta1, double beta2, float eps, float wd, float rescale, float clip,
+                          int32_t* step_state, int advance_step, const mst_step_metrics* metrics, const AdamEmb& emb, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
   mst_step_metrics mt = {0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
   if (metrics) {
@@ -156,10 +164,34 @@ extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, 
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     hipLaunchKernelGGL((adam_flat_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, s, n, w, grad, m, v, (T*)w16, step_state,
-                       (float)beta1, (float)beta2, eps, wd, rescale, clip, mt, step_state);
+                       (float)beta1, (float)beta2, eps, wd, rescale, clip, mt, step_state, emb);
     MST_CHECK_LAUNCH("adam_flat_kernel");
     return MST_OK;
   });
+}
+
+extern "C" int mst_adam_flat(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr,
+                             double beta1, double beta2, float eps, float wd, float rescale, float clip,
+                             int32_t* step_state, int advance_step, const mst_step_metrics* metrics, mst_stream_t stream) {
+  AdamEmb none = {};
+  return adam_flat_impl(dtype, n, w, grad, m, v, w16, lr, beta1, beta2, eps, wd, rescale, clip, step_state, advance_step, metrics, none, stream);
+}
+
+extern "C" int mst_adam_flat_emb(int dtype, int64_t n, float* w, const float* grad, float* m, float* v, void* w16, double lr, double beta1,
+                                 double beta2, float eps, float wd, float rescale, float clip, int32_t* step_state,
+                                 const mst_step_metrics* metrics, int64_t base, const int64_t* emb, int64_t n_emb, void* wt16,
+                                 mst_stream_t stream) {
+  MST_CHECK_ARG(n_emb >= 0 && n_emb <= 2 && (n_emb == 0 || (emb && wt16)) && base >= 0, "mst_adam_flat_emb: up to two matrices, with their table and wt16");
+  AdamEmb e = {};
+  for (int j = 0; j < (int)n_emb; ++j) {
+    const int64_t so = emb[4 * j], dst = emb[4 * j + 1], rows = emb[4 * j + 2], cols = emb[4 * j + 3];
+    MST_CHECK_ARG(rows > 0 && cols > 0 && rows * cols < (1ll << 31) && dst >= 0, "mst_adam_flat_emb: bad matrix %d", j);
+    // (a matrix outside this launch's range [base, base + n) simply never matches)
+    e.lo[e.n] = so - base; e.hi[e.n] = so - base + rows * cols; e.dst[e.n] = dst; e.rows[e.n] = (int32_t)rows; e.cols[e.n] = (int32_t)cols;
+    ++e.n;
+  }
+  e.wt16 = wt16;
+  return adam_flat_impl(dtype, n, w, grad, m, v, w16, lr, beta1, beta2, eps, wd, rescale, clip, step_state, 0, metrics, e, stream);
 }
 
 extern "C" int mst_transpose_shadows(int dtype, const float* w, void* wt16, const int64_t* desc,

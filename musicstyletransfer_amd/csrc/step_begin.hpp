@@ -23,6 +23,8 @@ struct StepBegin {  // mst_step_begin_args with the zero lists in 16-byte units 
   float* eps_out; int64_t n_eps; uint32_t eps_site; int64_t eps_index0;
   const int32_t* lens; int64_t B; uint8_t* mask_e; int64_t Se; int32_t add_e; uint8_t* mask_d; int64_t Sd; int32_t add_d;
   u32x4* zero_a; int64_t n16_a; u32x4* zero_b; int64_t n16_b; int n_state;
+  // optional transposed-shadow refresh hosted by the same launch (mst_step_begin_args.sh_*; sh_w == nullptr: none)
+  const float* sh_w; void* sh_wt16; const int64_t* sh_desc; const int64_t* sh_prefix; int sh_n_mat; int64_t sh_tiles;
 };
 
 // Workgroup `wg` of `nwg` (NT threads each). Every workgroup derives the new seed itself from (base seed, step counter + 1); the
@@ -116,7 +118,13 @@ static inline int pack_step_begin(const mst_step_begin_args& a, StepBegin& q, in
   if (g < n_state) g = n_state;
   *grid = g;
   q = StepBegin{a.rng_state, a.adam_state, a.lr, a.beta1, a.beta2, a.eps_out, a.n_eps, a.eps_site, a.eps_index0, a.lens, a.B,
-                a.mask_e, a.Se, a.add_e, a.mask_d, a.Sd, a.add_d, (u32x4*)a.zero_a, n16_a, (u32x4*)a.zero_b, n16_b, (int)n_state};
+                a.mask_e, a.Se, a.add_e, a.mask_d, a.Sd, a.add_d, (u32x4*)a.zero_a, n16_a, (u32x4*)a.zero_b, n16_b, (int)n_state,
+                nullptr, nullptr, nullptr, nullptr, 0, 0};
+  if (a.sh_w) {
+    MST_CHECK_ARG(a.sh_wt16 && a.sh_desc && a.sh_prefix && a.sh_n_mat > 0 && a.sh_tiles > 0 && a.sh_tiles < (1ll << 30),
+                  "mst_step_begin: the shadow refresh needs w, wt16, the matrix table and its tile prefix sums");
+    q.sh_w = a.sh_w; q.sh_wt16 = a.sh_wt16; q.sh_desc = a.sh_desc; q.sh_prefix = a.sh_prefix; q.sh_n_mat = (int)a.sh_n_mat; q.sh_tiles = a.sh_tiles;
+  }
   return MST_OK;
 }
 

@@ -58,6 +58,9 @@ extern "C" int mst_step_begin_v(const mst_step_begin_args* args, mst_stream_t st
   if (rc) return rc;
   hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)grid), dim3(SB_THREADS), 0, (hipStream_t)stream, q);
   MST_CHECK_LAUNCH("step_begin_kernel");
+  // (as a launch of its own the bookkeeping hosts nothing: a requested shadow refresh is the separate launch it always was)
+  if (args->sh_w)
+    return mst_transpose_shadows(args->sh_dtype, args->sh_w, args->sh_wt16, args->sh_desc, args->sh_prefix, args->sh_n_mat, args->sh_tiles, stream);
   return MST_OK;
 }
 
@@ -66,7 +69,7 @@ extern "C" int mst_step_begin(uint64_t* rng_state, int32_t* adam_state, double l
                               int32_t add_e, uint8_t* mask_d, int64_t Sd, int32_t add_d, void* zero_a, int64_t zero_a_bytes,
                               void* zero_b, int64_t zero_b_bytes, mst_stream_t stream) {
   const mst_step_begin_args a = {rng_state, adam_state, lr, beta1, beta2, eps_out, n_eps, eps_site, eps_index0, lens, B, mask_e, Se,
-                                 add_e, mask_d, Sd, add_d, zero_a, zero_a_bytes, zero_b, zero_b_bytes};
+                                 add_e, mask_d, Sd, add_d, zero_a, zero_a_bytes, zero_b, zero_b_bytes, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
   return mst_step_begin_v(&a, stream);
 }
 

@@ -182,6 +182,23 @@ class ParamStore:
         self.t_desc = torch.tensor(desc, dtype=torch.int64, device=device)
         self.t_prefix = torch.tensor(prefix, dtype=torch.int64, device=device)
         self.t_tiles = prefix[-1]
+        # Deferred shadow refresh (piano-roll ends): the transposed shadows of the matrices only the BACKWARD pass reads are rebuilt by
+        # extra workgroups of the NEXT step's first launch (mst_gemm_nt_pair_begin, sh_*) instead of a launch of their own behind the
+        # optimizer; the two embedding tables, which that first launch itself reads, are kept current by the optimizer launch
+        # (mst_adam_flat_emb). MST_SHADOW_RIDE=0: the separate launch.
+        emb_names = [n for n in ("encoder.embedding.weight", "decoder.embedding.weight") if n in self.t_specs]
+        late = [n for n in self.t_specs if n not in emb_names]
+        self.shadows_deferred = (cfg.kind == "pianoroll" and len(emb_names) == 2 and len(late) > 0 and
+                                 os.environ.get("MST_SHADOW_RIDE", "1") != "0" and os.environ.get("MST_BEGIN_RIDE", "1") != "0")
+        ldesc, lprefix = [], [0]
+        for name in late:
+            so, r, c = self.t_specs[name]
+            ldesc += [so, self.t_off[name], r, c]
+            lprefix.append(lprefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+        self.t_desc_late = torch.tensor(ldesc or [0, 0, 1, 1], dtype=torch.int64, device=device)
+        self.t_prefix_late = torch.tensor(lprefix, dtype=torch.int64, device=device)
+        self.t_n_late, self.t_tiles_late = len(late), lprefix[-1]
+        self.emb_specs = [(self.t_specs[n][0], self.t_off[n], self.t_specs[n][1], self.t_specs[n][2]) for n in emb_names]
 
         # shared by every StepPlan of this store (plans run one after the other on one stream): the per-step RNG state
         # — ONE stream of seeds however many (B, T) shapes a run goes through — and the weight-gradient work buffer
@@ -814,6 +831,8 @@ class StepPlan:
                      eps_index0=self.sample_offset * cfg.latent_dim, lens=self.seq_lens,
                      mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
                      zero_a=self._recon_buf, zero_b=st.g if tick else None)
+        if st.shadows_deferred and cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0":
+            begin["shadows"] = dict(w=st.w, wt16=st.wt16, desc=st.t_desc_late, prefix=st.t_prefix_late, n_mat=st.t_n_late, tiles=st.t_tiles_late)
         # (piano-roll ends: nothing in the embedding GEMMs reads what the bookkeeping writes — it rides on their launch)
         ride = cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0"
         if not ride:
@@ -1189,9 +1208,10 @@ class StepPlan:
         # end-of-step bookkeeping (total loss, running metric sums) on the first Adam launch: losses(combine=False)
         guard = self._guard()
         mt = dict(recon=self.recon, kl=self.kl, kl_weight=self.kl_weight, total=self.total, metric=self.metric_acc, **guard)
+        emb = (lambda base: dict(base=base, specs=st.emb_specs, wt16=st.wt16)) if st.shadows_deferred else (lambda base: None)
         if self.gscale == self.gscale_enc:
             o.adam_flat(st.w, st.g, st.m, st.v, st.w16, st.step_state, lr=self.lr,
-                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, metrics=mt, **self.opt)
+                        rescale=1.0 / (self.global_batch * self.gscale), clip=clip, advance_step=False, metrics=mt, emb=emb(0), **self.opt)
         else:
             # encoder.* tensors come first in the flat buffers; everything from decoder.latent2hid on is decoder-side.
             # NOTE the latent_proj gradients are produced by latent_bwd at the encoder-side scale.
@@ -1200,8 +1220,9 @@ class StepPlan:
             for a, b, gs, adv in rng:
                 o.adam_flat(st.w[a:b], st.g[a:b], st.m[a:b], st.v[a:b], st.w16[a:b], st.step_state, lr=self.lr,
                             rescale=1.0 / (self.global_batch * gs), clip=clip, advance_step=adv,
-                            metrics=mt if a == 0 else (guard or None), **self.opt)
-        o.transpose_shadows(st.w, st.wt16, st.t_desc, st.t_prefix, len(st.t_specs), st.t_tiles)
+                            metrics=mt if a == 0 else (guard or None), emb=emb(a), **self.opt)
+        if not st.shadows_deferred:  # (deferred: the next step's first launch rebuilds them, forward())
+            o.transpose_shadows(st.w, st.wt16, st.t_desc, st.t_prefix, len(st.t_specs), st.t_tiles)
 
     # ------------------------------------------------------------------------------ step
     def fwd_bwd_kernels(self, is_train=True):

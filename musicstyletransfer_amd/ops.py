@@ -603,10 +603,17 @@ def loss_combine(recon, kl, kl_weight, total=None, metric_acc=None, guard=None):
 
 # --------------------------------------------------------------------------- optimizer / shadows
 def adam_flat(w, grad, m, v, w16, step_state, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0, clip=-1.0,
-              advance_step=True, metrics=None):
+              advance_step=True, metrics=None, emb=None):
     """metrics: dict(recon, kl, kl_weight, total, metric) -> loss_combine's bookkeeping runs in this launch;
     + status / expect: the step guard (_step_metrics)"""
     mt = _step_metrics(metrics) if metrics is not None else None
+    if emb is not None:  # (the optimizer keeps the transposed shadows of these matrices current: mst_adam_flat_emb)
+        assert not advance_step
+        flat = [int(x) for spec in emb["specs"] for x in spec]
+        call("mst_adam_flat_emb", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd, rescale, clip,
+             ptr(step_state), C.byref(mt) if mt is not None else None, emb.get("base", 0), (_lib.c_i64 * len(flat))(*flat), len(emb["specs"]),
+             ptr(emb["wt16"]), stream())
+        return
     call("mst_adam_flat", dt(w16), w.numel(), ptr(w), ptr(grad), ptr(m), ptr(v), ptr(w16), lr, beta1, beta2, eps, wd,
          rescale, clip, ptr(step_state), 1 if advance_step else 0, C.byref(mt) if mt is not None else None, stream())
 
@@ -645,7 +652,9 @@ def randn(out, seed=0, seed_ptr=None, site=0):
 
 
 def _step_begin_args(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0.999, eps_out=None, eps_site=0x7FFF0000, eps_index0=0,
-                     lens=None, mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None):
+                     lens=None, mask_e=None, add_e=0, mask_d=None, add_d=1, zero_a=None, zero_b=None, shadows=None):
+    """shadows: dict(w, wt16, desc, prefix, n_mat, tiles) — a transposed-shadow refresh (transpose_shadows' arguments) hosted by the
+    launch that carries the bookkeeping"""
     q = StepBeginArgs()
     nbytes = lambda t: t.numel() * t.element_size() if t is not None else 0
     q.rng_state, q.adam_state, q.lr, q.beta1, q.beta2 = ptr(rng_state), ptr(adam_state), lr, beta1, beta2
@@ -654,6 +663,9 @@ def _step_begin_args(rng_state=None, adam_state=None, lr=0.0, beta1=0.9, beta2=0
     q.mask_e, q.Se, q.add_e = ptr(mask_e), (mask_e.shape[1] if mask_e is not None else 0), add_e
     q.mask_d, q.Sd, q.add_d = ptr(mask_d), (mask_d.shape[1] if mask_d is not None else 0), add_d
     q.zero_a, q.zero_a_bytes, q.zero_b, q.zero_b_bytes = ptr(zero_a), nbytes(zero_a), ptr(zero_b), nbytes(zero_b)
+    if shadows:
+        q.sh_dtype, q.sh_w, q.sh_wt16 = dt(shadows["wt16"]), ptr(shadows["w"]), ptr(shadows["wt16"])
+        q.sh_desc, q.sh_prefix, q.sh_n_mat, q.sh_tiles = ptr(shadows["desc"]), ptr(shadows["prefix"]), shadows["n_mat"], shadows["tiles"]
     return q
 
 

@@ -539,3 +539,47 @@ def test_a_failed_position0_tail_is_flagged_skipped_and_replaced_by_the_five_lau
     store.step_status[0:1].fill_(1)
     with pytest.raises(RuntimeError, match="position-0 tail"):
         store.read_metrics()
+
+
+def test_transposed_shadows_follow_the_weights_without_their_own_launch(gpu):
+    """Piano-roll ends: the optimizer launch keeps the two embedding tables' transposed shadows current (mst_adam_flat_emb) and the NEXT
+    step's first launch rebuilds the backward-only ones (mst_gemm_nt_pair_begin, sh_*): after the optimizer the embedding shadows
+    equal the weights, after the next forward pass all of them do — and the run equals one with the separate refresh launch."""
+    import os
+    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (48, 48, 2, 16, 64, 2, 2, 32, 1, 2), 4, 16, 61)
+
+    def fresh(st, names):
+        ok = True
+        for n in names:
+            so, r, c = st.t_specs[n]
+            want = st.w[so: so + r * c].view(r, c).t().to(st.act_dtype)
+            ok &= bool(torch.equal(st.t(n)[:, :r], want))
+        return ok
+
+    res = {}
+    for ride in ("1", "0"):
+        os.environ["MST_SHADOW_RIDE"] = ride
+        try:
+            store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+        finally:
+            os.environ.pop("MST_SHADOW_RIDE", None)
+        assert store.shadows_deferred == (ride == "1")
+        plan = E.StepPlan(store, 4, 16, lr=1e-2)
+        plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
+        for _ in range(3):
+            plan.step_kernels(True)
+        torch.cuda.synchronize()
+        emb = ["encoder.embedding.weight", "decoder.embedding.weight"]
+        late = [n for n in store.t_specs if n not in emb]
+        assert fresh(store, emb)
+        if ride == "1":
+            assert not fresh(store, late), "the backward-only shadows are one optimizer step behind until the next forward pass"
+            plan._tick_adam = False
+            plan.forward()
+            torch.cuda.synchronize()
+        assert fresh(store, emb + late)
+        res[ride] = store.w.cpu().numpy().copy()
+    # (not bit for bit: the small configuration's LayerNorm parameter gradients and loss sums are fp32 atomics, order-dependent in
+    # the last bits from run to run whatever the path)
+    from test_parallel_gpu import _close_after_adam
+    _close_after_adam(res["1"], res["0"], 1e-2, 3)
