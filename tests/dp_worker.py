@@ -24,7 +24,7 @@ def engine_params(E, cfg):
     return params
 
 
-def engine_batch():
+def engine_batch(T_LEN=T_LEN):
     import numpy as np
     rng = np.random.default_rng(78)
     roll = (rng.random((B_GLOBAL, T_LEN + 1, ENGINE_DIMS[1])) < 0.1).astype(np.uint8)
@@ -35,14 +35,23 @@ def engine_batch():
                 classes=rng.integers(0, 2, size=B_GLOBAL).astype(np.int64))
 
 
-def run_engine(rank, world, reducer=None, reduce_fn=None):
+# the headline configuration's paths under co-tenancy: encoder width 256 with heads of 32 and 6 row blocks (the K|Q|V projection inside
+# the attention launch), two encoder layers (the one-launch position-0 tails, whose grid barrier needs 16 workgroups of an
+# oversubscribed launch on ONE XCD — with a second process launching the same kernels on the same card)
+WIDE_DIMS = ("pianoroll", 32, 32, 2, 16, 256, 2, 8, 64, 1, 4)
+WIDE_T = 192
+
+
+def run_engine(rank, world, reducer=None, reduce_fn=None, wide=False):
     """STEPS training steps of this rank's shard; returns what the parent compares"""
     import torch
     from musicstyletransfer_amd import engine as E
     dev = torch.device("cuda", torch.cuda.current_device())
-    cfg = E.VAEConfig(*ENGINE_DIMS)
+    dims, T_LEN = (WIDE_DIMS, WIDE_T) if wide else (ENGINE_DIMS, globals()["T_LEN"])
+    cfg = E.VAEConfig(*dims)
     store = E.ParamStore(cfg, dev, torch.bfloat16, params_np=engine_params(E, cfg))
-    b = engine_batch()
+    store.tail_policy = "raise"
+    b = engine_batch(T_LEN)
     per = B_GLOBAL // world
     lo, hi = rank * per, (rank + 1) * per
     plan = E.StepPlan(store, per, T_LEN, lr=LR, clip_gradient=1.0, global_batch=B_GLOBAL, internal_eps=True, seed=SEED,
@@ -57,8 +66,10 @@ def run_engine(rank, world, reducer=None, reduce_fn=None):
         for _ in range(STEPS - 1):
             plan.run(reduce_fn=reduce_fn, reducer=reducer)
         st.synchronize()
+    status = store.read_metrics(reset=False)  # (raises if a step was skipped: tail_policy)
     return dict(w=store.w.cpu().numpy(), g1=g1, eps1=eps1, total1=tot1, total_last=plan.total.cpu().numpy(),
-                steps=int(store.step_state[0].item()), three_graphs=int(plan.graph_late is not None))
+                steps=int(store.step_state[0].item()), three_graphs=int(plan.graph_late is not None),
+                tails=int(plan._tail_used["fwd"]) + int(plan._tail_used["bwd"]), tail_fused=int(store.tail_fused), skipped=int(status["skipped_steps"]))
 
 
 def trainer_setup():
@@ -117,9 +128,10 @@ def main():
         from musicstyletransfer_amd import parallel
         dist = parallel.init_process_group(a.world, a.rank)
         eng = run_engine(a.rank, a.world, reducer=parallel.GradReducer(dist), reduce_fn=parallel.make_grad_allreduce(dist))
+        wide = run_engine(a.rank, a.world, reducer=parallel.GradReducer(dist), reduce_fn=parallel.make_grad_allreduce(dist), wide=True)
         tr = run_trainer()
         np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **{"eng_" + k: v for k, v in eng.items()},
-                 **{"tr_" + k: v for k, v in tr.items()})
+                 **{"wide_" + k: v for k, v in wide.items()}, **{"tr_" + k: v for k, v in tr.items()})
         dist.barrier()
         dist.destroy_process_group()
     except BaseException:

@@ -42,6 +42,34 @@ def test_engine_two_ranks_match_the_single_process_global_batch(gpu, dp_results)
     _close_after_adam(r0["eng_w"], ref["w"], W.LR, W.STEPS)
 
 
+def test_wide_engine_two_ranks_share_the_card_with_the_one_launch_tails(gpu, dp_results):
+    """the same comparison at the headline configuration's widths: both ranks run the one-launch position-0 tails (a grid barrier among
+    16 workgroups that must land on one XCD) and the attention launch with the projection inside WHILE SHARING THE CARD — the
+    co-tenancy the step guard exists for. No step may have been skipped, the tails must still be in use, and the two ranks' run must
+    equal the single-process run of the global batch."""
+    import dp_worker as W
+    ref = W.run_engine(0, 1, wide=True)
+    r0, r1 = dp_results
+    for r in (r0, r1):
+        assert int(r["wide_skipped"]) == 0 and int(r["wide_tail_fused"]) == 1 and int(r["wide_tails"]) == 2
+        assert int(r["wide_three_graphs"]) == 1 and int(r["wide_steps"]) == W.STEPS
+    assert ref["tails"] == 2 and ref["skipped"] == 0
+    per = W.B_GLOBAL // 2
+    assert np.array_equal(r0["wide_eps1"], ref["eps1"][:per]) and np.array_equal(r1["wide_eps1"], ref["eps1"][per:])
+    # At these widths the feed-forward launches are the fused ones, whose workgroups walk the hidden chunks in an order rotated by
+    # their position in the launch (gemm_nt.hip MST_FFN_ROT: 8 us per step): the fp32 sum of FFN2 runs in another order for a row
+    # block that sits elsewhere in the launch, i.e. a shard equals the global batch to a rounding of the activation type (most
+    # samples bit for bit, a few elements one bf16 ulp apart), not bit for bit as at the narrow widths above
+    np.testing.assert_allclose(np.concatenate([r0["wide_total1"], r1["wide_total1"]]), ref["total1"], rtol=2e-3)
+    assert (np.concatenate([r0["wide_total1"], r1["wide_total1"]]) == ref["total1"]).mean() >= 0.5
+    assert np.array_equal(r0["wide_g1"], r1["wide_g1"]) and np.array_equal(r0["wide_w"], r1["wide_w"])
+    scale = np.abs(ref["g1"]).max()
+    assert np.abs(r0["wide_g1"] - ref["g1"]).max() <= 1e-2 * scale, np.abs(r0["wide_g1"] - ref["g1"]).max() / scale
+    # (Adam's update is ~lr * sign(g): gradients that agree to a rounding still flip the sign of the near-zero ones)
+    d = np.abs(r0["wide_w"] - ref["w"])
+    assert d.max() <= 2.1 * W.LR * W.STEPS and (d > 0.5 * W.LR).mean() < 0.05, (d.max(), (d > 0.5 * W.LR).mean())
+
+
 def test_trainer_two_ranks_match_the_single_rank_trainer(gpu, dp_results):
     import dp_worker as W
     for k in ("WORLD_SIZE", "RANK"):
