@@ -1176,8 +1176,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     kf[s] = glb_row_frag<T>(Kg, a.ld_qkv, wave * 32 + (lane & 31), S, s, lane);
     vf[s] = glb_row_frag<T>(Vg, a.ld_qkv, wave * 32 + (lane & 31), S, s, lane);
   }
+  ATT_STAMP(0);
   stage_pair<T, DH>(bufA, Qg, a.ld_qkv, S, bufB, dOg, a.ld_dout, do_rows, SP, tid, nthr);
   __syncthreads();
+  ATT_STAMP(1);
   const int nq0 = sparse ? 1 : NBo;  // (whole) query tiles that contribute to pass 0
 
   // ---- phase A: dV, delta, dK for the owned keys (attn_bwd_kv_kernel's two passes over the query tiles)
@@ -1223,6 +1225,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
       neg_delta = -delta;
     }
     owner_store<T, DH>(drow ? drow + a.v_off : nullptr, acc, lane);
+    ATT_STAMP(2);
     // ---- pass 1: dK
 #pragma unroll
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
@@ -1312,6 +1315,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
       }
     }
   }
+  ATT_STAMP(3);
   // phase B's first Q / dO fragments: requested before the barrier and the K / V staging
   typename Act<T>::vec8 qf[KS], dof[KS];
 #pragma unroll
@@ -1322,6 +1326,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   __syncthreads();  // every wave is done with the staged Q and dO
   stage_pair<T, DH>(bufA, Kg, a.ld_qkv, S, bufB, Vg, a.ld_qkv, S, SP, tid, nthr);
   const bool exact = __syncthreads_or(padded);
+  ATT_STAMP(4);
 
   // ---- phase B: dQ for the owned queries (attn_bwd_q_kernel's tiles)
   for (int ob = wave; ob < NBo; ob += NW) {
@@ -1352,6 +1357,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     }
     owner_store<T, DH>(q_lane < S ? dbase + a.q_off + q_lane * a.ld_dqkv : nullptr, acc, lane);
   }
+  ATT_STAMP(5);
   if constexpr (DH <= 16 && !SPARSE) {
     if (lone) {  // dQ of the lone query: keys on the lanes
       const int64_t e = S - 1;

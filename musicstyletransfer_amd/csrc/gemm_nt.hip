@@ -14,6 +14,7 @@
 #include <math.h>
 #include <type_traits>
 #include "common.hpp"
+#include "bce_math.hpp"
 #include "step_begin.hpp"
 #include "shadows.hpp"
 
@@ -780,8 +781,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 
 // ---------------------------------------------------------------------------------------------------------------
 // Output layer + per-pitch BCE in ONE launch (mst_gemm_sigmoid_bce): the decoder's Dense[D -> P] (model.py:253-256) with
-// sigmoid + BinaryCrossEntropy (loss.py:27-80) in its epilogue. The tile spans the whole row of P pitches (64 x 128 or
-// 64 x 256, the LDS-staged (time x pitch) tile), so logits never reach HBM: the epilogue turns the fp32 accumulators into the
+// sigmoid + BinaryCrossEntropy (loss.py:27-80) in its epilogue. A tile is 64 frames x BN pitches (128 or 256: the LDS-staged
+// (time x pitch) tile) — the whole row of pitches at configs[1], one of P / 256 column tiles of it at configs[2]'s 2048 (the
+// loss is a plain sum over frames and pitches, so column tiles only share the sample's atomic) — and the logits never reach
+// HBM: the epilogue turns the fp32 accumulators into the
 // logit gradient (the backward pass's operand), optionally the probabilities (reconstruction output), and the sample's
 // loss sum — the arithmetic of sigmoid_bce_kernel on the logit rounded to the activation type, which is what the two-launch
 // form reads back. A tile holds rows of ONE sample (the host requires T % 64 == 0): one atomic per workgroup.
@@ -795,8 +798,9 @@ __device__ __forceinline__ void gemm_bce_tile(const mst_gemm_args& a, const mst_
   f32x4 acc[TN][TM];
   int64_t m0, n0;
   float bias8[8];
-  gemm_bias_preload<BM, BN>(a, bias8);  // (BN == N: the chunk's columns do not depend on the tile)
+  gemm_bias_preload<BM, BN>(a, bias8);
   gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
+  const int64_t P = a.N;                       // pitches per frame (a multiple of BN: this tile holds columns [n0, n0 + BN))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, frow = lane & 15, fq = lane >> 4;
   float* sF = reinterpret_cast<float*>(smem);
@@ -806,7 +810,7 @@ __device__ __forceinline__ void gemm_bce_tile(const mst_gemm_args& a, const mst_
     for (int j = 0; j < TN; ++j)
       *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc[j][i];
   const int64_t b = m0 / q.T;                  // the tile's sample
-  const int64_t per_sample = q.T * (int64_t)BN;
+  const int64_t per_sample = q.T * P;
   float w = 0.f;
   if (q.downweight) {                          // loss.py:58-81: w_b = n_pos / (n_neg + 1e-12) over the SAMPLE's labels
     const uint8_t* lab = q.labels + b * per_sample;
@@ -819,46 +823,58 @@ __device__ __forceinline__ void gemm_bce_tile(const mst_gemm_args& a, const mst_
     float np = 0.f;
 #pragma unroll
     for (int i = 0; i < NT / 64; ++i) np += red[i];
-    w = np / (((float)q.T * (float)BN - np) + 1e-12f);
+    w = np / (((float)q.T * (float)P - np) + 1e-12f);
   }
   __syncthreads();                              // staged tile visible (and `red` free again)
   const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
-  const float inv_n = 1.f / ((float)q.T * (float)BN), ls = q.label_smoothing;
+  const int64_t gc = n0 + nc;                   // this thread's 8 pitches in the frame
+  const float inv_n = 1.f / ((float)q.T * (float)P), ls = q.label_smoothing;
   float lsum = 0.f;
+  const float s1 = (1.f - ls) + 0.5f * ls, s0 = 0.5f * ls;
+  auto sweep = [&](auto dwc) {
+    constexpr bool DW = decltype(dwc)::value;
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int row = row0 + it * RSTEP;
-    const int64_t m = m0 + row;
-    if (m >= a.M) continue;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
-    const float t8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const uint64_t lab8 = *reinterpret_cast<const uint64_t*>(q.labels + m * BN + nc);
-    Pack8 pb, gb, xb;
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = row0 + it * RSTEP;
+      const int64_t m = m0 + row;
+      const bool live = m < a.M;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
+      const float t8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const uint64_t lab8 = live ? *reinterpret_cast<const uint64_t*>(q.labels + m * P + gc) : 0ull;
+      Pack8 pb, gb, xb;
+      float x8[8];
+      bool in_dom = true;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xb.h[e] = f32_to_bits<T>((t8[e] + bias8[e]) * a.alpha);  // the logit as the unfused pipeline stores it
-      const float x = bits_to_f32<T>(xb.h[e]);
-      const float y = (float)((lab8 >> (8 * e)) & 0xFFull);
-      const float p = __frcp_rn(1.f + __expf(-x));
-      const float omp = 1.f - p;
-      const float sm = (1.f - ls) * y + 0.5f * ls;
-      const float lp = __logf(1e-12f + p), lq = __logf(1e-12f + omp);
-      float bce = -(sm * lp + (1.f - sm) * lq);
-      float dbce = -(sm * __frcp_rn(1e-12f + p) - (1.f - sm) * __frcp_rn(1e-12f + omp)) * p * omp;
-      if (q.downweight && y == 0.f) {  // loss.py:52-54: (w*bce)*bce where label == 0
-        dbce = 2.f * w * bce * dbce;
-        bce = w * bce * bce;
+      for (int e = 0; e < 8; ++e) {
+        xb.h[e] = f32_to_bits<T>((t8[e] + bias8[e]) * a.alpha);  // the logit as the unfused pipeline stores it
+        x8[e] = bits_to_f32<T>(xb.h[e]);
+        in_dom = in_dom && bce_fast_domain(x8[e]);
       }
-      lsum += bce;
-      pb.h[e] = f32_to_bits<T>(p);
-      gb.h[e] = f32_to_bits<T>(dbce * inv_n * q.gscale);
+      const bool fast = __all(in_dom || !live);  // wave-uniform (bce_math.hpp: three transcendental instructions per element, not six)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = (float)((lab8 >> (8 * e)) & 0xFFull);
+        float p, bce, dbce;
+        bce_fast<DW>(x8[e], y, s1, s0, w, p, bce, dbce);
+        if (!fast) {  // a saturated logit somewhere in this wave: ITS element takes the reference's operation order (an element's
+                      // result depends on its own logit only, so the fused and the two-launch forms agree bit for bit)
+          float p2, b2, d2;
+          bce_exact<DW>(x8[e], y, ls, w, p2, b2, d2);
+          if (!bce_fast_domain(x8[e])) { p = p2; bce = b2; dbce = d2; }
+        }
+        lsum += live ? bce : 0.f;
+        pb.h[e] = f32_to_bits<T>(p);
+        gb.h[e] = f32_to_bits<T>(dbce * inv_n * q.gscale);
+      }
+      if (!live) continue;
+      if (a.C) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + m * a.ldc + gc) = gb.u;
+      if constexpr (KEEP) keepA[(ch >> 3) * (BM * 8) + row * 8 + ((ch & 7) ^ (row & 7))] = gb.u;  // (KEEP: P == BN)
+      if (q.probs) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.probs) + m * q.ldp + gc) = pb.u;
+      if (q.logits) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.logits) + m * q.ldl + gc) = xb.u;
     }
-    if (a.C) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + m * a.ldc + nc) = gb.u;
-    if constexpr (KEEP) keepA[(ch >> 3) * (BM * 8) + row * 8 + ((ch & 7) ^ (row & 7))] = gb.u;
-    if (q.probs) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.probs) + m * q.ldp + nc) = pb.u;
-    if (q.logits) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.logits) + m * q.ldl + nc) = xb.u;
-  }
+  };
+  if (q.downweight) sweep(std::true_type()); else sweep(std::false_type());
   lsum = wave_sum(lsum);
   if (lane == 0) red[wave] = lsum;
   __syncthreads();
@@ -929,7 +945,7 @@ static int launch_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q, hipStr
       opted = true;
     }
   }
-  hipLaunchKernelGGL((gemm_bce_kernel<T, BN>), dim3((unsigned)cdiv(a.M, 64)), dim3(512), lds, s, a, q);
+  hipLaunchKernelGGL((gemm_bce_kernel<T, BN>), dim3((unsigned)(cdiv(a.M, 64) * (a.N / BN))), dim3(512), lds, s, a, q);
   MST_CHECK_LAUNCH("gemm_bce_kernel");
   return MST_OK;
 }
@@ -1765,8 +1781,10 @@ static int check_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q) {
   MST_CHECK_ARG(a.M > 0 && a.K > 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.A && a.B,
                 "mst_gemm_sigmoid_bce: bad GEMM operands");
   MST_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0), "mst_gemm_sigmoid_bce: operands must be 16-byte aligned");
-  MST_CHECK_ARG(a.N == 128 || a.N == 256, "mst_gemm_sigmoid_bce: the row of pitches must be 128 or 256 wide (got %lld): use mst_gemm_nt + "
-                "mst_sigmoid_bce for other widths", (long long)a.N);
+  MST_CHECK_ARG(a.N == 128 || (a.N > 0 && a.N % 256 == 0), "mst_gemm_sigmoid_bce: the row of pitches must be 128 or a multiple of 256 wide (got %lld): use "
+                "mst_gemm_nt + mst_sigmoid_bce for other widths", (long long)a.N);
+  MST_CHECK_ARG(a.N <= 256 || !q.downweight, "mst_gemm_sigmoid_bce: the label down-weighting counts a sample's positives in every workgroup — rows wider than "
+                "one tile (256) take mst_gemm_nt + mst_sigmoid_bce");
   MST_CHECK_ARG(q.T > 0 && q.T % 64 == 0 && a.M % q.T == 0, "mst_gemm_sigmoid_bce: T must be a multiple of 64 and divide M (a tile holds one sample's rows)");
   MST_CHECK_ARG(!a.c_f32 && !a.resid && !a.gate && !a.rowadd && !a.grpadd && a.act == MST_ACT_NONE && a.dropout_p == 0.f && !a.self_resid &&
                 a.c_rows_per_group <= 0 && !a.a_u8, "mst_gemm_sigmoid_bce: only bias, alpha and an A row remap are supported");
@@ -1786,7 +1804,7 @@ extern "C" int mst_gemm_sigmoid_bce(const mst_gemm_args* args, const mst_bce_arg
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (a.N == 256) return launch_gemm_bce<T, 256>(a, q, s);
+    if (a.N % 256 == 0) return launch_gemm_bce<T, 256>(a, q, s);
     return launch_gemm_bce<T, 128>(a, q, s);
   });
 }

@@ -46,7 +46,68 @@ __device__ __forceinline__ void wave_dots(const float* x, int n_in, const float*
   }
 }
 
-template <typename T>
+// wave_dots for contractions of at most 64 * CH elements with every weight load of a pass of U outputs issued up front and the
+// NEXT pass's loads in flight while the current one is reduced (two register sets): the weights are cold lines after every
+// optimizer step, and one dependent round trip per 64 elements of every output made latent_fwd 58 us at configs[2]
+// (2Z = 512 outputs of 256: four passes of four). Same FMA order per output as wave_dots. Loads are unconditional
+// (indices clamped, surplus products multiplied by zero): a conditional load costs a vmcnt(0) drain at the join.
+template <int U, int CH, typename F>
+__device__ __forceinline__ void wave_dots_pre(const float* x, int n_in, const float* __restrict__ W, int n_out, int wave, int n_waves,
+                                              int lane, F&& emit) {
+  const int step = n_waves * U;
+  float xs[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) xs[k] = (lane + 64 * k < n_in) ? x[lane + 64 * k] : 0.f;
+  auto load = [&](float (&w)[U][CH], int j0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u < n_out ? j0 + u : n_out - 1;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int d = lane + 64 * k < n_in ? lane + 64 * k : n_in - 1;
+        w[u][k] = W[(int64_t)j * n_in + d];
+      }
+    }
+  };
+  auto reduce = [&](const float (&w)[U][CH], int j0) {
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[u] = 0.f;
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (lane + 64 * k < n_in) acc[u] = fmaf(xs[k], w[u][k], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float v = wave_sum(acc[u]);
+      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
+    }
+  };
+  int j0 = wave * U;
+  if (j0 >= n_out) return;
+  float wa[U][CH], wb[U][CH];
+  load(wa, j0);
+  for (;;) {
+    const int j1 = j0 + step;
+    load(wb, j1 < n_out ? j1 : j0);  // (past the end: the same rows again, unused)
+    reduce(wa, j0);
+    if (j1 >= n_out) break;
+    const int j2 = j1 + step;
+    load(wa, j2 < n_out ? j2 : j1);
+    reduce(wb, j1);
+    if (j2 >= n_out) break;
+    j0 = j2;
+  }
+}
+
+// PRE: the small-shape form (both products in one pass of OPW outputs per wave, weights preloaded: latent_fwd_pre_shape); the
+// general form is a separate instantiation so that its two register sets per product do not cost the small one its registers
+// (in one kernel the 1024-thread launch bounds made the compiler spill 16 / 94 registers of the forward / backward fast paths).
+__host__ __device__ inline bool latent_fwd_pre_shape(int64_t De, int64_t Z, int64_t Dd) {
+  return 2 * Z <= (LAT_THREADS / 64) * OPW && De <= 64 * PRE_C && Dd <= (LAT_THREADS / 64) * OPW && Z <= 64;
+}
+template <typename T, bool PRE>
 __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, int Dd, const T* __restrict__ enc_out,
                                                          int64_t enc_stride, const float* __restrict__ Wl,
                                                          const float* __restrict__ bl, const float* __restrict__ eps,
@@ -68,11 +129,11 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
   // Every load whose ADDRESS does not depend on a result is issued before the first barrier: in the step all of these
   // lines are cold (the weights were rewritten by the optimizer), and the three phases used to pay five dependent
   // memory round trips (20 us for a few hundred kFLOP). Fast path: one pass of OPW outputs per wave in both products.
-  const bool pre1 = 2 * Z <= NW * OPW && De <= 64 * PRE_C, pre2 = Dd <= NW * OPW && Z <= 64;
+  constexpr bool pre1 = PRE, pre2 = PRE;
   const int c = classes[b];
   float w1[OPW][PRE_C], w2[OPW], b1 = 0.f, bh2 = 0.f, cls2 = 0.f, pos2 = 0.f, eps_r = 0.f;
   const int j1 = wave * OPW;  // this wave's outputs in both products
-  if (pre1) {
+  if constexpr (pre1) {
 #pragma unroll
     for (int u = 0; u < OPW; ++u)
 #pragma unroll
@@ -82,7 +143,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
       }
     if (lane < OPW && j1 + lane < 2 * Z) b1 = bl[j1 + lane];
   }
-  if (pre2) {
+  if constexpr (pre2) {
 #pragma unroll
     for (int u = 0; u < OPW; ++u) w2[u] = (j1 + u < Dd && lane < Z) ? Wh[(int64_t)(j1 + u) * Z + lane] : 0.f;
     if (lane < OPW && j1 + lane < Dd) {
@@ -96,7 +157,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
   __syncthreads();
   // one wave per output, lanes across the contraction (coalesced weight rows); OPW outputs at a time so that their
   // weight loads are all in flight together (one output at a time was eight dependent L2 round trips per wave)
-  if (pre1) {
+  if constexpr (pre1) {
     float acc[OPW];
 #pragma unroll
     for (int u = 0; u < OPW; ++u) {
@@ -111,7 +172,8 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
       if (lane == u && j1 + u < 2 * Z) lat[j1 + u] = v + b1;
     }
   } else {
-    wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
+    if (De <= 64 * PRE_C) wave_dots_pre<OPW, PRE_C>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
+    else wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
   }
   __syncthreads();
   float klacc = 0.f;
@@ -133,7 +195,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
     for (int w = 0; w < NW; ++w) t += klred[w];
     kl[b] = t;
   }
-  if (pre2) {
+  if constexpr (pre2) {
     const float zv = lane < Z ? zs[lane] : 0.f;
 #pragma unroll
     for (int u = 0; u < OPW; ++u) {
@@ -141,18 +203,60 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, 
       if (lane == u && j1 + u < Dd) dec_in[b * dec_stride + j1 + u] = from_f32<T>(alpha_d * (v + bh2 + cls2) + pos2);
     }
   } else {
-    wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, [&](int j, float acc) {
+    auto emit2 = [&](int j, float acc) {
       const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
       dec_in[b * dec_stride + j] = from_f32<T>(v);
-    });
+    };
+    if (Z <= 64 * PRE_C) wave_dots_pre<OPW, PRE_C>(zs, Z, Wh, Dd, wave, NW, lane, emit2);
+    else wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, emit2);
   }
+}
+
+// sum over j = j0, j0 + step, ... < n of v[j] * W[j, col] (v in LDS), UNR weight loads in flight at a time and the next batch
+// requested before the current one is consumed; the FMA order of the plain loop. (One load per FMA made the generic path a
+// chain of dependent cold round trips: latent_bwd_vec 56 us at configs[2], 128 rows per thread.)
+template <int UNR>
+__device__ __forceinline__ float strided_col_dot(const float* v, const float* __restrict__ W, int64_t ldw, int col, int j0, int step, int n) {
+  float acc = 0.f;
+  if (j0 >= n) return acc;
+  const int cnt = (n - j0 + step - 1) / step;  // terms of this thread
+  const float* wp = W + (int64_t)j0 * ldw + col;
+  const int64_t wstep = (int64_t)step * ldw;
+  auto load = [&](float (&w)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) w[u] = wp[(int64_t)(t0 + u < cnt ? t0 + u : cnt - 1) * wstep];
+  };
+  auto fold = [&](const float (&w)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (t0 + u < cnt) acc = fmaf(v[j0 + (t0 + u) * step], w[u], acc);
+  };
+  float wa[UNR], wb[UNR];
+  load(wa, 0);
+  for (int t0 = 0;;) {
+    load(wb, t0 + UNR < cnt ? t0 + UNR : t0);
+    fold(wa, t0);
+    t0 += UNR;
+    if (t0 >= cnt) break;
+    load(wa, t0 + UNR < cnt ? t0 + UNR : t0);
+    fold(wb, t0);
+    t0 += UNR;
+    if (t0 >= cnt) break;
+  }
+  return acc;
 }
 
 // per-sample backward vectors: t = alpha_d * g0, dz, dlat = [dmu | dsigma], dh0.
 // Columns of the weight matrices are contracted (consecutive threads read consecutive columns, coalesced); each
 // output is split over NP row parts that are combined through LDS, so a thread's dependent FMA chain is
 // rows / NP long instead of rows.
-template <typename T>
+constexpr int LAT_PRE_H = 8, LAT_PRE_L = 32;
+__host__ __device__ inline bool latent_bwd_pre_shape(int64_t De, int64_t Z, int64_t Dd) {
+  if (Z > LAT_THREADS || De > LAT_THREADS) return false;
+  const int64_t np_h = LAT_THREADS / Z, np_l = LAT_THREADS / De;
+  return (Dd + np_h - 1) / np_h <= LAT_PRE_H && (2 * Z + np_l - 1) / np_l <= LAT_PRE_L;
+}
+template <typename T, bool PRE>
 __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int Z, int Dd, const float* __restrict__ Wl,
                                                                      const float* __restrict__ eps,
                                                                      const float* __restrict__ Wh,
@@ -173,12 +277,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   // Fast path (one round per product, few rows per thread): the weight elements a thread will contract, and mu / sigma
   // / eps, are loaded before the first barrier — their addresses depend on nothing computed here, and in the step they
   // are cold lines (three dependent round trips otherwise).
-  constexpr int PRE_H = 8, PRE_L = 32;
+  constexpr int PRE_H = LAT_PRE_H, PRE_L = LAT_PRE_L;
   const int zc = Z < LAT_THREADS ? Z : LAT_THREADS, np_h = LAT_THREADS / zc > 0 ? LAT_THREADS / zc : 1;
   const int dc = De < LAT_THREADS ? De : LAT_THREADS, np_l = LAT_THREADS / dc > 0 ? LAT_THREADS / dc : 1;
-  const bool pre = Z <= LAT_THREADS && De <= LAT_THREADS && (Dd + np_h - 1) / np_h <= PRE_H && (2 * Z + np_l - 1) / np_l <= PRE_L;
+  constexpr bool pre = PRE;  // host: latent_bwd_pre_shape
   float wh[PRE_H], wl[PRE_L], m_r = 0.f, s_r = 0.f, e_r = 0.f;
-  if (pre) {
+  if constexpr (pre) {
     const int i = tid % zc, pt = tid / zc;
 #pragma unroll
     for (int k = 0; k < PRE_H; ++k) {
@@ -206,12 +310,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
     for (int i0 = 0; i0 < Z; i0 += LAT_THREADS) {             // one round unless Z > 1024
       const int i = i0 + tid % zc, pt = tid / zc;
       float acc = 0.f;
-      if (pre) {
+      if constexpr (pre) {
 #pragma unroll
         for (int k = 0; k < PRE_H; ++k)
           if (pt + k * np < Dd) acc = fmaf(t[pt + k * np], wh[k], acc);
       } else if (i < Z && pt < np) {
-        for (int j = pt; j < Dd; j += np) acc = fmaf(t[j], Wh[(int64_t)j * Z + i], acc);
+        acc = strided_col_dot<16>(t, Wh, Z, i, pt, np, Dd);
       }
       part[tid] = acc;
       __syncthreads();
@@ -238,12 +342,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
     for (int d0 = 0; d0 < De; d0 += LAT_THREADS) {
       const int d = d0 + tid % dc, pt = tid / dc;
       float acc = 0.f;
-      if (pre) {
+      if constexpr (pre) {
 #pragma unroll
         for (int k = 0; k < PRE_L; ++k)
           if (pt + k * np < 2 * Z) acc = fmaf(dl[pt + k * np], wl[k], acc);
       } else if (d < De && pt < np) {
-        for (int j = pt; j < 2 * Z; j += np) acc = fmaf(dl[j], Wl[(int64_t)j * De + d], acc);
+        acc = strided_col_dot<16>(dl, Wl, De, d, pt, np, 2 * Z);
       }
       part[tid] = acc;
       __syncthreads();
@@ -300,9 +404,14 @@ extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   MST_CHECK_ARG(lds <= 60000, "mst_latent_fwd: De + 3Z too large for one workgroup");
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((latent_fwd_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
-                       (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
-                       alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
+    if (latent_fwd_pre_shape(De, Z, Dd))
+      hipLaunchKernelGGL((latent_fwd_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
+                         (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
+                         alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
+    else
+      hipLaunchKernelGGL((latent_fwd_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
+                         (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
+                         alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
     MST_CHECK_LAUNCH("latent_fwd_kernel");
     return MST_OK;
   });
@@ -328,9 +437,14 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   const int n_wl = (int)cdiv(2 * Z * De, 64), n_wh = (int)cdiv(Dd * Z, 64), n_cls = (int)cdiv(B * Dd, 256);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
-                       eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
-                       dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+    if (latent_bwd_pre_shape(De, Z, Dd))
+      hipLaunchKernelGGL((latent_bwd_vec_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
+                         eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
+                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+    else
+      hipLaunchKernelGGL((latent_bwd_vec_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
+                         eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
+                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     hipLaunchKernelGGL((latent_param_grads_kernel<T>), dim3((unsigned)(n_wl + n_wh + n_cls)), dim3(256), 0, s, B, (int)De, (int)Z,
                        (int)Dd, dlat, (const T*)enc_out, enc_sample_stride, tvec, z, classes, dWl, dbl, dWh, dbh, dcls_d, ld_cls,
@@ -351,9 +465,14 @@ extern "C" int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, i
   const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    hipLaunchKernelGGL((latent_bwd_vec_kernel<T>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
-                       (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
-                       scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
+    if (latent_bwd_pre_shape(De, Z, Dd))
+      hipLaunchKernelGGL((latent_bwd_vec_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
+                         (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
+                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
+    else
+      hipLaunchKernelGGL((latent_bwd_vec_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
+                         (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
+                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     return MST_OK;
   });

@@ -11,8 +11,10 @@
 // All are HBM-bound: one read of logits (+labels), optional writes of probabilities and of the
 // logit gradient in the same pass, per-sample sums reduced in-wave then with one atomic per wave.
 #include <math.h>
+#include <type_traits>
 #include "common.hpp"
 #include "loss_combine.hpp"
+#include "bce_math.hpp"
 
 namespace mst {
 
@@ -146,67 +148,80 @@ __global__ __launch_bounds__(BCE_THREADS) void sigmoid_bce_kernel(int64_t rows_p
     const float nn = (float)rows_per_sample * (float)P - np;
     w = np / (nn + 1e-12f);
   }
-  // a thread handles 4 consecutive pitches of one frame per iteration
-  const int vec_per_row = (P + 3) / 4;
-  const int64_t nvec = rows_per_sample * vec_per_row;
+  // a thread handles VEC consecutive pitches of one frame per iteration: 8 (16-byte logit / probability / gradient accesses, one
+  // 8-byte label load) where the rows allow, else 4
+  const float s1 = (1.f - ls) + 0.5f * ls, s0 = 0.5f * ls;
   float acc = 0.f;
-#pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * BCE_THREADS + tid; i < nvec; i += (int64_t)gridDim.x * BCE_THREADS) {
-    // (32-bit quotient / remainder: nvec < 2^31 is checked on the host; the 64-bit forms were ~200 instructions per thread
-    // in a kernel whose threads handle one vector each)
-    const uint32_t iq = (uint32_t)i / (uint32_t)vec_per_row;
-    const int64_t r = b * rows_per_sample + iq;
-    const int c0 = (int)((uint32_t)i - iq * (uint32_t)vec_per_row) * 4;
-    float x[4];
-    {
-      u32x2 raw = *reinterpret_cast<const u32x2*>(logits + r * ld + c0);
-      x[0] = bits_to_f32<T>((uint16_t)(raw[0] & 0xffff)); x[1] = bits_to_f32<T>((uint16_t)(raw[0] >> 16));
-      x[2] = bits_to_f32<T>((uint16_t)(raw[1] & 0xffff)); x[3] = bits_to_f32<T>((uint16_t)(raw[1] >> 16));
-    }
-    uint32_t lab4 = 0;  // four label bytes in one load when the row is 4-byte aligned
-    if (P % 4 == 0) {
-      lab4 = *reinterpret_cast<const uint32_t*>(labels + r * P + c0);
-    } else {
+  auto sweep = [&](auto dwc, auto vecc) {
+    constexpr bool DW = decltype(dwc)::value;
+    constexpr int VEC = decltype(vecc)::value;
+    const int vec_per_row = (P + VEC - 1) / VEC;
+    const int64_t nvec = rows_per_sample * vec_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * BCE_THREADS + tid; i < nvec; i += (int64_t)gridDim.x * BCE_THREADS) {
+      // (32-bit quotient / remainder: nvec < 2^31 is checked on the host; the 64-bit forms were ~200 instructions per thread
+      // in a kernel whose threads handle one vector each)
+      const uint32_t iq = (uint32_t)i / (uint32_t)vec_per_row;
+      const int64_t r = b * rows_per_sample + iq;
+      const int c0 = (int)((uint32_t)i - iq * (uint32_t)vec_per_row) * VEC;
+      float x[VEC];
+      uint64_t lab = 0;  // the label bytes in one load when the row is aligned
+      if constexpr (VEC == 8) {
+        Pack8 raw;
+        raw.u = *reinterpret_cast<const u32x4*>(logits + r * ld + c0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c0 + e < P) lab4 |= (uint32_t)labels[r * P + c0 + e] << (8 * e);
-    }
-    float pv[4], gv[4];
+        for (int e = 0; e < 8; ++e) x[e] = bits_to_f32<T>(raw.h[e]);
+        lab = *reinterpret_cast<const uint64_t*>(labels + r * P + c0);
+      } else {
+        u32x2 raw = *reinterpret_cast<const u32x2*>(logits + r * ld + c0);
+        x[0] = bits_to_f32<T>((uint16_t)(raw[0] & 0xffff)); x[1] = bits_to_f32<T>((uint16_t)(raw[0] >> 16));
+        x[2] = bits_to_f32<T>((uint16_t)(raw[1] & 0xffff)); x[3] = bits_to_f32<T>((uint16_t)(raw[1] >> 16));
+        if (P % 4 == 0) {
+          lab = *reinterpret_cast<const uint32_t*>(labels + r * P + c0);
+        } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = c0 + e;
-      pv[e] = 0.f; gv[e] = 0.f;
-      if (c < P) {
-        const float y = (float)((lab4 >> (8 * e)) & 0xFFu);
-        const float p = __frcp_rn(1.f + __expf(-x[e]));  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
-        const float omp = 1.f - p;
-        const float s = (1.f - ls) * y + 0.5f * ls;
-        const float lp = __logf(1e-12f + p), lq = __logf(1e-12f + omp);
-        float bce = -(s * lp + (1.f - s) * lq);
-        // d bce / d logit = d bce/dp * p(1-p)
-        float dbce = -(s * __frcp_rn(1e-12f + p) - (1.f - s) * __frcp_rn(1e-12f + omp)) * p * omp;
-        if (downweight && y == 0.f) {  // loss.py:52-54: (w*bce)*bce where label == 0
-          dbce = 2.f * w * bce * dbce;
-          bce = w * bce * bce;
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < P) lab |= (uint64_t)labels[r * P + c0 + e] << (8 * e);
         }
-        acc += bce;
-        pv[e] = p;
-        gv[e] = dbce * inv_n * gscale;
+      }
+      bool in_dom = true;  // (pad columns hold zero logits)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) in_dom = in_dom && ((VEC != 8 && c0 + e >= P) || bce_fast_domain(x[e]));
+      const bool fast = __all(in_dom);  // wave-uniform: three transcendental instructions per element instead of six (bce_math.hpp)
+      Pack8 pv, gv;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int c = c0 + e;
+        pv.h[e] = 0; gv.h[e] = 0;
+        if (VEC == 8 || c < P) {  // (VEC 8: P is a multiple of 8, no partial vector)
+          const float y = (float)((lab >> (8 * e)) & 0xFFull);
+          float p, bce, dbce;
+          bce_fast<DW>(x[e], y, s1, s0, w, p, bce, dbce);
+          if (!fast) {  // a saturated logit somewhere in this wave: ITS element takes the reference's operation order (an element's
+                        // result depends on its own logit only, so the fused and the two-launch forms agree bit for bit)
+            float p2, b2, d2;
+            bce_exact<DW>(x[e], y, ls, w, p2, b2, d2);
+            if (!bce_fast_domain(x[e])) { p = p2; bce = b2; dbce = d2; }
+          }
+          acc += bce;
+          pv.h[e] = f32_to_bits<T>(p);
+          gv.h[e] = f32_to_bits<T>(dbce * inv_n * gscale);
+        }
+      }
+      if constexpr (VEC == 8) {
+        if (probs) *reinterpret_cast<u32x4*>(probs + r * ldp + c0) = pv.u;
+        if (dlogits) *reinterpret_cast<u32x4*>(dlogits + r * ldd + c0) = gv.u;
+      } else {
+        if (probs) *reinterpret_cast<u32x2*>(probs + r * ldp + c0) = u32x2{pv.u[0], pv.u[1]};
+        if (dlogits) *reinterpret_cast<u32x2*>(dlogits + r * ldd + c0) = u32x2{gv.u[0], gv.u[1]};
       }
     }
-    if (probs) {
-      u32x2 o;
-      o[0] = (uint32_t)f32_to_bits<T>(pv[0]) | ((uint32_t)f32_to_bits<T>(pv[1]) << 16);
-      o[1] = (uint32_t)f32_to_bits<T>(pv[2]) | ((uint32_t)f32_to_bits<T>(pv[3]) << 16);
-      *reinterpret_cast<u32x2*>(probs + r * ldp + c0) = o;
-    }
-    if (dlogits) {
-      u32x2 o;
-      o[0] = (uint32_t)f32_to_bits<T>(gv[0]) | ((uint32_t)f32_to_bits<T>(gv[1]) << 16);
-      o[1] = (uint32_t)f32_to_bits<T>(gv[2]) | ((uint32_t)f32_to_bits<T>(gv[3]) << 16);
-      *reinterpret_cast<u32x2*>(dlogits + r * ldd + c0) = o;
-    }
-  }
+  };
+  const bool wide = P % 8 == 0 && ld % 8 == 0 && (!probs || ldp % 8 == 0) && (!dlogits || ldd % 8 == 0) &&
+                    (((uintptr_t)logits | (uintptr_t)probs | (uintptr_t)dlogits) & 15) == 0 && ((uintptr_t)labels & 7) == 0;
+  typedef std::integral_constant<int, 8> V8;
+  typedef std::integral_constant<int, 4> V4;
+  if (downweight) { if (wide) sweep(std::true_type(), V8()); else sweep(std::true_type(), V4()); }
+  else { if (wide) sweep(std::false_type(), V8()); else sweep(std::false_type(), V4()); }
   const float total = block_sum_1024(acc, red);
   if (tid == 0) atomicAdd(loss + b, total * inv_n);
 }

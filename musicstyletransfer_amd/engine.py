@@ -546,7 +546,9 @@ class StepPlan:
         self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
         self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
         # output layer + BCE in one launch when a tile can hold whole rows of pitches of one sample (configs[1]: P 128, T 256)
-        self.fuse_bce = cfg.kind == "pianoroll" and o.can_fuse_bce(cfg.out_dim, T)
+        fb = os.environ.get("MST_FUSE_BCE", "1")  # "0": never, "all": wherever the launch exists (A/B runs), default: where it pays
+        self.fuse_bce = (cfg.kind == "pianoroll" and o.can_fuse_bce(cfg.out_dim, T, negative_label_downscaling) and fb != "0" and
+                         (fb == "all" or o.bce_fusion_pays(cfg.out_dim)))
         # the attention output projection inside the feed-forward launches: "head" = W_proj + LayerNorm-1 in front of the
         # forward block (two launches less per layer at equal time), "all" = also its dgrad behind the backward block
         # (measured slower: +14 us on a launch that is already one latency-bound workgroup per CU), "0" = neither

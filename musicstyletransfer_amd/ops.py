@@ -142,9 +142,19 @@ def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wp
     call("mst_row_tail_bwd", C.byref(q), stream())
 
 
-def can_fuse_bce(P, T):
-    """shapes the output-layer GEMM + BCE launch exists for (mst_gemm_sigmoid_bce)"""
-    return P in (128, 256) and T % 64 == 0
+def can_fuse_bce(P, T, downweight=False):
+    """shapes the output-layer GEMM + BCE launch exists for (mst_gemm_sigmoid_bce): a row of 128 pitches, or of any multiple of
+    256 (column tiles; the label down-weighting, which counts a sample's positives in every workgroup, only on rows of one tile)"""
+    return (P == 128 or (P % 256 == 0 and (P == 256 or not downweight))) and T % 64 == 0
+
+
+def bce_fusion_pays(P):
+    """Where the engine routes the output layer through the fused launch. Measured at configs[2] (2048 pitches, B 64, T 256): the
+    fused launch 110 us against mst_gemm_nt 37 us + mst_sigmoid_bce 59 us — eight column tiles per row block, each a
+    one-workgroup-per-CU launch slot whose epilogue is the loss arithmetic with the matrix pipe idle, lose more than the 134 MB of
+    logits written and read back cost; at one tile per row (128 / 256 pitches) the fused launch also carries the backward pass's
+    first GEMM (configs[1]: 24 us for all three)."""
+    return P <= 256
 
 
 def _gemm_bce_args(A, B, labels, loss, T, dlogits=None, probs=None, logits=None, label_smoothing=0.0, downweight=False, gscale=1.0, **kw):

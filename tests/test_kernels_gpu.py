@@ -1276,13 +1276,16 @@ def test_softmax_ce_uniform_known_answer(gpu):
     close(loss, want, 1e-6, 1e-6, "uniform CE = log V * n_valid / T")
 
 
-@pytest.mark.parametrize("B,T,P,ls,dw", [(4, 16, 128, 0.0, False), (4, 16, 128, 0.1, True), (3, 7, 30, 0.0, True),
-                                         (64, 256, 128, 0.0, False)])
-def test_sigmoid_bce(gpu, B, T, P, ls, dw):
+@pytest.mark.parametrize("B,T,P,ls,dw,scale", [(4, 16, 128, 0.0, False, 2.0), (4, 16, 128, 0.1, True, 2.0), (3, 7, 30, 0.0, True, 2.0),
+                                               (64, 256, 128, 0.0, False, 2.0),
+                                               # saturated logits (beyond [-16, 9]): waves that hold one take the reference's own
+                                               # operation order, 1e-12 epsilons and fl(1 - p) included (bce_math.hpp)
+                                               (4, 16, 128, 0.1, False, 8.0), (3, 7, 30, 0.0, True, 8.0)])
+def test_sigmoid_bce(gpu, B, T, P, ls, dw, scale):
     o = ops()
     ldp = o.roundup(P, 8)
     logits = torch.zeros(B * T, ldp, dtype=BF, device=gpu)
-    logits[:, :P] = rnd((B * T, P), gpu, seed=80, scale=2.0)
+    logits[:, :P] = rnd((B * T, P), gpu, seed=80, scale=scale)
     g = torch.Generator().manual_seed(81)
     labels = (torch.rand(B * T, P, generator=g) < 0.1).to(torch.uint8).to(gpu)
     loss = torch.zeros(B, device=gpu)
@@ -1313,7 +1316,9 @@ def test_sigmoid_bce(gpu, B, T, P, ls, dw):
 
 
 @pytest.mark.parametrize("B,T,P,D,ls,dw,dtype", [(4, 128, 128, 128, 0.0, False, BF), (3, 64, 256, 64, 0.1, True, torch.float16),
-                                                 (64, 256, 128, 128, 0.0, False, BF)])
+                                                 (64, 256, 128, 128, 0.0, False, BF),
+                                                 # rows of several 256-pitch column tiles (configs[2]: 2048 pitches)
+                                                 (3, 64, 512, 128, 0.1, False, BF), (2, 128, 2048, 128, 0.0, False, torch.float16)])
 def test_gemm_sigmoid_bce_equals_gemm_then_bce(gpu, B, T, P, D, ls, dw, dtype):
     """mst_gemm_sigmoid_bce (output layer + sigmoid + BCE in one launch, logits never stored) against mst_gemm_nt followed
     by mst_sigmoid_bce on the same operands, with the decoder's row remap (rows 1..T of T+1): bit-identical logit gradient
