@@ -115,12 +115,12 @@ __device__ __forceinline__ void key_load(KeyRegs& kr, const uint8_t* __restrict_
 // the K / V rows that the tiles of a head share, and the other half of each 128-byte line (the neighbouring head),
 // are then re-read from that XCD's L2 instead of crossing the fabric again.
 __device__ __forceinline__ void attn_wg_coords(int64_t B, int64_t H, int& tile, int64_t& bh) {
-  const int64_t gx = gridDim.x;
+  const uint32_t gx = gridDim.x;  // (32-bit quotients: grid.x * grid.y < 2^31 workgroups)
   if (B % 8 == 0) {
-    const int64_t lin = blockIdx.x + gx * blockIdx.y, xcd = lin % 8, j = lin / 8, G = H * gx;
-    const int64_t b = xcd + 8 * (j / G), r = j % G;
-    bh = b * H + r / gx;
-    tile = (int)(r % gx);
+    const uint32_t lin = blockIdx.x + gx * blockIdx.y, xcd = lin % 8u, j = lin / 8u, G = (uint32_t)H * gx;
+    const uint32_t jq = j / G, r = j - jq * G, rq = r / gx;
+    bh = (int64_t)(xcd + 8u * jq) * H + rq;
+    tile = (int)(r - rq * gx);
   } else {
     tile = blockIdx.x;
     bh = blockIdx.y;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stats_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tile; int64_t bh;
   attn_wg_coords(a.B, a.H, tile, bh);
-  const int64_t b = bh / a.H, hd = bh % a.H;
+  const int64_t b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (B * H <= 65535: a 32-bit division, not the ~200-instruction 64-bit one, at the head of the kernel)
   const int64_t S = a.S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tile; int64_t bh;
   attn_wg_coords(a.B, a.H, tile, bh);
-  const int64_t b = bh / a.H, hd = bh % a.H;
+  const int64_t b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (B * H <= 65535: a 32-bit division, not the ~200-instruction 64-bit one, at the head of the kernel)
   const int64_t S = a.S;
   const int64_t plane = a.B * a.H * S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tile; int64_t bh;
   attn_wg_coords(a.B, a.H, tile, bh);
-  const int64_t b = bh / a.H, hd = bh % a.H;
+  const int64_t b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (B * H <= 65535: a 32-bit division, not the ~200-instruction 64-bit one, at the head of the kernel)
   const int64_t S = a.S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
   const T* Kg = base + a.k_off;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tile; int64_t bh;
   attn_wg_coords(a.B, a.H, tile, bh);
-  const int64_t b = bh / a.H, hd = bh % a.H;
+  const int64_t b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (B * H <= 65535: a 32-bit division, not the ~200-instruction 64-bit one, at the head of the kernel)
   const int64_t S = a.S;
   const int64_t plane = a.B * a.H * S;
   const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP;
   float* sRed = sLogl + SP;  // [LONE_RED]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
-  const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
+  const int64_t bh = res_wg_bh(a.B, a.H), b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (32-bit division: B * H <= 65535)
   const int64_t plane = a.B * a.H * S;
   const bool lone = lone_row_shape(S, DH) && a.q_limit >= S;  // the last row is handled apart (above)
   const int NBo = lone ? NB - 1 : NB;                            // owner blocks swept with MFMA tiles
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sNd = sLogl + SP;
   float* sRed = sNd + SP;  // [LONE_RED]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
-  const int64_t bh = res_wg_bh(a.B, a.H), b = bh / a.H, hd = bh % a.H;
+  const int64_t bh = res_wg_bh(a.B, a.H), b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;  // (32-bit division: B * H <= 65535)
   const int64_t plane = a.B * a.H * S;
   const bool lone = !SPARSE && lone_row_shape(S, DH);  // the last row is handled apart (see lone_row_shape)
   const int NBo = lone ? NB - 1 : NB;                    // owner blocks swept with MFMA tiles

@@ -415,12 +415,17 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   const TA* a_ptr[A_CH];
   bool a_ok[A_CH];
   int a_lds[A_CH], a_ch[A_CH];
+  // (a tile that cannot straddle a remap group — groups a multiple of the tile height, as in every remapped launch of the step —
+  // takes ONE 64-bit division for its first row instead of one per staged chunk)
+  const bool a_tile_remap = AREMAP && a.a_rows_per_group > 0 && a.a_rows_per_group % BM == 0;
+  const int64_t a_pm0 = a_tile_remap ? remap_row(m0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : 0;
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
     int64_t m = m0 + row;
     a_ok[i] = m < a.M && c < BM * CHUNKS;
-    int64_t pm = AREMAP ? remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : (a_ok[i] ? m : 0);
+    int64_t pm = a_tile_remap ? (a_ok[i] ? a_pm0 + row : 0)
+                              : (AREMAP ? remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : (a_ok[i] ? m : 0));
     a_ptr[i] = A + pm * a.lda + ch * 8;
     a_ch[i] = ch * 8;
     a_lds[i] = row * CHUNKS + (ch ^ swz(row));
@@ -635,12 +640,17 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
   // in the step these lines are cold, and a row-by-row loop exposed one memory round trip per row at 8 waves per CU
   u32x4 rv[ITERS], xv[ITERS];
   float mean_r[ITERS], rstd_r[ITERS];
+  // the row remap once per tile where a tile cannot straddle a group (the step's remapped launch: rows 1..T of T + 1, T a multiple
+  // of the tile height): per row it is two 64-bit divisions, ~200 instructions each, in front of every row's loads
+  const bool tile_remap = a.c_rows_per_group <= 0 || a.c_rows_per_group % BM == 0;
+  const int64_t pm0 = remap_row(m0, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+  auto phys_row = [&](int64_t m) { return tile_remap ? pm0 + (m - m0) : remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset); };
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int64_t m = m0 + row0 + it * RSTEP;
     rv[it] = u32x4{0u, 0u, 0u, 0u}; xv[it] = rv[it]; mean_r[it] = 0.f; rstd_r[it] = 0.f;
     if (m < a.M) {
-      const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+      const int64_t pm = phys_row(m);
       if (lds_resid) rv[it] = *reinterpret_cast<const u32x4*>(lds_resid + (row0 + it * RSTEP) * lds_resid_ld + nc);
       else if (resid) rv[it] = *reinterpret_cast<const u32x4*>(resid + m * a.ldr + nc);
       if (MODE == 2) {
@@ -656,7 +666,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
     const int row = row0 + it * RSTEP;
     const int64_t m = m0 + row;
     if (m < a.M) {  // uniform for the lanes of a row
-      const int64_t pm = remap_row(m, a.c_rows_per_group, a.c_group_stride, a.c_group_offset);
+      const int64_t pm = phys_row(m);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
       float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

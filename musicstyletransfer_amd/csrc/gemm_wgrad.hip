@@ -82,14 +82,18 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WGK, wk = wave % WGK;
   const mst_wgrad_args& a = b.p[pi];
-  const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
-  const int64_t in_p = item - b.item_prefix[pi];
-  const int64_t local = in_p % tiles_p;
-  const int split_id = (int)(in_p / tiles_p), split_here = b.split_p[pi];
-  const int64_t tiles_k = (a.K + BKO - 1) / BKO;
-  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * BKO;
+  // (32-bit quotients throughout: items, tiles, M and K are below 2^31 — checked on the host — and a 64-bit division is ~200
+  // instructions; ten of them stood between a workgroup's start and its first load)
+  const uint32_t tiles_p = (uint32_t)(b.tile_prefix[pi + 1] - b.tile_prefix[pi]);
+  const uint32_t in_p = (uint32_t)(item - b.item_prefix[pi]);
+  const uint32_t split_u = in_p / tiles_p;
+  const int64_t local = in_p - split_u * tiles_p;
+  const int split_id = (int)split_u, split_here = b.split_p[pi];
+  const uint32_t tiles_k = ((uint32_t)a.K + BKO - 1) / BKO;
+  const uint32_t tile_n = (uint32_t)local / tiles_k;
+  const int64_t n0 = (int64_t)tile_n * BN, k0 = (int64_t)((uint32_t)local - tile_n * tiles_k) * BKO;
 
-  const int64_t m_chunk = ((a.M + split_here - 1) / split_here + BMR - 1) / BMR * BMR;
+  const int64_t m_chunk = (int64_t)((((uint32_t)a.M + (uint32_t)split_here - 1) / (uint32_t)split_here + BMR - 1) / BMR * BMR);
   const int64_t m_begin = (int64_t)split_id * m_chunk;
   const int64_t m_end = (m_begin + m_chunk < a.M) ? m_begin + m_chunk : a.M;
   if (m_begin >= m_end) return;  // uniform for the whole workgroup
@@ -121,9 +125,17 @@ __device__ __forceinline__ void wgrad_body(const WgradBatch& b, unsigned char* s
   // 64-bit divisions per chunk and stage made the two remapped problems' workgroups finish at 95 us when the median
   // workgroup of the whole-step launch finished at 70.) Groups shorter than a stage keep the division.
   const bool div_a = remap_a && a.a_rows_per_group < BMR, div_b = remap_b && a.b_rows_per_group < BMR;
-  int64_t pa0 = remap_a ? remap_row(m_begin + a_r0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : 0;
-  int64_t pb0 = remap_b ? remap_row(m_begin + b_r0, a.b_rows_per_group, a.b_group_stride, a.b_group_offset) : 0;
-  int64_t oa0 = remap_a ? (m_begin + a_r0) % a.a_rows_per_group : 0, ob0 = remap_b ? (m_begin + b_r0) % a.b_rows_per_group : 0;
+  int64_t pa0 = 0, pb0 = 0, oa0 = 0, ob0 = 0;
+  if (remap_a) {
+    const uint32_t m = (uint32_t)(m_begin + a_r0), g = m / (uint32_t)a.a_rows_per_group;
+    oa0 = m - g * (uint32_t)a.a_rows_per_group;
+    pa0 = (int64_t)g * a.a_group_stride + a.a_group_offset + oa0;  // remap_row
+  }
+  if (remap_b) {
+    const uint32_t m = (uint32_t)(m_begin + b_r0), g = m / (uint32_t)a.b_rows_per_group;
+    ob0 = m - g * (uint32_t)a.b_rows_per_group;
+    pb0 = (int64_t)g * a.b_group_stride + a.b_group_offset + ob0;
+  }
 
   auto load_tile = [&](int64_t mb) {
     const bool full = mb + BMR <= m_end;  // uniform: only the last stage of a slab can be partial
@@ -431,8 +443,8 @@ __global__ __launch_bounds__(WGN * WGK * 64) void wgrad_kernel(WgradBatch b) {
   // one XCD's L2, and the operands cross the fabric about once (117 MB for the encoder layer's four problems)
   // instead of once per XCD that owns a tile needing them (312 MB with the tile-major order).
   const int64_t n_items = b.item_prefix[b.n];
-  const int64_t per_xcd = (n_items + 7) / 8;
-  const int64_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int64_t per_xcd = (n_items + 7) >> 3;
+  const int64_t item = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   if (item >= n_items) return;
 #ifdef MST_WGRAD_STAMPS
   if (threadIdx.x == 0 && item < 512) g_wgrad_wg[2 * item] = __builtin_amdgcn_s_memrealtime();
@@ -478,17 +490,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradBatch b, Partial
   const mst_wgrad_args& a = b.p[pi];
   const int64_t local = tile_lin - b.tile_prefix[pi];
   const int64_t tiles_p = b.tile_prefix[pi + 1] - b.tile_prefix[pi];
-  const int bk = ((b.narrow >> pi) & 1u) ? 128 : BKO;  // this problem's tile width in k (rows of the slot are bk floats long)
-  const int64_t tiles_k = (a.K + bk - 1) / bk;
-  const int64_t n0 = (local / tiles_k) * BN, k0 = (local % tiles_k) * bk;
+  const bool nar = (b.narrow >> pi) & 1u;
+  const int bk = nar ? 128 : BKO;  // this problem's tile width in k (rows of the slot are bk floats long)
+  // (shifts and 32-bit quotients: this kernel's threads do eleven loads each, and the 64-bit divisions of the tile decode were
+  // most of its instructions)
+  const int bk_log = nar ? 7 : (BKO == 256 ? 8 : BKO == 128 ? 7 : 6);
+  static_assert(BKO == 256 || BKO == 128 || BKO == 64, "tile width in k must be a power of two");
+  const uint32_t tiles_k = ((uint32_t)a.K + bk - 1) >> bk_log;
+  const uint32_t tile_n = (uint32_t)local / tiles_k;
+  const int64_t n0 = (int64_t)tile_n * BN, k0 = (int64_t)((uint32_t)local - tile_n * tiles_k) << bk_log;
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // element of the tile
   if (e >= BN * bk) return;
-  const int nl = e / bk, kl = e % bk;
+  const int nl = e >> bk_log, kl = e & (bk - 1);
   const int64_t n = n0 + nl, k = k0 + kl;
   if (n >= a.N || k >= a.K) return;
   // slabs that own rows of this problem (wgrad_kernel returns early, writing nothing, for the others)
   const int sp = b.split_p[pi];
-  const int64_t m_chunk = ((a.M + sp - 1) / sp + BMR - 1) / BMR * BMR;
+  const int64_t m_chunk = (int64_t)((((uint32_t)a.M + (uint32_t)sp - 1) / (uint32_t)sp + BMR - 1) / BMR * BMR);
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < sp && (int64_t)s * m_chunk < a.M; ++s)
     sum += *reinterpret_cast<const f32x4*>(b.partial + (b.item_prefix[pi] + (int64_t)s * tiles_p + local) * (BN * BKO) + e);
@@ -559,6 +577,8 @@ static int launch_wgrad(const WgradBatch& b, int big, const PartialSumBatch* ps,
 
 static int check_wgrad(const mst_wgrad_args& a) {
   MST_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "mst_gemm_wgrad: M,N,K must be positive");
+  MST_CHECK_ARG(a.M < (1ll << 30) && a.N < (1ll << 30) && a.K < (1ll << 30) && a.a_rows_per_group < (1ll << 30) && a.b_rows_per_group < (1ll << 30),
+                "mst_gemm_wgrad: M, N, K and the remap group sizes must stay below 2^30 (the kernels' tile decode is 32-bit)");
   // N and K may be ragged as long as the 16-byte chunk that straddles the edge stays inside the row
   // (callers keep pad columns zero); outputs beyond N / K are never written.
   MST_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= roundup(a.N, 8) && a.ldb >= roundup(a.K, 8),
