@@ -410,6 +410,22 @@ int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    float* mu, float* sigma, float* z, float* kl,
                    void* dec_in, int64_t dec_sample_stride, mst_stream_t stream);
 
+/* mst_latent_fwd with the decoder's FIRST K | Q | V projection (transformer.py:88-93 applied to model.py:241-245's input) on the
+ * same launch: `proj` is that Dense as a GEMM over the B * T rows 1..T of every sample (a_remap = c_remap = (T, T + 1, 1),
+ * A = the decoder input, B = the [3 Dd, Dd] 16-bit weight shadow, bias, C = qkv) — rows the embedding GEMM produced at the start
+ * of the step, so their projection is independent of the latent block and runs as extra workgroups beside its B workgroups;
+ * row 0 of a sample (dec_in[b, 0, :], produced here) is projected by its own latent workgroup (fp32 dot products over the same
+ * 16-bit operands). mst_latent_fwd_qkv_ok: 1 for the shapes this form takes (T a multiple of 128, Dd 128 or 256); for the others run mst_latent_fwd and the projection as mst_gemm_nt. */
+int mst_latent_fwd_qkv_ok(int64_t B, int64_t T, int64_t De, int64_t Z, int64_t Dd);
+int mst_latent_fwd_qkv(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
+                       const void* enc_out, int64_t enc_sample_stride,
+                       const float* Wl, const float* bl, const float* eps,
+                       const float* Wh, const float* bh,
+                       const int32_t* classes, const float* cls_d, int64_t ld_cls,
+                       const float* pos_d, float alpha_d,
+                       float* mu, float* sigma, float* z, float* kl,
+                       void* dec_in, int64_t dec_sample_stride, const mst_gemm_args* proj, mst_stream_t stream);
+
 int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const void* enc_out, int64_t enc_sample_stride,
                    const float* Wl, const float* eps, const float* Wh,

@@ -207,6 +207,9 @@ SIGNATURES = {
                                     vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp, vp]),
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
+    "mst_latent_fwd_qkv_ok": (C.c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "mst_latent_fwd_qkv": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
+                                     vp, c_f32, vp, vp, vp, vp, vp, c_i64, C.POINTER(GemmArgs), vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
                                  vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),

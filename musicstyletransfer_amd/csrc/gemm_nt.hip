@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "bce_math.hpp"
+#include "latent_fwd.hpp"
 #include "step_begin.hpp"
 #include "shadows.hpp"
 
@@ -787,6 +788,35 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
   }
   gemm_mainloop<T, BM, BN, WGM, WGN, 64>(a, smem, acc, m0, n0);
   gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(a, l, smem, acc, m0, nullptr, 0, nullptr, 0, sPar);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mst_latent_fwd_qkv: the latent block's forward launch (B workgroups of dependent dot products — 8 us with 192 CUs idle) also
+// runs the decoder's FIRST K | Q | V projection (transformer.py:88-93 on model.py:241-245's input): rows 1..T of every sample are
+// the embedding GEMM's output, ready since the step's first launch, so their projection is independent of the latent block and
+// rides here as 128 x 128 tiles behind the B latent workgroups (16 waves each, the launch's block size); row 0 of a sample is
+// what the latent workgroup itself produces, and it projects that row too (LatentFwdArgs.Wq). As a launch of its own the
+// projection stood between latent_fwd and the decoder's attention in the dependent chain (12.4 us).
+template <typename T, bool PRE>
+// MEASURED, NOT THE DEFAULT (engine: MST_LATENT_QKV=1 selects it): 18.9 us for the launch against 6.9 + 11.6 us for the two — a
+// 16-wave workgroup is a poor GEMM tile at K = 128 (two stages: the tile is one dependent chain of load, load, epilogue, ~12 us, and a
+// CU holds one or two of them where it overlaps five or six 4-wave workgroups of the 64 x 64 kernel: the tiles alone take 16.9 us),
+// and at the 64 VGPRs that let two such workgroups share a CU the latent role spills 19 registers and takes 14.3 us alone.
+__global__ __launch_bounds__(LAT_THREADS) void latent_qkv_kernel(LatentFwdArgs la, mst_gemm_args g, int n_lat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < n_lat) {
+    latent_fwd_wg<T, PRE>(la, (int64_t)blockIdx.x, reinterpret_cast<float*>(smem));
+    return;
+  }
+  constexpr int BM = 128, BN = 128, WGM = 2, WGN = 8;  // (the fast epilogue walks NT / 16 = 64 rows per pass: a wave-row block is 64 rows)
+  static_assert(WGM * WGN * 64 == LAT_THREADS, "one block size per launch");
+  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+  int64_t m0, n0;
+  float bias_pre[8];
+  const int64_t tile = (int64_t)blockIdx.x - n_lat;
+  gemm_bias_preload<BM, BN>(g, bias_pre, tile);
+  gemm_mainloop<T, BM, BN, WGM, WGN, 64, true, false>(g, smem, acc, m0, n0, tile);
+  gemm_epilogue<T, BM, BN, WGM, WGN, false, true, 1, false>(g, smem, acc, m0, n0, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1888,6 +1918,65 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // (32-deep K stages for launches of 1281..2048 64 x 64 tiles — eight workgroups per CU, one resident round for the decoder's
     // 257 x 6 projection tiles — measured no faster: +2 us per step)
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
+  });
+}
+
+extern "C" int mst_latent_fwd_qkv_ok(int64_t B, int64_t T, int64_t De, int64_t Z, int64_t Dd) {
+  // shapes mst_latent_fwd_qkv takes: whole 128-row tiles inside a sample's rows 1..T, whole 128-column tiles of the 3 Dd outputs,
+  // 64-deep K stages, a decoder width the row-0 matvec is laid out for (128 or 256)
+  return B > 0 && T > 0 && T % 128 == 0 && (3 * Dd) % 128 == 0 && (Dd == 128 || Dd == 256) && De > 0 && Z > 0 &&
+         sizeof(float) * (size_t)(De + 3 * Z + Dd) <= 60000;
+}
+
+extern "C" int mst_latent_fwd_qkv(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out, int64_t enc_sample_stride,
+                                  const float* Wl, const float* bl, const float* eps, const float* Wh, const float* bh,
+                                  const int32_t* classes, const float* cls_d, int64_t ld_cls, const float* pos_d, float alpha_d, float* mu,
+                                  float* sigma, float* z, float* kl, void* dec_in, int64_t dec_sample_stride, const mst_gemm_args* proj,
+                                  mst_stream_t stream) {
+  MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_fwd_qkv: sizes must be positive");
+  MST_CHECK_ARG(enc_out && Wl && bl && eps && Wh && bh && classes && cls_d && pos_d && mu && sigma && z && kl && dec_in && proj,
+                "mst_latent_fwd_qkv: null pointer");
+  const mst_gemm_args& g = *proj;
+  int rc = check_gemm_common(g);
+  if (rc) return rc;
+  // the projection of rows 1..T: logical row m of B * T -> physical row (m / T) * (T + 1) + 1 + m % T on both sides
+  const int64_t T = g.c_rows_per_group;
+  MST_CHECK_ARG(T > 0 && g.a_rows_per_group == T && g.c_group_offset == 1 && g.a_group_offset == 1 && g.c_group_stride == T + 1 &&
+                    g.a_group_stride == T + 1 && g.M == B * T,
+                "mst_latent_fwd_qkv: proj must map the B * T rows 1..T of T + 1 on both sides (a_remap = c_remap = (T, T + 1, 1))");
+  MST_CHECK_ARG(g.dtype == dtype && g.N == 3 * Dd && g.K == Dd && mst_latent_fwd_qkv_ok(B, T, De, Z, Dd),
+                "mst_latent_fwd_qkv: shape not taken (mst_latent_fwd_qkv_ok): run mst_latent_fwd and the projection GEMM");
+  MST_CHECK_ARG(!g.c_f32 && !g.a_u8 && !g.resid && !g.gate && !g.rowadd && !g.grpadd && g.act == MST_ACT_NONE && g.dropout_p == 0.f &&
+                    !g.self_resid && g.alpha == 1.f && g.ldc % 8 == 0 && g.ldb >= Dd && (uint64_t)(B * (T + 1)) * (uint64_t)g.N < (1ull << 32),
+                "mst_latent_fwd_qkv: the projection takes a bias only");
+  MST_CHECK_ARG(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && ((uintptr_t)g.C % 16 == 0), "mst_latent_fwd_qkv: operands must be 16-byte aligned");
+  LatentFwdArgs la = {};
+  la.De = (int)De; la.Z = (int)Z; la.Dd = (int)Dd; la.enc_out = enc_out; la.enc_stride = enc_sample_stride;
+  la.Wl = Wl; la.bl = bl; la.eps = eps; la.Wh = Wh; la.bh = bh; la.classes = classes; la.cls_d = cls_d; la.ld_cls = ld_cls;
+  la.pos_d = pos_d; la.alpha_d = alpha_d; la.mu = mu; la.sigma = sigma; la.z = z; la.kl = kl; la.dec_in = dec_in;
+  la.dec_stride = dec_sample_stride;
+  la.Wq = g.B; la.ld_wq = g.ldb; la.bq = g.bias; la.qkv0 = g.C; la.qkv_stride = (T + 1) * g.ldc; la.nq = (int)g.N;
+  const size_t lds_lat = sizeof(float) * (size_t)(De + 3 * Z + Dd);
+  const size_t lds_gemm = (size_t)2 * (128 + 128) * 64 * 2, lds_epi = (size_t)128 * (128 + 4) * 4;
+  size_t lds = lds_lat;
+  if (lds_gemm > lds) lds = lds_gemm;
+  if (lds_epi > lds) lds = lds_epi;
+  const int64_t tiles = (g.M / 128) * (g.N / 128), n_lat = B;
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_act(dtype, [&](auto tag) -> int {
+    typedef decltype(tag) TT;
+    const bool pre = latent_fwd_pre_shape(De, Z, Dd);
+    const void* fn = pre ? reinterpret_cast<const void*>(&latent_qkv_kernel<TT, true>) : reinterpret_cast<const void*>(&latent_qkv_kernel<TT, false>);
+    static bool opted[2] = {false, false};
+    if (!opted[pre]) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_epi);
+      if (e != hipSuccess) { set_error("latent_qkv_kernel: LDS opt-in of %zu bytes: %s", lds_epi, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+      opted[pre] = true;
+    }
+    if (pre) hipLaunchKernelGGL((latent_qkv_kernel<TT, true>), dim3((unsigned)(n_lat + tiles)), dim3(LAT_THREADS), lds, s, la, g, (int)n_lat);
+    else hipLaunchKernelGGL((latent_qkv_kernel<TT, false>), dim3((unsigned)(n_lat + tiles)), dim3(LAT_THREADS), lds, s, la, g, (int)n_lat);
+    MST_CHECK_LAUNCH("latent_qkv_kernel");
+    return MST_OK;
   });
 }
 

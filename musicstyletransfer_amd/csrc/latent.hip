@@ -16,200 +16,14 @@
 #include <math.h>
 #include "common.hpp"
 #include "outer_jobs.hpp"
+#include "latent_fwd.hpp"
 
 namespace mst {
 
-constexpr int LAT_THREADS = 1024;  // 16 waves: these kernels are B workgroups of dependent dot products (latency-bound)
-constexpr int OPW = 8;             // outputs a wave works on at once
-constexpr int PRE_C = 4;           // 64-lane chunks of a contraction whose weights the forward keeps in registers (De <= 256)
-
-// out[j] = sum_d x[d] * W[j, d] for j < n_out: wave w takes outputs [w*U, w*U+U), then strides by n_waves*U;
-// `emit(j, value)` runs on lane 0
-template <int U, typename F>
-__device__ __forceinline__ void wave_dots(const float* x, int n_in, const float* __restrict__ W, int n_out, int wave, int n_waves,
-                                          int lane, F&& emit) {
-  for (int j0 = wave * U; j0 < n_out; j0 += n_waves * U) {
-    float acc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = 0.f;
-    for (int d = lane; d < n_in; d += 64) {
-      const float xv = x[d];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (j0 + u < n_out) acc[u] = fmaf(xv, W[(int64_t)(j0 + u) * n_in + d], acc[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
-    }
-  }
-}
-
-// wave_dots for contractions of at most 64 * CH elements with every weight load of a pass of U outputs issued up front and the
-// NEXT pass's loads in flight while the current one is reduced (two register sets): the weights are cold lines after every
-// optimizer step, and one dependent round trip per 64 elements of every output made latent_fwd 58 us at configs[2]
-// (2Z = 512 outputs of 256: four passes of four). Same FMA order per output as wave_dots. Loads are unconditional
-// (indices clamped, surplus products multiplied by zero): a conditional load costs a vmcnt(0) drain at the join.
-template <int U, int CH, typename F>
-__device__ __forceinline__ void wave_dots_pre(const float* x, int n_in, const float* __restrict__ W, int n_out, int wave, int n_waves,
-                                              int lane, F&& emit) {
-  const int step = n_waves * U;
-  float xs[CH];
-#pragma unroll
-  for (int k = 0; k < CH; ++k) xs[k] = (lane + 64 * k < n_in) ? x[lane + 64 * k] : 0.f;
-  auto load = [&](float (&w)[U][CH], int j0) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u < n_out ? j0 + u : n_out - 1;
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int d = lane + 64 * k < n_in ? lane + 64 * k : n_in - 1;
-        w[u][k] = W[(int64_t)j * n_in + d];
-      }
-    }
-  };
-  auto reduce = [&](const float (&w)[U][CH], int j0) {
-    float acc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc[u] = 0.f;
-#pragma unroll
-      for (int k = 0; k < CH; ++k)
-        if (lane + 64 * k < n_in) acc[u] = fmaf(xs[k], w[u][k], acc[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
-    }
-  };
-  int j0 = wave * U;
-  if (j0 >= n_out) return;
-  float wa[U][CH], wb[U][CH];
-  load(wa, j0);
-  for (;;) {
-    const int j1 = j0 + step;
-    load(wb, j1 < n_out ? j1 : j0);  // (past the end: the same rows again, unused)
-    reduce(wa, j0);
-    if (j1 >= n_out) break;
-    const int j2 = j1 + step;
-    load(wa, j2 < n_out ? j2 : j1);
-    reduce(wb, j1);
-    if (j2 >= n_out) break;
-    j0 = j2;
-  }
-}
-
-// PRE: the small-shape form (both products in one pass of OPW outputs per wave, weights preloaded: latent_fwd_pre_shape); the
-// general form is a separate instantiation so that its two register sets per product do not cost the small one its registers
-// (in one kernel the 1024-thread launch bounds made the compiler spill 16 / 94 registers of the forward / backward fast paths).
-__host__ __device__ inline bool latent_fwd_pre_shape(int64_t De, int64_t Z, int64_t Dd) {
-  return 2 * Z <= (LAT_THREADS / 64) * OPW && De <= 64 * PRE_C && Dd <= (LAT_THREADS / 64) * OPW && Z <= 64;
-}
 template <typename T, bool PRE>
-__global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(int De, int Z, int Dd, const T* __restrict__ enc_out,
-                                                         int64_t enc_stride, const float* __restrict__ Wl,
-                                                         const float* __restrict__ bl, const float* __restrict__ eps,
-                                                         const float* __restrict__ Wh, const float* __restrict__ bh,
-                                                         const int32_t* __restrict__ classes,
-                                                         const float* __restrict__ cls_d, int64_t ld_cls,
-                                                         const float* __restrict__ pos_d, float alpha_d,
-                                                         float* __restrict__ mu, float* __restrict__ sigma,
-                                                         float* __restrict__ z, float* __restrict__ kl,
-                                                         T* __restrict__ dec_in, int64_t dec_stride) {
+__global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(LatentFwdArgs a) {
   extern __shared__ float sm[];
-  float* h0 = sm;            // [De]
-  float* lat = sm + De;      // [2Z]
-  float* zs = lat + 2 * Z;   // [Z]
-  __shared__ float klred[LAT_THREADS / 64];
-  constexpr int NW = LAT_THREADS / 64;
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Every load whose ADDRESS does not depend on a result is issued before the first barrier: in the step all of these
-  // lines are cold (the weights were rewritten by the optimizer), and the three phases used to pay five dependent
-  // memory round trips (20 us for a few hundred kFLOP). Fast path: one pass of OPW outputs per wave in both products.
-  constexpr bool pre1 = PRE, pre2 = PRE;
-  const int c = classes[b];
-  float w1[OPW][PRE_C], w2[OPW], b1 = 0.f, bh2 = 0.f, cls2 = 0.f, pos2 = 0.f, eps_r = 0.f;
-  const int j1 = wave * OPW;  // this wave's outputs in both products
-  if constexpr (pre1) {
-#pragma unroll
-    for (int u = 0; u < OPW; ++u)
-#pragma unroll
-      for (int k = 0; k < PRE_C; ++k) {
-        const int d = lane + k * 64;
-        w1[u][k] = (j1 + u < 2 * Z && d < De) ? Wl[(int64_t)(j1 + u) * De + d] : 0.f;
-      }
-    if (lane < OPW && j1 + lane < 2 * Z) b1 = bl[j1 + lane];
-  }
-  if constexpr (pre2) {
-#pragma unroll
-    for (int u = 0; u < OPW; ++u) w2[u] = (j1 + u < Dd && lane < Z) ? Wh[(int64_t)(j1 + u) * Z + lane] : 0.f;
-    if (lane < OPW && j1 + lane < Dd) {
-      bh2 = bh[j1 + lane];
-      cls2 = cls_d[(int64_t)c * ld_cls + j1 + lane];
-      pos2 = pos_d[j1 + lane];
-    }
-  }
-  if (tid < Z) eps_r = eps[b * Z + tid];
-  for (int d = tid; d < De; d += LAT_THREADS) h0[d] = to_f32(enc_out[b * enc_stride + d]);
-  __syncthreads();
-  // one wave per output, lanes across the contraction (coalesced weight rows); OPW outputs at a time so that their
-  // weight loads are all in flight together (one output at a time was eight dependent L2 round trips per wave)
-  if constexpr (pre1) {
-    float acc[OPW];
-#pragma unroll
-    for (int u = 0; u < OPW; ++u) {
-      acc[u] = 0.f;
-#pragma unroll
-      for (int k = 0; k < PRE_C; ++k)
-        if (lane + k * 64 < De) acc[u] = fmaf(h0[lane + k * 64], w1[u][k], acc[u]);  // same order as wave_dots
-    }
-#pragma unroll
-    for (int u = 0; u < OPW; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == u && j1 + u < 2 * Z) lat[j1 + u] = v + b1;
-    }
-  } else {
-    if (De <= 64 * PRE_C) wave_dots_pre<OPW, PRE_C>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
-    else wave_dots<OPW>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
-  }
-  __syncthreads();
-  float klacc = 0.f;
-  for (int i = tid; i < Z; i += LAT_THREADS) {
-    const float m = lat[i], s = lat[Z + i];
-    const float zz = m + (i == tid ? eps_r : eps[b * Z + i]) * s;
-    mu[b * Z + i] = m;
-    sigma[b * Z + i] = s;
-    z[b * Z + i] = zz;
-    zs[i] = zz;
-    const float s2 = s * s;
-    klacc += 0.5f * (s2 + m * m - 1.f - logf(s2));
-  }
-  klacc = wave_sum(klacc);
-  if (lane == 0) klred[wave] = klacc;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-    for (int w = 0; w < NW; ++w) t += klred[w];
-    kl[b] = t;
-  }
-  if constexpr (pre2) {
-    const float zv = lane < Z ? zs[lane] : 0.f;
-#pragma unroll
-    for (int u = 0; u < OPW; ++u) {
-      const float v = wave_sum(zv * w2[u]);  // (fmaf(zv, w, 0) of wave_dots)
-      if (lane == u && j1 + u < Dd) dec_in[b * dec_stride + j1 + u] = from_f32<T>(alpha_d * (v + bh2 + cls2) + pos2);
-    }
-  } else {
-    auto emit2 = [&](int j, float acc) {
-      const float v = alpha_d * (acc + bh[j] + cls_d[(int64_t)c * ld_cls + j]) + pos_d[j];
-      dec_in[b * dec_stride + j] = from_f32<T>(v);
-    };
-    if (Z <= 64 * PRE_C) wave_dots_pre<OPW, PRE_C>(zs, Z, Wh, Dd, wave, NW, lane, emit2);
-    else wave_dots<OPW>(zs, Z, Wh, Dd, wave, NW, lane, emit2);
-  }
+  latent_fwd_wg<T, PRE>(a, (int64_t)blockIdx.x, sm);
 }
 
 // sum over j = j0, j0 + step, ... < n of v[j] * W[j, col] (v in LDS), UNR weight loads in flight at a time and the next batch
@@ -404,14 +218,13 @@ extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   MST_CHECK_ARG(lds <= 60000, "mst_latent_fwd: De + 3Z too large for one workgroup");
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (latent_fwd_pre_shape(De, Z, Dd))
-      hipLaunchKernelGGL((latent_fwd_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
-                         (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
-                         alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
-    else
-      hipLaunchKernelGGL((latent_fwd_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
-                         (int)Dd, (const T*)enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d,
-                         alpha_d, mu, sigma, z, kl, (T*)dec_in, dec_sample_stride);
+    LatentFwdArgs la = {};
+    la.De = (int)De; la.Z = (int)Z; la.Dd = (int)Dd; la.enc_out = enc_out; la.enc_stride = enc_sample_stride;
+    la.Wl = Wl; la.bl = bl; la.eps = eps; la.Wh = Wh; la.bh = bh; la.classes = classes; la.cls_d = cls_d; la.ld_cls = ld_cls;
+    la.pos_d = pos_d; la.alpha_d = alpha_d; la.mu = mu; la.sigma = sigma; la.z = z; la.kl = kl; la.dec_in = dec_in;
+    la.dec_stride = dec_sample_stride;
+    if (latent_fwd_pre_shape(De, Z, Dd)) hipLaunchKernelGGL((latent_fwd_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, la);
+    else hipLaunchKernelGGL((latent_fwd_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, la);
     MST_CHECK_LAUNCH("latent_fwd_kernel");
     return MST_OK;
   });

@@ -783,8 +783,11 @@ class StepPlan:
         dh = D // H
         if side == "encoder" and i == self.cfg.e_layers - 1:
             return self._top_encoder_layer_fwd(i, L, x_in)
-        o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
-                       0, D, 2 * D)
+        if side == "decoder" and i == 0 and getattr(self, "_dec_qkv_done", False):  # (projected on the latent block's launch: forward())
+            o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
+        else:
+            o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
+                           0, D, 2 * D)
         # (Dense + LayerNorm in one launch, ops.gemm_nt_ln_fwd, does not pay in the forward pass: graph-replay timings at
         # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
         # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM
@@ -855,10 +858,20 @@ class StepPlan:
             x = self._layer_fwd("encoder", i, L, x, self.keymask_e, De, cfg.e_heads, Se, self.e_p, self._site_e(i))
         self.enc_out = x
         # ---- latent block + decoder position 0 (model.py:97-103,292,229-232)
-        o.latent_fwd(x.view(B, Se, -1), st.p("encoder.latent_proj.weight"), st.p("encoder.latent_proj.bias"), self.eps,
-                     st.p("decoder.latent2hid.weight"), st.p("decoder.latent2hid.bias"), self.classes,
-                     st.p("decoder.class2hid.weight"), self.pos_d, sq_d, self.mu, self.sigma, self.z, self.kl,
-                     self.x0_d.view(B, Sd, -1))
+        lat = (x.view(B, Se, -1), st.p("encoder.latent_proj.weight"), st.p("encoder.latent_proj.bias"), self.eps,
+               st.p("decoder.latent2hid.weight"), st.p("decoder.latent2hid.bias"), self.classes,
+               st.p("decoder.class2hid.weight"), self.pos_d, sq_d, self.mu, self.sigma, self.z, self.kl,
+               self.x0_d.view(B, Sd, -1))
+        # piano-roll ends: rows 1..T of the decoder input exist since the step's first launch, so the decoder's first K | Q | V
+        # projection does not have to wait for the latent block — MST_LATENT_QKV=1 lets it ride on its launch (mst_latent_fwd_qkv).
+        # Off by default: measured at parity at step level (0.661 vs 0.661 ms) — 16-wave workgroups make poor GEMM tiles at K = 128
+        self._dec_qkv_done = (cfg.kind != "token" and cfg.d_layers > 0 and os.environ.get("MST_LATENT_QKV", "0") == "1" and
+                              o.can_latent_fwd_qkv(B, T, De, cfg.latent_dim, Dd))
+        if self._dec_qkv_done:
+            o.latent_fwd_qkv(*lat, self.x0_d, st.fused(st.w16, "decoder.layer0", "weight"), st.fused(st.w, "decoder.layer0", "bias"),
+                             self.dec[0].qkv)
+        else:
+            o.latent_fwd(*lat)
         # ---- decoder positions 1..T (model.py:241-245, transformer.py:237)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos_d, self.x0_d.view(B, Sd, -1), 1, sq_d)

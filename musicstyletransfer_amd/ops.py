@@ -516,6 +516,24 @@ def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu
          ptr(kl), ptr(dec_in3), dec_in3.stride(0), stream())
 
 
+def can_latent_fwd_qkv(B, T, De, Z, Dd):
+    """shapes mst_latent_fwd_qkv takes (the decoder's first K | Q | V projection on the latent block's launch)"""
+    return bool(_lib.load().mst_latent_fwd_qkv_ok(B, T, De, Z, Dd))
+
+
+def latent_fwd_qkv(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in3, x0_d, Wq, bq, qkv):
+    """latent_fwd, and on the same launch qkv = x0_d @ Wq^T + bq for the decoder's first layer: rows 1..T of every sample as GEMM
+    tiles beside the latent workgroups, row 0 by the latent workgroup that produces it (mst_latent_fwd_qkv).
+    x0_d: [B * (T + 1), ld] decoder input (dec_in3 is its [B, T + 1, ld] view), Wq: [3 Dd, Dd] 16-bit shadow, qkv: [B * (T + 1), ld]"""
+    B, Sd = dec_in3.shape[0], dec_in3.shape[1]
+    T = Sd - 1
+    De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
+    g = _gemm_args(x0_d, Wq, qkv, M=B * T, N=3 * Dd, K=Dd, bias=bq, a_remap=(T, Sd, 1), c_remap=(T, Sd, 1))
+    call("mst_latent_fwd_qkv", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
+         ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
+         ptr(kl), ptr(dec_in3), dec_in3.stride(0), C.byref(g), stream())
+
+
 def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d, kl_weight, gscale, dWl, dbl, dWh, dbh,
                dcls_d, d_enc_out3, scratch, enc_scale=1.0):
     B = enc_out3.shape[0]

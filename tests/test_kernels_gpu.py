@@ -1145,6 +1145,50 @@ def test_group_colsum(gpu, B, T, D, s_off):
 
 
 # ------------------------------------------------------------------------------------------ latent
+@pytest.mark.parametrize("B,T,De,Z,Dd,dtype", [(64, 256, 256, 64, 128, BF), (8, 128, 256, 256, 128, torch.float16), (3, 128, 64, 16, 128, BF)])
+def test_latent_fwd_qkv_equals_latent_fwd_then_the_projection(gpu, B, T, De, Z, Dd, dtype):
+    """mst_latent_fwd_qkv (the decoder's first K | Q | V projection on the latent block's launch: rows 1..T of every sample as GEMM
+    tiles beside the latent workgroups, row 0 by its latent workgroup) against mst_latent_fwd followed by the projection GEMM
+    over all B * (T + 1) rows: the latent outputs and rows 1..T bit for bit (same MFMA order per element), row 0 to fp32
+    summation order (dot products instead of an MFMA chain, same 16-bit operands, fp32 accumulation, one rounding)"""
+    o = ops()
+    assert o.can_latent_fwd_qkv(B, T, De, Z, Dd)
+    Sd, Cn = T + 1, 3
+    enc = rnd((B, 4, De), gpu, 1.0, dtype, seed=60)
+    Wl = rnd((2 * Z, De), gpu, dtype=torch.float32, seed=61, scale=0.2)
+    bl = rnd((2 * Z,), gpu, dtype=torch.float32, seed=62, scale=0.5) + 1.0
+    Wh = rnd((Dd, Z), gpu, dtype=torch.float32, seed=63, scale=0.3)
+    bh = rnd((Dd,), gpu, dtype=torch.float32, seed=64, scale=0.1)
+    cls_d = rnd((Cn, Dd), gpu, dtype=torch.float32, seed=65)
+    pos_d = rnd((Sd, Dd), gpu, dtype=torch.float32, seed=66)
+    eps = rnd((B, Z), gpu, dtype=torch.float32, seed=67)
+    classes = (torch.arange(B, dtype=torch.int32) % Cn).to(gpu)
+    Wq = rnd((3 * Dd, Dd), gpu, 0.1, dtype, seed=68)
+    bq = rnd((3 * Dd,), gpu, 0.1, torch.float32, seed=69)
+    x_rows = rnd((B, T, Dd), gpu, 1.0, dtype, seed=70)
+    outs = []
+    for fused in (False, True):
+        mu = torch.zeros(B, Z, device=gpu); sigma = torch.zeros(B, Z, device=gpu); z = torch.zeros(B, Z, device=gpu)
+        kl = torch.zeros(B, device=gpu)
+        x0_d = torch.zeros(B * Sd, Dd, dtype=dtype, device=gpu)
+        x0_d.view(B, Sd, Dd)[:, 1:] = x_rows  # rows 1..T: the embedding GEMM's output
+        qkv = torch.zeros(B * Sd, 3 * Dd, dtype=dtype, device=gpu)
+        lat = (enc, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, math.sqrt(Dd), mu, sigma, z, kl, x0_d.view(B, Sd, Dd))
+        if fused:
+            o.latent_fwd_qkv(*lat, x0_d, Wq, bq, qkv)
+        else:
+            o.latent_fwd(*lat)
+            o.gemm_nt(x0_d, Wq, qkv, K=Dd, bias=bq)
+        torch.cuda.synchronize()
+        outs.append((mu, sigma, z, kl, x0_d, qkv))
+    for a_, b_, name in zip(outs[0][:5], outs[1][:5], ("mu", "sigma", "z", "kl", "decoder input")):
+        assert torch.equal(a_, b_), name
+    q0, q1 = outs[0][5].view(B, Sd, -1), outs[1][5].view(B, Sd, -1)
+    assert torch.equal(q0[:, 1:], q1[:, 1:]), "rows 1..T of the projection"
+    close(q1[:, 0], q0[:, 0].float(), 1e-2, 2e-2, "row 0 of the projection")
+    assert q1[:, 0].abs().sum() > 0
+
+
 def test_latent_fwd_bwd(gpu):
     o = ops()
     B, S, De, Z, Dd, Cn, Sd = 5, 6, 64, 16, 32, 3, 7
