@@ -235,6 +235,9 @@ struct AttnArgs {
   // `qkv` for the backward pass) instead of read. x: [B*S, ld_x] layer input; w: [3 Dm, ld_w] 16-bit weights whose row c is
   // output column c of the qkv layout; bias: fp32 [3 Dm]
   const void* x; int64_t ld_x; const void* w; int64_t ld_w; const float* bias; int64_t Dm;
+  // resident forward with TWO staged tiles instead of three (sequences whose Q | K | V do not fit together: Q for the statistics phase,
+  // then K and V over it for the output phase; the owners' own fragments come from global memory)
+  int restage;
 };
 
 // Online softmax statistics of one 32-query x 32-key tile, key on the lane.
@@ -997,16 +1000,21 @@ __device__ __forceinline__ void qkv_prologue(const AttnArgs& a, T* sQ, T* sK, T*
   }
 }
 
-template <typename T, int DH, bool QKV = false>
+// CHUNKED (a.restage = C >= 2, sequences whose K and V do not fit LDS even without Q — configs[4]'s encoder, S 1024 at head size 32):
+// the output phase stages K and V in C chunks of SP / C keys over the Q tile and every wave carries the accumulators of its (at most
+// two) owned query blocks across the chunks. A separate instantiation: the two accumulator sets are registers the other forms do not pay.
+template <typename T, int DH, bool QKV = false, bool CHUNKED = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_FWD : 4))) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
   const int64_t S = a.S;
   const int NB = (int)((S + 31) / 32), SP = NB * 32;
+  const bool restage = !QKV && a.restage;  // two tiles: [Q, then K][V]; CHUNKED: one tile: [Q, then a chunk of K | the same chunk of V]
+  const int CR = CHUNKED ? SP / a.restage : SP;  // keys staged at a time in the output phase
   T* sQ = reinterpret_cast<T*>(att_smem);
-  T* sK = sQ + SP * LD;
-  T* sV = sK + SP * LD;
-  float* sSk = reinterpret_cast<float*>(sV + SP * LD);
+  T* sK = restage ? sQ : sQ + SP * LD;
+  T* sV = sK + CR * LD;
+  float* sSk = reinterpret_cast<float*>(CHUNKED ? sQ + SP * LD : sV + SP * LD);
   float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP;
   float* sRed = sLogl + SP;  // [LONE_RED]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
@@ -1021,8 +1029,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     qkv_prologue<T>(a, sQ, sK, sV, b, hd, NB);
   } else {
     stage_all<T, DH>(sQ, base + a.q_off, a.ld_qkv, S, SP, tid, nthr);
-    stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
-    stage_all<T, DH>(sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
+    if (!restage) {
+      stage_all<T, DH>(sK, base + a.k_off, a.ld_qkv, S, SP, tid, nthr);
+      stage_all<T, DH>(sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
+    }
   }
   __syncthreads();  // (a workgroup barrier waits for LDS traffic only: the projection's qkv stores drain under the statistics phase)
   ATT_STAMP(2);
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     const int64_t k_lane = ob * 32 + (lane & 31);
     typename Act<T>::vec8 kf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) kf[s] = lds_row_frag<T, DH>(sK, ob * 32, s, lane);
+    for (int s = 0; s < KS; ++s) kf[s] = restage ? glb_row_frag<T>(base + a.k_off, a.ld_qkv, k_lane, S, s, lane) : lds_row_frag<T, DH>(sK, ob * 32, s, lane);
     const bool in = k_lane < S;
     const bool vk = in && a.keymask[b * S + k_lane];
     const float madd = vk ? 0.f : MASK_VALUE;
@@ -1058,7 +1068,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
       const bool vk = a.keymask[b * S + e];
       const float madd = vk ? 0.f : MASK_VALUE;
       float ke[DH];
-      lds_row_load<T, DH>(sK + e * LD, ke);
+      if (restage) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) ke[f] = to_f32(base[a.k_off + e * a.ld_qkv + f]);
+      } else {
+        lds_row_load<T, DH>(sK + e * LD, ke);
+      }
       float m = NEG_BIG, l = 0.f;
       for (int q = tid; q < S; q += nthr) {
         const float t = fmaf(lds_row_dot<T, DH>(sQ + q * LD, ke), a.scale, madd);
@@ -1086,13 +1101,58 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   }
   const bool exact = __syncthreads_or(padded);  // does this sequence hold a padded key?
   ATT_STAMP(3);
+  if constexpr (CHUNKED) {
+    // ---- phase B in C chunks of CR keys; this wave's owned query blocks are ob0 = wave and ob1 = wave + NW (host: NB <= 2 NW, no lone row)
+    constexpr int OBM = 2;
+    typename Act<T>::vec8 qf[OBM][KS];
+    f32x16 o[OBM][DB];
+    bool act[OBM];
+#pragma unroll
+    for (int i = 0; i < OBM; ++i) {
+      const int ob = wave + i * NW;
+      act[i] = ob < NBo && (int64_t)ob * 32 < a.q_limit;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qf[i][s] = glb_row_frag<T>(base + a.q_off, a.ld_qkv, act[i] ? (int64_t)ob * 32 + (lane & 31) : S, S, s, lane);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) o[i][d] = zero16<DH>();
+    }
+    const int tiles_c = CR / 32;
+    for (int c = 0; c < a.restage; ++c) {
+      if (c > 0) __syncthreads();  // every wave is done with the previous chunk (c = 0: with the staged Q, the barrier above)
+      const int64_t k0 = (int64_t)c * CR;
+      stage_pair<T, DH>(sK, base + a.k_off + k0 * a.ld_qkv, a.ld_qkv, S - k0, sV, base + a.v_off + k0 * a.ld_qkv, a.ld_qkv, S - k0, CR, tid, nthr);
+      __syncthreads();
+      const int nt = (NBo - c * tiles_c) < tiles_c ? (NBo - c * tiles_c) : tiles_c;  // (the last chunk may hold fewer tiles)
+#pragma unroll
+      for (int i = 0; i < OBM; ++i) {
+        if (!act[i]) continue;
+        if (exact) {
+          for (int kt = 0; kt < nt; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
+        } else {
+          for (int kt = 0; kt < nt; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
+        }
+      }
+    }
+    T* og = reinterpret_cast<T*>(a.out) + b * S * a.ld_out + hd * DH;
+#pragma unroll
+    for (int i = 0; i < OBM; ++i) {
+      const int64_t q_lane = (int64_t)(wave + i * NW) * 32 + (lane & 31);
+      owner_store<T, DH>((act[i] && q_lane < S && q_lane < a.q_limit) ? og + q_lane * a.ld_out : nullptr, o[i], lane);
+    }
+    return;
+  }
+  if (restage) {  // (every wave is done with the staged Q)
+    stage_pair<T, DH>(sK, base + a.k_off, a.ld_qkv, S, sV, base + a.v_off, a.ld_qkv, S, SP, tid, nthr);
+    __syncthreads();
+  }
 
   // ---- phase B: O = P^T V for the owned queries (attn_fwd_out_kernel's tiles)
   for (int ob = wave; ob < NBo; ob += NW) {
     if ((int64_t)ob * 32 >= a.q_limit) break;
     typename Act<T>::vec8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = lds_row_frag<T, DH>(sQ, ob * 32, s, lane);
+    for (int s = 0; s < KS; ++s)
+      qf[s] = restage ? glb_row_frag<T>(base + a.q_off, a.ld_qkv, (int64_t)ob * 32 + (lane & 31), S, s, lane) : lds_row_frag<T, DH>(sQ, ob * 32, s, lane);
     f32x16 o[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
@@ -1116,7 +1176,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
     if (lone) {  // O[e] = sum_k P[k,e] V[k]: keys on the lanes (P stays fp32 here; the MFMA form rounds it to the activation type)
       const int64_t e = S - 1;
       float qe[DH], acc[DH];
-      lds_row_load<T, DH>(sQ + e * LD, qe);
+      if (restage) {
+#pragma unroll
+        for (int f = 0; f < DH; ++f) qe[f] = to_f32(base[a.q_off + e * a.ld_qkv + f]);
+      } else {
+        lds_row_load<T, DH>(sQ + e * LD, qe);
+      }
 #pragma unroll
       for (int f = 0; f < DH; ++f) acc[f] = 0.f;
       for (int k = tid; k < S; k += nthr) {
@@ -1409,7 +1474,7 @@ static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_
   }
   return best;
 }
-template <int DH> static size_t res_lds_fwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 3 * SP * LdsLd<DH>::V * 2 + 5 * SP * 4 + LONE_RED * 4; }
+template <int DH> static size_t res_lds_fwd(int64_t S, int tiles = 3) { const size_t SP = (size_t)cdiv(S, 32) * 32; return (size_t)tiles * SP * LdsLd<DH>::V * 2 + 5 * SP * 4 + LONE_RED * 4; }
 template <int DH> static size_t res_lds_bwd(int64_t S) { const size_t SP = (size_t)cdiv(S, 32) * 32; return 2 * SP * LdsLd<DH>::V * 2 + 6 * SP * 4 + LONE_RED * 4; }
 
 static int attn_check(int64_t B, int64_t S, int64_t H, int64_t dh, int64_t ld, int64_t k_off, int64_t q_off, int64_t v_off) {
@@ -1446,9 +1511,38 @@ static int launch_fwd_qkv(const AttnArgs& a, hipStream_t s) {
 }
 
 template <typename T, int DH>
-static int launch_fwd(const AttnArgs& a, hipStream_t s) {
-  const size_t lds = res_lds_fwd<DH>(a.S);
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_FWD : 16, lone_row_shape(a.S, DH) && a.q_limit >= a.S)) {
+static int launch_fwd(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
+  size_t lds = res_lds_fwd<DH>(a.S);
+  const bool lone_f = lone_row_shape(a.S, DH) && a.q_limit >= a.S;
+  const int waves_cu = DH == 16 ? 4 * MST_ATT16_WAVES_FWD : 16;
+  int nw = choose_resident(a.S, a.B * a.H, lds, waves_cu, lone_f);
+  if (!nw) {  // Q | K | V do not fit together: two tiles, K and V staged over Q between the phases (configs[4]'s decoder: S 1025, dh 16)
+    static const bool off = getenv("MST_ATTN_RESTAGE") && getenv("MST_ATTN_RESTAGE")[0] == '0';
+    const size_t lds2 = res_lds_fwd<DH>(a.S, 2);
+    const int nw2 = off ? 0 : choose_resident(a.S, a.B * a.H, lds2, waves_cu, lone_f);
+    if (nw2) { nw = nw2; lds = lds2; a.restage = 1; }
+    else if (!off && !lone_f && DH >= 32) {
+      // ... nor K | V alone: one tile, the output phase in two chunks of keys (configs[4]'s encoder: S 1024, head size 32)
+      const int NB = (int)cdiv(a.S, 32);
+      const size_t lds1 = res_lds_fwd<DH>(a.S, 1);
+      const int nw1 = NB % 2 == 0 ? choose_resident(a.S, a.B * a.H, lds1, waves_cu, false) : 0;
+      if (nw1 && NB <= 2 * nw1) {
+        a.restage = 2;
+        static size_t attr_lds1 = 64 * 1024;
+        if (lds1 > attr_lds1) {
+          const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+          if (e != hipSuccess) { set_error("attn_fwd_res_kernel (chunked): LDS opt-in of %zu bytes: %s", lds1, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+          attr_lds1 = lds1;
+        }
+        hipLaunchKernelGGL((attn_fwd_res_kernel<T, DH, false, true>), dim3((unsigned)(a.B * a.H)), dim3(nw1 * 64), lds1, s, a);
+        MST_CHECK_LAUNCH("attn_fwd_res_kernel (chunked)");
+        return MST_OK;
+      }
+    }
+  }
+  if (nw) {
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KB has to be opted into
     if (lds > attr_lds) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<T, DH>),

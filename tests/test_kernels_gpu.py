@@ -874,7 +874,10 @@ def test_attention_with_fused_projection_equals_gemm_then_attention(gpu, B, S, H
 
 
 @pytest.mark.parametrize("B,S,H,dh", [(2, 64, 2, 32), (3, 5, 2, 16), (2, 257, 8, 16), (2, 256, 8, 32), (1, 100, 1, 64),
-                                     (1, 1024, 2, 32)])
+                                     (1, 1024, 2, 32),
+                                     # configs[4]'s decoder: Q | K | V do not fit LDS together - the resident forward stages K and V
+                                     # over Q between its phases (two tiles), the lone row 1025 apart
+                                     (1, 1025, 2, 16), (2, 700, 2, 32)])
 @pytest.mark.parametrize("path", ["auto", "stream"])
 def test_attention_fwd_bwd(gpu, monkeypatch, B, S, H, dh, path):
     """auto: the resident single-launch kernels when the sequence fits in LDS (all cases but S=1024), else the
