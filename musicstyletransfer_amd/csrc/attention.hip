@@ -1451,6 +1451,90 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
   }
 }
 
+// ---- dQ with the keys staged in CHUNKS (sequences too long for the resident backward kernel: configs[4]'s encoder, S 1024).
+// The streaming attn_bwd_q_kernel re-stages 64 keys at a time for four waves and spends 860 cycles per tile visit — twice the
+// resident kernels — on per-stage bookkeeping; here one workgroup owns a (batch, head), stages K | V in chunks of CR keys for all
+// of its waves at once, fills the per-key constants once, and every wave carries the dQ accumulators of its (up to OBM) query
+// blocks across the chunks. Same tile arithmetic (bwd_q_tile). 8 waves: 256 registers each hold four blocks' accumulators and fragments.
+template <typename T, int DH, int OBM>
+__global__ __launch_bounds__(512) void attn_bwd_q_chunk_kernel(AttnArgs a, int n_chunks) {
+  constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+  const int64_t S = a.S;
+  const int NB = (int)((S + 31) / 32), SP = NB * 32, CR = SP / n_chunks;
+  T* sK = reinterpret_cast<T*>(att_smem);
+  T* sV = sK + CR * LD;
+  float* sSk = reinterpret_cast<float*>(sV + CR * LD);
+  float* sCk = sSk + SP; float* sMadd = sCk + SP; float* sMax = sMadd + SP; float* sLogl = sMax + SP; float* sNd = sLogl + SP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
+  const int64_t bh = res_wg_bh(a.B, a.H), b = (int64_t)((uint32_t)bh / (uint32_t)a.H), hd = bh - b * a.H;
+  const int64_t plane = a.B * a.H * S;
+  const float log2_scale = __log2f(a.scale);
+  const T* base = reinterpret_cast<const T*>(a.qkv) + b * S * a.ld_qkv + hd * DH;
+  const T* dOg = reinterpret_cast<const T*>(a.dout) + b * S * a.ld_dout + hd * DH;
+  const bool sparse = a.q_limit > 0 && a.q_limit <= 32;    // dO is zero from row q_limit on (the top encoder layer)
+  const int64_t do_rows = sparse ? a.q_limit : S;
+  // the owned blocks' Q / dO fragments: requested first, they are not needed before the first chunk is staged
+  typename Act<T>::vec8 qf[OBM][KS], dof[OBM][KS];
+  f32x16 acc[OBM][DB];
+  bool act[OBM];
+#pragma unroll
+  for (int i = 0; i < OBM; ++i) {
+    const int ob = wave + i * NW;
+    act[i] = ob < NB;
+    const int64_t q_lane = act[i] ? (int64_t)ob * 32 + (lane & 31) : S;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qf[i][s] = glb_row_frag<T>(base + a.q_off, a.ld_qkv, q_lane, S, s, lane);
+      dof[i][s] = glb_row_frag<T>(dOg, a.ld_dout, q_lane, do_rows, s, lane);
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[i][d] = zero16<DH>();
+  }
+  // per-key constants of the whole sequence (attn_bwd_q_kernel computes them per stage)
+  int padded = 0;
+  for (int k = tid; k < SP; k += nthr) {
+    const bool in = k < S;
+    const bool vk = in && a.keymask[b * S + k];
+    const float rmax = in ? a.lse[bh * S + k] : 0.f, logl = in ? a.lse[plane + bh * S + k] : 0.f;
+    float sk2, ck2;
+    key_consts(in, vk, rmax, logl, a.scale, sk2, ck2);
+    sSk[k] = sk2; sCk[k] = ck2 + log2_scale;  // the exponential is P * scale (bwd_q_tile)
+    sMadd[k] = vk ? 0.f : MASK_VALUE; sMax[k] = rmax; sLogl[k] = in ? logl : INFINITY;
+    sNd[k] = in ? -a.delta[bh * S + k] : 0.f;
+    padded |= (in && !vk);
+  }
+  const bool exact = __syncthreads_or(padded);
+  const int tiles_c = CR / 32;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c > 0) __syncthreads();  // every wave is done with the previous chunk
+    const int64_t k0 = (int64_t)c * CR;
+    if (k0 >= S) break;  // (uniform)
+    stage_pair<T, DH>(sK, base + a.k_off + k0 * a.ld_qkv, a.ld_qkv, S - k0, sV, base + a.v_off + k0 * a.ld_qkv, a.ld_qkv, S - k0, CR, tid, nthr);
+    __syncthreads();
+    const int nt = (NB - c * tiles_c) < tiles_c ? (NB - c * tiles_c) : tiles_c;
+#pragma unroll
+    for (int i = 0; i < OBM; ++i) {
+      if (!act[i]) continue;
+      const bool light = sparse && (wave + i * NW) > 0;  // this block's dO rows are zero
+      if (light) {
+        if (exact) for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, true, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+        else for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, false, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+      } else if (exact) {
+        for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+      } else {
+        for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+      }
+    }
+  }
+  T* dst = reinterpret_cast<T*>(a.dqkv) + b * S * a.ld_dqkv + hd * DH + a.q_off;
+#pragma unroll
+  for (int i = 0; i < OBM; ++i) {
+    const int64_t q_lane = (int64_t)(wave + i * NW) * 32 + (lane & 31);
+    owner_store<T, DH>((act[i] && q_lane < S) ? dst + q_lane * a.ld_dqkv : nullptr, acc[i], lane);
+  }
+}
+
 // Waves per workgroup for the resident kernels, or 0 when the sequence does not fit: maximise (resident waves per CU)
 // x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU,
 // the 96 of the head-size-16 instantiations 20 (two 9-wave workgroups of a 257-row sequence: the decoder of configs[1]).
@@ -1584,6 +1668,27 @@ static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_bwd_kv_kernel");
+  {  // dQ: one workgroup per (batch, head) with the keys staged in chunks where the constants and two chunk tiles fit LDS
+    static const bool off = getenv("MST_ATTN_QCHUNK") && getenv("MST_ATTN_QCHUNK")[0] == '0';
+    constexpr int OBM = 4, NWQ = 8;
+    const int NB = (int)cdiv(a.S, 32);
+    if (!off && DH == 32 && NB <= OBM * NWQ) {  // (head size 32: at 64 four blocks' accumulators and fragments do not fit 256 registers)
+      for (int nc = 1; nc <= 4; nc *= 2) {
+        if (NB % nc != 0) break;
+        const size_t lds = (size_t)2 * (NB * 32 / nc) * LdsLd<DH>::V * 2 + (size_t)6 * NB * 32 * 4;
+        if (lds > 150 * 1024) continue;
+        static size_t attr_lds = 64 * 1024;
+        if (lds > attr_lds) {
+          const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_chunk_kernel<T, DH, OBM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) { set_error("attn_bwd_q_chunk_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+          attr_lds = lds;
+        }
+        hipLaunchKernelGGL((attn_bwd_q_chunk_kernel<T, DH, OBM>), dim3((unsigned)(a.B * a.H)), dim3(NWQ * 64), lds, s, a, nc);
+        MST_CHECK_LAUNCH("attn_bwd_q_chunk_kernel");
+        return MST_OK;
+      }
+    }
+  }
   hipLaunchKernelGGL((attn_bwd_q_kernel<T, DH>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_bwd_q_kernel");
   return MST_OK;
