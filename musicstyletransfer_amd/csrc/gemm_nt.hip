@@ -2013,9 +2013,28 @@ extern "C" int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a0.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
+    const int64_t sh_tiles = sb.sh_w ? sb.sh_tiles : 0;
+    // long contractions (configs[2]: 2048 pitch columns per frame): 128 x 128 tiles — the uint8 frames cross L2 -> LDS once per
+    // 128 output columns instead of once per 64 (three times instead of six for the two tables), 33 K stages amortise the tile's
+    // prologue and epilogue; at configs[1]'s K = 128 the 64 x 64 form stays (1 536 short tiles fill the chip, 384 long ones do not)
+    static const bool big_off = getenv("MST_GEMM_PAIR_BIG") && getenv("MST_GEMM_PAIR_BIG")[0] == '0';
+    if (!big_off && a0.K >= 1024 && a1.K >= 1024 && gemm_fast_form<128, 128>(a0) && gemm_fast_form<128, 128>(a1)) {
+      const int t0 = (int)((a0.M / 128) * (a0.N / 128)), t1 = (int)((a1.M / 128) * (a1.N / 128));
+      const size_t lds_b = (size_t)2 * (128 + 128) * 64 * 2;  // (epilogue: one 64-row block of the tile at a time, PATH 4: 34 KB)
+      static bool opted = false;
+      if (!opted) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pair_kernel<T, 128, 128, 2, 2, 64, 4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        if (e != hipSuccess) { set_error("gemm_nt_pair_kernel: LDS opt-in of %zu bytes: %s", lds_b, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+        opted = true;
+      }
+      hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 128, 128, 2, 2, 64, 4>), dim3((unsigned)(n_begin + t0 + t1 + sh_tiles)), dim3(256), lds_b, s, a0, a1,
+                         t0, t1, sb, n_begin);
+      MST_CHECK_LAUNCH("gemm_nt_pair_kernel");
+      return MST_OK;
+    }
     const int tiles0 = (int)((a0.M / 64) * (a0.N / 64)), tiles1 = (int)((a1.M / 64) * (a1.N / 64));
     const size_t lds = (size_t)2 * (64 + 64) * 64 * 2;  // K-loop stages; the 64 x 68 fp32 epilogue staging is smaller
-    const int64_t sh_tiles = sb.sh_w ? sb.sh_tiles : 0;
     hipLaunchKernelGGL((gemm_nt_pair_kernel<T, 64, 64, 2, 2, 64, 1>), dim3((unsigned)(n_begin + tiles0 + tiles1 + sh_tiles)), dim3(256), lds, s, a0,
                        a1, tiles0, tiles1, sb, n_begin);
     MST_CHECK_LAUNCH("gemm_nt_pair_kernel");

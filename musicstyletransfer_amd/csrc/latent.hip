@@ -70,6 +70,43 @@ __host__ __device__ inline bool latent_bwd_pre_shape(int64_t De, int64_t Z, int6
   const int64_t np_h = LAT_THREADS / Z, np_l = LAT_THREADS / De;
   return (Dd + np_h - 1) / np_h <= LAT_PRE_H && (2 * Z + np_l - 1) / np_l <= LAT_PRE_L;
 }
+// the same for FOUR consecutive columns (one 16-byte load per row): four times fewer load instructions and four times more row parts
+// per output (latent_bwd_vec's general path at configs[2]: 512 rows x 256 columns — 32 rows per thread in four batches instead of 128 in eight)
+template <int UNR>
+__device__ __forceinline__ f32x4 strided_col_dot4(const float* v, const float* __restrict__ W, int64_t ldw, int col, int j0, int step, int n) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (j0 >= n) return acc;
+  const int cnt = (n - j0 + step - 1) / step;
+  const float* wp = W + (int64_t)j0 * ldw + col;
+  const int64_t wstep = (int64_t)step * ldw;
+  auto load = [&](f32x4 (&w)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) w[u] = *reinterpret_cast<const f32x4*>(wp + (int64_t)(t0 + u < cnt ? t0 + u : cnt - 1) * wstep);
+  };
+  auto fold = [&](const f32x4 (&w)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (t0 + u < cnt) {
+        const float x = v[j0 + (t0 + u) * step];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(x, w[u][e], acc[e]);
+      }
+  };
+  f32x4 wa[UNR], wb[UNR];
+  load(wa, 0);
+  for (int t0 = 0;;) {
+    load(wb, t0 + UNR < cnt ? t0 + UNR : t0);
+    fold(wa, t0);
+    t0 += UNR;
+    if (t0 >= cnt) break;
+    load(wa, t0 + UNR < cnt ? t0 + UNR : t0);
+    fold(wb, t0);
+    t0 += UNR;
+    if (t0 >= cnt) break;
+  }
+  return acc;
+}
+
 template <typename T, bool PRE>
 __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int Z, int Dd, const float* __restrict__ Wl,
                                                                      const float* __restrict__ eps,
@@ -85,7 +122,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   extern __shared__ float sm[];
   float* t = sm;             // [Dd]
   float* dl = sm + Dd;       // [2Z]
-  float* part = dl + 2 * Z;  // [LAT_THREADS] partial sums
+  float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(dl + 2 * Z) + 15) & ~(uintptr_t)15);  // [LAT_THREADS] partial sums (general form: float4 each)
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   // Fast path (one round per product, few rows per thread): the weight elements a thread will contract, and mu / sigma
@@ -151,7 +188,20 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
     }
   }
   // dh0[d] = sum_j dlat[j] * Wl[j,d], same split
-  {
+  if (!pre && De % 4 == 0 && De / 4 <= LAT_THREADS && ((uintptr_t)Wl & 15) == 0) {
+    // general path, four columns per thread: `part` holds LAT_THREADS float4 here (the host sizes it for the general form)
+    const int dc4 = De / 4, np4 = LAT_THREADS / dc4;
+    const int c4 = tid % dc4, pt = tid / dc4;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    if (pt < np4) a4 = strided_col_dot4<8>(dl, Wl, De, 4 * c4, pt, np4, 2 * Z);
+    reinterpret_cast<f32x4*>(part)[tid] = a4;
+    __syncthreads();
+    for (int d = tid; d < De; d += LAT_THREADS) {
+      float a = 0.f;
+      for (int p2 = 0; p2 < np4; ++p2) a += part[(p2 * dc4 + d / 4) * 4 + (d & 3)];
+      d_enc_out[b * denc_stride + d] = from_f32<T>(a);
+    }
+  } else {
     const int np = np_l;  // 4 at De = 256
     for (int d0 = 0; d0 < De; d0 += LAT_THREADS) {
       const int d = d0 + tid % dc, pt = tid / dc;
@@ -246,7 +296,7 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   float* dlat = scratch + B * Dd;   // [B, 2Z]
   MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd: latent size above %d", LAT_THREADS);
   MST_CHECK_ARG(2 * Z * De < (1ll << 31) && Dd * Z < (1ll << 31) && B * Dd < (1ll << 31), "mst_latent_bwd: sizes above 2^31 elements");
-  const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
+  const size_t lds = sizeof(float) * (Dd + 2 * Z + (latent_bwd_pre_shape(De, Z, Dd) ? 1 : 4) * LAT_THREADS + 4);  // (+ 4: the float4 view's alignment)
   const int n_wl = (int)cdiv(2 * Z * De, 64), n_wh = (int)cdiv(Dd * Z, 64), n_cls = (int)cdiv(B * Dd, 256);
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
@@ -275,7 +325,7 @@ extern "C" int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, i
   MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_bwd_vec: sizes must be positive");
   MST_CHECK_ARG(Wl && eps && Wh && classes && mu && sigma && d_dec_in && dcls_d && d_enc_out && scratch, "mst_latent_bwd_vec: null pointer");
   MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd_vec: latent size above %d", LAT_THREADS);
-  const size_t lds = sizeof(float) * (Dd + 2 * Z + LAT_THREADS);
+  const size_t lds = sizeof(float) * (Dd + 2 * Z + (latent_bwd_pre_shape(De, Z, Dd) ? 1 : 4) * LAT_THREADS + 4);  // (+ 4: the float4 view's alignment)
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     if (latent_bwd_pre_shape(De, Z, Dd))

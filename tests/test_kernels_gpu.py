@@ -280,7 +280,8 @@ def test_gemm_nt_and_wgrad_uint8_frames_equal_the_16bit_operand(gpu, M, P, N, pe
     close(grads[0], 0.5 * frames[:, :P].float().t() @ dY.float().cpu(), 1e-3, 1e-3 * math.sqrt(M), "embedding wgrad on uint8 frames")
 
 
-@pytest.mark.parametrize("B,T,P,De,Dd,dtype", [(64, 256, 128, 256, 128, BF), (4, 64, 2048, 128, 64, torch.float16), (3, 50, 40, 64, 64, BF)])
+@pytest.mark.parametrize("B,T,P,De,Dd,dtype", [(64, 256, 128, 256, 128, BF), (4, 64, 2048, 128, 64, torch.float16), (3, 50, 40, 64, 64, BF),
+                                                (4, 128, 2048, 256, 128, BF)])  # (the last: long contraction, 128 x 128 tiles)
 def test_gemm_nt_pair_equals_the_two_launches(gpu, B, T, P, De, Dd, dtype):
     """mst_gemm_nt_pair: the encoder's and the decoder's embedding GEMM (same uint8 frames, different tables, adds and output
     row remap) in one launch — bit-identical to the two launches, also where the form falls back to them (the ragged third case)"""
