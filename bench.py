@@ -465,12 +465,17 @@ def run_rank(args):
     plan = E.StepPlan(store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B * world, internal_eps=True, seed=1000,
                       sample_offset=rank * B, site_base=64 * rank)
     host = synthetic_batches(4, B, T, P, seed=1234 + rank)
-    overlap = world > 1 and os.environ.get("MST_DP_OVERLAP", "1") != "0"
+    # MST_DP_OVERLAP: "1" = two gradient ranges, the early one all-reduced while the rest of backward runs; "0" = one all-reduce
+    # between backward and Adam; unset = MEASURED on this job's ranks before anything is timed (below): cutting the step into
+    # a third graph and flushing the early weight gradients apart costs ~60 us on one MI355X, which the overlap has to win back
+    ov_env = os.environ.get("MST_DP_OVERLAP")
+    overlap = world > 1 and ov_env != "0" and plan.grad_cut() > 0
+    sched_tune = None
     group, tune = None, None
     if world > 1:
         # which RCCL algorithm carries the step's gradient ranges: measured on this job's own ranks before anything is timed
         cut = plan.grad_cut() if overlap else 0
-        group, tune = parallel.autotune_allreduce(dist, [store.n - cut, cut], dev)
+        group, tune = parallel.autotune_allreduce(dist, [store.n - cut, cut] + ([store.n] if overlap and ov_env is None else []), dev)
     reduce_fn = parallel.make_grad_allreduce(dist, group) if world > 1 else None
     # data parallel: the early part of the gradient bucket is all-reduced while the rest of backward runs
     reducer = parallel.GradReducer(dist, group) if overlap else None
@@ -494,6 +499,24 @@ def run_rank(args):
         plan.bind_inputs(blobs[0])
         plan.step_kernels(True, reduce_fn=reduce_fn)  # first step eager (HIP module loads), then capture
         torch.cuda.synchronize()
+        if world > 1 and overlap and ov_env is None:
+            # the data-parallel schedule, measured: a few steps of each form on the first batch buffer, MAX over the ranks
+            def time_schedule(ov, steps=12, warm=4):
+                plan.capture(True, split_optimizer=True, overlap=ov)
+                for i in range(warm + steps):
+                    if i == warm:
+                        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    plan.run(reduce_fn=reduce_fn, reducer=reducer if ov else None)
+                torch.cuda.synchronize()
+                t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t[0].item())
+            sched_tune = {"overlapped_ms": time_schedule(True), "single_allreduce_ms": time_schedule(False)}
+            overlap = sched_tune["overlapped_ms"] <= sched_tune["single_allreduce_ms"]
+            sched_tune["chosen"] = "overlapped" if overlap else "single all-reduce"
+            if not overlap:
+                reducer = None
         graphs = {}
         for buf in blobs:
             plan.bind_inputs(buf)
@@ -574,7 +597,7 @@ def run_rank(args):
         rccl = {"nranks": world, "backend": dist.get_backend(), "bucket_bytes": 4 * store.n,
                 "ranges_bytes": {"overlapped_with_backward": 4 * (store.n - cut), "exposed": 4 * cut} if cut else {"exposed": 4 * store.n},
                 "schedule": "two ranges, the early one on the wire during the rest of backward" if cut else "one all-reduce between backward and Adam",
-                "exposed_allreduce_us": exposed_us, "autotune": tune, "log": parallel.rccl_report()}
+                "exposed_allreduce_us": exposed_us, "autotune": tune, "schedule_autotune": sched_tune, "log": parallel.rccl_report()}
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
