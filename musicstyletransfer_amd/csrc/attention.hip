@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void attn_fwd_out_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ bwd_kv
-template <typename T, int DH>
+template <typename T, int DH, bool SPARSE = false>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
   constexpr int ATT_STAGE = Stage<DH>::ROWS;
   constexpr int KS = DH / 16, DB = (DH + 31) / 32;
@@ -643,16 +643,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
   f32x16 acc[DB];
   float neg_delta = 0.f;
   T* const drow = (k_lane < S) ? reinterpret_cast<T*>(a.dqkv) + (b * S + k_lane) * a.ld_dqkv + hd * DH : nullptr;
+  // Sparse mode (0 < q_limit <= 32: dO is zero from row q_limit on — the top encoder layer, as in attn_bwd_res_kernel): dV and delta
+  // need the first query tile alone (pass 0 is one stage, one tile), every other tile of dK is the LIGHT form (dP = 0). The dense
+  // kernel spent the same 139 us on this layer as on the one below it.
+  constexpr bool sparse = SPARSE;  // host: 0 < q_limit <= 32 (a separate instantiation: as run-time branches the dense kernel paid 18 us for them)
   // pass 0: dV and delta; pass 1: dK
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
-    for (int64_t q0 = 0; q0 < S; q0 += ATT_STAGE) {
+    const int64_t Sp = (sparse && pass == 0 && S > ATT_STAGE) ? ATT_STAGE : S;  // query rows this pass sweeps
+    for (int64_t q0 = 0; q0 < Sp; q0 += ATT_STAGE) {
       __syncthreads();
       stage_store<T, DH>(sQ, rq, tid);
       stage_store<T, DH>(sdO, rdo, tid);
       {  // next stage (wrapping to the first one for the second pass)
-        const int64_t qn = (q0 + ATT_STAGE < S) ? q0 + ATT_STAGE : 0;
+        const int64_t qn = (q0 + ATT_STAGE < Sp) ? q0 + ATT_STAGE : 0;
         if (qn != 0 || pass == 0) {
           stage_load<T, DH>(rq, Qg, a.ld_qkv, qn, S, tid);
           stage_load<T, DH>(rdo, dOg, a.ld_dout, qn, S, tid);
@@ -664,8 +669,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
         if (q0 + blk * 32 >= S) break;
         // (query rows >= S need no guard: their staged Q and dO rows are zero)
         if (pass == 0) {
+          if (sparse && (q0 > 0 || blk > 0)) break;  // (their dO rows are zero: nothing for dV)
           if (exact) bwd_kv_tile<T, DH, 0, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
           else bwd_kv_tile<T, DH, 0, false>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2, madd, rmax, logl, neg_delta, acc, lane);
+        } else if (sparse && (q0 > 0 || blk > 0)) {
+          if (exact) bwd_kv_tile<T, DH, 1, true, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
+          else bwd_kv_tile<T, DH, 1, false, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
         } else {
           if (exact) bwd_kv_tile<T, DH, 1, true>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
           else bwd_kv_tile<T, DH, 1, false>(sQ, sdO, blk, a.scale, kf, vf, sk2, ck2s, madd, rmax, logl, neg_delta, acc, lane);
@@ -1666,7 +1675,8 @@ static int launch_bwd(const AttnArgs& a, hipStream_t s) {
     return MST_OK;
   }
   dim3 grid((unsigned)cdiv(a.S, ATT_WG_ROWS), (unsigned)(a.B * a.H));
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH>), grid, dim3(256), 0, s, a);
+  if (sparse_shape) hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH, false>), grid, dim3(256), 0, s, a);
   MST_CHECK_LAUNCH("attn_bwd_kv_kernel");
   {  // dQ: one workgroup per (batch, head) with the keys staged in chunks where the constants and two chunk tiles fit LDS
     static const bool off = getenv("MST_ATTN_QCHUNK") && getenv("MST_ATTN_QCHUNK")[0] == '0';

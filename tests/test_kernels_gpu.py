@@ -937,9 +937,13 @@ def test_attention_q_limit_produces_only_the_first_queries(gpu, monkeypatch, pat
     assert (p3[:, 1:] == 5.0).all()
 
 
-@pytest.mark.parametrize("B,S,H,dh,ragged", [(2, 70, 2, 32, False), (8, 256, 2, 32, True), (3, 257, 2, 16, True)])
-def test_attention_bwd_q_limit_is_bit_identical_to_dense(gpu, B, S, H, dh, ragged):
-    """dO that is zero outside query 0 (the top encoder layer): the sparse mode skips work, not arithmetic"""
+@pytest.mark.parametrize("B,S,H,dh,ragged", [(2, 70, 2, 32, False), (8, 256, 2, 32, True), (3, 257, 2, 16, True), (1, 1024, 2, 32, True)])
+@pytest.mark.parametrize("path", ["auto", "stream"])
+def test_attention_bwd_q_limit_is_bit_identical_to_dense(gpu, monkeypatch, B, S, H, dh, ragged, path):
+    """dO that is zero outside query 0 (the top encoder layer): the sparse mode skips work, not arithmetic — in the resident
+    kernel, in the streaming dV / dK kernel and in the chunked dQ kernel (the last shape: configs[4]'s sequence length)"""
+    if path == "stream":
+        monkeypatch.setenv("MST_ATTN_PATH", "stream")
     o = ops()
     D = H * dh
     qkv = rnd((B * S, 3 * D), gpu, seed=35)
