@@ -878,7 +878,10 @@ def test_attention_with_fused_projection_equals_gemm_then_attention(gpu, B, S, H
                                      (1, 1024, 2, 32),
                                      # configs[4]'s decoder: Q | K | V do not fit LDS together - the resident forward stages K and V
                                      # over Q between its phases (two tiles), the lone row 1025 apart
-                                     (1, 1025, 2, 16), (2, 700, 2, 32)])
+                                     (1, 1025, 2, 16), (2, 700, 2, 32),
+                                     # the same forms with padded keys in the second sample (the reference's operation order in those waves),
+                                     # a ragged last chunk, and a chunked dQ whose sequence is not a whole number of chunks' tiles
+                                     (2, 1000, 2, 32), (2, 1025, 1, 16), (2, 640, 2, 32)])
 @pytest.mark.parametrize("path", ["auto", "stream"])
 def test_attention_fwd_bwd(gpu, monkeypatch, B, S, H, dh, path):
     """auto: the resident single-launch kernels when the sequence fits in LDS (all cases but S=1024), else the
