@@ -21,4 +21,5 @@ def case(B, S, H, dh, dtype):
 
 
 case(64, 256, 8, 32, torch.bfloat16)
+case(64, 257, 8, 16, torch.bfloat16)  # the decoder of configs[1]
 case(32, 1024, 8, 32, torch.float16)
