@@ -623,6 +623,9 @@ def run_rank(args):
         "executed_flops_per_step": exec_flops, "algorithmic_flops_per_step": step_flops,
         "executed_tflops": exec_flops / (ms * 1e-3) / 1e12,
         "elbo": m["total_loss"], "kl": m["kl_loss"],
+        # steps of the timed run + warm-up whose loss was not finite: the optimizer left the model alone in them (mst_step_metrics'
+        # non-finite guard; seen in long free-running fp16 runs at T = 1024, never in the default run)
+        "nonfinite_steps": m.get("nonfinite_steps", 0),
         # what precision meets what tolerance against the CPU oracle on identical weights / inputs / eps, dropout 0
         # (tests/test_configs_gpu.py, tests/test_step_gpu.py): KL = 0.5 sum(sigma^2 + mu^2 - 1 - log sigma^2) has
         # no epsilon and sigma straddles 0 at Xavier init, where a handful of |sigma| < 1e-2 elements carry the error

@@ -624,6 +624,13 @@ typedef struct mst_step_metrics {
    * status[0] when an expectation failed and status[1] is incremented: the batch is skipped, not mis-learned. The host reads
    * the words with the metrics, takes its fallback and clears them. */
   uint32_t* status; const uint32_t* expect_ptr0; uint32_t expect_val0; const uint32_t* expect_ptr1; uint32_t expect_val1;
+  /* Non-finite guard (optional; needs status, which then has a third word): fin_recon / fin_kl = the step's fin_B per-sample
+   * losses. If one of them is not finite — an activation overflowed (fp16 at long sequences: the key-row softmax lets a query
+   * collect up to T key masses, attention outputs of several thousand), or sigma reached 0 under log(sigma^2) — the gradients
+   * are NaN too and an update would destroy every parameter: mst_adam_flat then leaves parameters, moments and the step count
+   * alone, adds nothing to the metric sums and increments status[2]. NOT sticky: the next batch is tried again. Every optimizer
+   * launch of the step gets the same pointers (a second range without `recon` skips with the first). */
+  const float* fin_recon; const float* fin_kl; int64_t fin_B;
 } mst_step_metrics;
 #define MST_TAIL_SPIN_FWD 1u     /* a grid barrier of mst_row_tail_fwd gave up waiting */
 #define MST_TAIL_SPIN_BWD 2u     /* ... of mst_row_tail_bwd */

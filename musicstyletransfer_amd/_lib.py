@@ -106,7 +106,8 @@ TAIL_SPIN_FWD, TAIL_SPIN_BWD, STEP_INCOMPLETE = 1, 2, 16
 
 class StepMetrics(C.Structure):
     _fields_ = [("B", c_i64), ("recon", vp), ("kl", vp), ("kl_weight", c_f32), ("total", vp), ("metric", vp),
-                ("status", vp), ("expect_ptr0", vp), ("expect_val0", c_u32), ("expect_ptr1", vp), ("expect_val1", c_u32)]
+                ("status", vp), ("expect_ptr0", vp), ("expect_val0", c_u32), ("expect_ptr1", vp), ("expect_val1", c_u32),
+                ("fin_recon", vp), ("fin_kl", vp), ("fin_B", c_i64)]
 
 
 class PartialSum(C.Structure):

@@ -37,6 +37,17 @@ __device__ __forceinline__ bool step_is_bad(const mst_step_metrics& mt, bool& in
   if (mt.expect_ptr1 && __hip_atomic_load(mt.expect_ptr1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mt.expect_val1) incomplete = true;
   return incomplete || __hip_atomic_load(mt.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
+// the non-finite guard of mst_step_metrics: true (for every thread of every workgroup alike) when one of the step's per-sample
+// losses is not finite. Called by all threads of a 256-thread workgroup (workgroup barrier inside).
+__device__ __forceinline__ bool step_loss_nonfinite(const mst_step_metrics& mt) {
+  if (!mt.fin_recon || !mt.status) return false;
+  int ok = 1;
+  for (int64_t b = threadIdx.x; b < mt.fin_B; b += blockDim.x) {
+    const float t = mt.fin_recon[b] + (mt.fin_kl ? mt.fin_kl[b] : 0.f);
+    ok &= (fabsf(t) <= 3.0e38f) ? 1 : 0;  // (false for inf and for NaN)
+  }
+  return !__syncthreads_and(ok);
+}
 // one thread, once per step
 __device__ __forceinline__ void step_mark_bad(const mst_step_metrics& mt, bool incomplete) {
   if (incomplete) __hip_atomic_fetch_or(mt.status, MST_STEP_INCOMPLETE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -62,6 +62,13 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(int64_t n, float* __rest
     }
     return;
   }
+  if (step_loss_nonfinite(mt)) {  // (uniform over the launch: every workgroup reads the same losses)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mt.recon) {
+      __hip_atomic_fetch_add(mt.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      state_rw[0] -= 1;
+    }
+    return;
+  }
   if (blockIdx.x == 0 && mt.recon) loss_combine_wg(mt.B, mt.recon, mt.kl, mt.kl_weight, mt.total, mt.metric, red);  // (uniform branch)
   const float lr_t = reinterpret_cast<const float*>(state)[1];
   const int64_t nvec = n / 4;
@@ -148,7 +155,7 @@ static int adam_flat_impl(int dtype, int64_t n, float* w, const float* grad, flo
                           double beta1, double beta2, float eps, float wd, float rescale, float clip,
                           int32_t* step_state, int advance_step, const mst_step_metrics* metrics, const AdamEmb& emb, mst_stream_t stream) {
   MST_CHECK_ARG(n > 0 && w && grad && m && v && step_state, "mst_adam_flat: bad argument");
-  mst_step_metrics mt = {0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u};
+  mst_step_metrics mt = {};
   if (metrics) {
     MST_CHECK_ARG(metrics->recon == nullptr || (metrics->B > 0 && metrics->kl), "mst_adam_flat: metrics need B, recon and kl");
     MST_CHECK_ARG(metrics->status || (!metrics->expect_ptr0 && !metrics->expect_ptr1), "mst_adam_flat: expectations need the status words");

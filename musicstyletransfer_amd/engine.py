@@ -207,11 +207,13 @@ class ParamStore:
         # running metric sums of every step since the last read (trainer.py:107-120,181-186), whatever plan ran it:
         #   metric_acc = [sum kl, sum total, count]; tok_parts = per-workgroup partial rows of the masked token metrics
         #   {sum -log p[label], #arg-max hits, #top-k hits, #valid} accumulated by mst_softmax_ce (token ends)
-        # step_status = two sticky int32 words {flags, skipped steps} of the step guard (mst_step_metrics): set on the device when
-        # a one-launch position-0 tail (mst_row_tail_*) could not finish, read with the metrics (same device->host copy)
+        # step_status = three int32 words of the step guard (mst_step_metrics), read with the metrics (same device->host copy):
+        # {flags, skipped steps} — sticky, set on the device when a one-launch position-0 tail (mst_row_tail_*) could not finish —
+        # and the number of steps the optimizer skipped because a loss was not finite (not sticky: the next batch is tried again)
         self._metric_buf = torch.zeros(8, **f32)
         self.metric_acc = self._metric_buf[:3]
-        self.step_status = self._metric_buf[4:6].view(torch.int32)
+        self.step_status = self._metric_buf[4:7].view(torch.int32)
+        self.nonfinite_steps = 0      # steps skipped for a non-finite loss since the store was made (read_metrics adds them up)
         self.tail_fused = os.environ.get("MST_ROW_TAIL", "1") != "0"  # False: the five-launch form of the position-0 tails
         self.tail_checked = False     # row_tail_selfcheck() ran for this store
         self.tail_policy = os.environ.get("MST_TAIL_FAILURE", "fallback")  # or "raise"
@@ -245,7 +247,7 @@ class ParamStore:
         """A one-launch position-0 tail could not do its work in `skipped` steps since the last read (flags: _lib.TAIL_* /
         STEP_INCOMPLETE). The optimizer launches of those steps left the model untouched (step guard), so nothing wrong was
         learned; from here on the five-launch form runs (policy 'fallback'), or the run stops (policy 'raise')."""
-        o.zero(self._metric_buf[4:8])
+        o.zero(self._metric_buf[4:6])
         self.tail_failures.append((int(flags), int(skipped)))
         self.tail_fused = False
         msg = (f"the one-launch position-0 tail of the top encoder layer failed (status flags {int(flags):#x}: "
@@ -264,10 +266,17 @@ class ParamStore:
         The step-status words travel in the same copy: a set flag is handled here (handle_step_status)."""
         buf = self._metric_buf.cpu()
         acc = buf[:3].tolist()
-        flags, skipped = buf[4:6].view(torch.int32).tolist()
+        flags, skipped, nonfinite = buf[4:7].view(torch.int32).tolist()
+        if nonfinite:
+            # (the optimizer left the model alone in those steps: an overflowed activation or sigma = 0 would have made every
+            # gradient NaN — mst_step_metrics' non-finite guard)
+            self.nonfinite_steps += int(nonfinite)
+            o.zero(self._metric_buf[6:7])
+            warnings.warn(f"{int(nonfinite)} training step(s) skipped: a per-sample loss was not finite (an fp16 activation overflow or "
+                          "sigma = 0 under log(sigma^2)); parameters, moments and the step count were left as they were", RuntimeWarning)
         if flags or skipped:
             self.handle_step_status(flags, skipped)
-        out = {"kl_sum": acc[0], "total_sum": acc[1], "count": acc[2], "skipped_steps": skipped}
+        out = {"kl_sum": acc[0], "total_sum": acc[1], "count": acc[2], "skipped_steps": skipped, "nonfinite_steps": int(nonfinite)}
         if self.tok_parts is not None:
             t = self.tok_parts.cpu().double().sum(0).tolist()
             out.update(nll_sum=t[0], acc_hits=t[1], topk_hits=t[2], n_tokens=t[3])
@@ -637,7 +646,12 @@ class StepPlan:
             exp.append((self.sync_words[0:1], 3 * G))
         if self._tail_used["bwd"]:
             exp.append((self.sync_words[4:5], 2 * G))
-        return dict(status=self.store.step_status, expect=exp) if exp else {}
+        g = dict(status=self.store.step_status, expect=exp)
+        if self.global_batch == self.B:
+            # one rank: the optimizer also skips a step whose loss is not finite (its gradients are NaN: an update would destroy the
+            # model). Not with more ranks: the loss is per rank, the all-reduced gradient is not — ranks would part ways.
+            g["finite"] = (self.recon, self.kl)
+        return g
 
     # ------------------------------------------------------------------------------ inputs
     def bind_inputs(self, buf):
@@ -1318,4 +1332,4 @@ class StepPlan:
         """(kl_loss, total_loss) batch means accumulated on the device (trainer.py:115-116,185-186); one sync."""
         m = self.store.read_metrics(reset)
         n = max(m["count"], 1.0)
-        return {"kl_loss": m["kl_sum"] / n, "total_loss": m["total_sum"] / n, "count": m["count"]}
+        return {"kl_loss": m["kl_sum"] / n, "total_loss": m["total_sum"] / n, "count": m["count"], "nonfinite_steps": m["nonfinite_steps"]}

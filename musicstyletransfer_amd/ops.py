@@ -617,6 +617,10 @@ def _step_metrics(metrics):
     for i, (word, val) in enumerate(exp):
         setattr(mt, f"expect_ptr{i}", ptr(word))
         setattr(mt, f"expect_val{i}", int(val))
+    fin = metrics.get("finite")  # (recon, kl): the non-finite guard (needs status: three int32 words)
+    if fin is not None:
+        assert metrics.get("status") is not None and metrics["status"].numel() >= 3
+        mt.fin_recon, mt.fin_kl, mt.fin_B = ptr(fin[0]), ptr(fin[1]), fin[0].numel()
     return mt
 
 

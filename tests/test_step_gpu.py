@@ -546,7 +546,7 @@ def test_a_failed_position0_tail_is_flagged_skipped_and_replaced_by_the_five_lau
     assert fired == [1] and not store.tail_fused and m["skipped_steps"] == 1 and m["count"] == B  # only step 0 was counted
     flags, skipped = store.tail_failures[-1]
     assert skipped == 1 and flags == 16, flags   # MST_STEP_INCOMPLETE: the forward tail's barrier counter stayed short
-    assert store.step_status.tolist() == [0, 0]
+    assert store.step_status.tolist() == [0, 0, 0]
     step(plan, 1)  # the batch again, now through the five launches
     assert plan._tail_used == dict(fwd=False, bwd=False)
     step(plan, 2)
@@ -560,6 +560,43 @@ def test_a_failed_position0_tail_is_flagged_skipped_and_replaced_by_the_five_lau
     store.step_status[0:1].fill_(1)
     with pytest.raises(RuntimeError, match="position-0 tail"):
         store.read_metrics()
+
+
+def test_a_step_with_a_non_finite_loss_leaves_the_model_alone(gpu):
+    """mst_step_metrics' non-finite guard: a poisoned activation (here: an infinite embedding weight, standing in for an fp16
+    overflow at long sequences) makes the losses and every gradient NaN — the optimizer launch must not apply them. Parameters,
+    moments and the step count stay as they were, the step is counted in the third status word, the metric sums do not take
+    it, and the NEXT step (weight repaired) trains normally: the guard is not sticky."""
+    import warnings
+    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (32, 32, 2, 16, 32, 1, 2, 32, 1, 2), 4, 16, 37)
+    store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+    plan = E.StepPlan(store, 4, 16, lr=1e-3)
+    plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
+    plan.step_kernels(True)
+    torch.cuda.synchronize()
+    assert plan.metrics()["count"] == 4 and int(store.step_state[0].item()) == 1
+    emb = store.p("encoder.embedding.weight")
+    keep = emb[0, 0].item()
+    emb[0, 0] = float("inf")
+    store.refresh_shadows()
+    w_before, m_before = store.w.clone(), store.m.clone()
+    plan.step_kernels(True)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(plan.recon).all() or not torch.isfinite(plan.kl).all()
+    assert torch.equal(store.w.nan_to_num(posinf=1e30), w_before.nan_to_num(posinf=1e30)) and torch.equal(store.m, m_before)
+    assert int(store.step_state[0].item()) == 1
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        m = plan.metrics()
+    assert m["nonfinite_steps"] == 1 and m["count"] == 0 and store.nonfinite_steps == 1
+    assert any("not finite" in str(c.message) for c in caught)
+    emb[0, 0] = keep
+    store.refresh_shadows()
+    plan.step_kernels(True)
+    torch.cuda.synchronize()
+    m = plan.metrics()
+    assert m["nonfinite_steps"] == 0 and m["count"] == 4 and int(store.step_state[0].item()) == 2
+    assert torch.isfinite(store.w).all() and not torch.equal(store.w, w_before)
 
 
 def test_transposed_shadows_follow_the_weights_without_their_own_launch(gpu):
