@@ -378,7 +378,9 @@ def run_decode(args):
     B, K, T, Z = 64, 4, 64, 256  # scripts/train-vae.sh: --max-seq-len 64, --latent-dim 256
     cfg = M.ModelConfig(M.EncoderConfig(TransformerConfig(256, 0.2, 2, 8, NUM_EVENTS), Z, 2, NUM_EVENTS),
                         M.DecoderConfig(TransformerConfig(128, 0.2, 1, 8, NUM_EVENTS), Z, 2, NUM_EVENTS))
-    m = M.Model(cfg).initialize(gpu(0), seed=1234)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # (the model prints its configuration, as the reference does: ONE JSON line on stdout)
+        m = M.Model(cfg).initialize(gpu(0), seed=1234)
     rng = np.random.default_rng(1234)
     tokens = rng.integers(3, NUM_EVENTS, size=(B, T + 1))
     tokens[:, 0] = 1
