@@ -11,8 +11,9 @@
 // and the gradient collapses to p - s (the 1e-12 terms cancel to below one ulp). It agrees with bce_exact to fp32 rounding
 // while the 1e-12 epsilons are invisible (smaller probability >= 1e-7: x >= -16) AND while the reference's own
 // fl(1 - p) still resolves the smaller probability (x <= 9: beyond that p is within a few ulp of 1 and the reference's
-// log(1 - p) is off by 1e-4 and more — which parity keeps); outside [-16, 9] callers take bce_exact (bce_fast_domain,
-// decided per wave so the branch is uniform).
+// log(1 - p) is off by 1e-4 and more — which parity keeps); outside [-16, 9] callers take bce_exact. The choice is per
+// ELEMENT (bce_fast_domain), so the fused and the unfused launch agree bit for bit whatever their element-to-lane maps;
+// callers evaluate bce_exact only in waves that hold an out-of-domain element (a wave-uniform vote), then select.
 #pragma once
 #include "common.hpp"
 
