@@ -851,6 +851,14 @@ __host__ __device__ inline bool lone_row_shape(int64_t S, int dh) { return dh <=
 #ifndef MST_ATT16_WAVES_BWD
 #define MST_ATT16_WAVES_BWD 4
 #endif
+// Waves per workgroup the resident kernels are compiled for. Head size 64 carries twice the fragments and accumulators per
+// wave: under 1024-thread bounds (128 registers per lane) its kernels spilled 46-162 registers; eight waves (256 registers,
+// two per SIMD) hold everything, and three 64-wide tiles of a sequence leave room for one workgroup per CU anyway.
+template <int DH> constexpr int RES_MAX_WAVES = DH == 64 ? 8 : 16;
+// (the plain forward kernel fits 118 registers at head size 64 and keeps sixteen waves — a 257- or 512-row sequence wants more
+// than eight owners —; its chunked and fused-projection forms are the ones that spilled)
+template <int DH, bool HEAVY> constexpr int FWD_MAX_WAVES = HEAVY ? RES_MAX_WAVES<DH> : 16;
+
 // (batch*head) of a 1-D grid; batch elements are dealt to the XCDs so that the heads of one element share an L2
 #ifndef MST_XCD_ROWS
 #define MST_XCD_ROWS 1
@@ -1013,7 +1021,7 @@ __device__ __forceinline__ void qkv_prologue(const AttnArgs& a, T* sQ, T* sK, T*
 // the output phase stages K and V in C chunks of SP / C keys over the Q tile and every wave carries the accumulators of its (at most
 // two) owned query blocks across the chunks. A separate instantiation: the two accumulator sets are registers the other forms do not pay.
 template <typename T, int DH, bool QKV = false, bool CHUNKED = false>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_FWD : 4))) void attn_fwd_res_kernel(AttnArgs a) {
+__global__ __launch_bounds__((FWD_MAX_WAVES<DH, QKV || CHUNKED> * 64)) __attribute__((amdgpu_waves_per_eu((DH == 16 ? MST_ATT16_WAVES_FWD : (FWD_MAX_WAVES<DH, QKV || CHUNKED> == 8 ? 2 : 4))))) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
   const int64_t S = a.S;
@@ -1216,7 +1224,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ?
 }
 
 template <typename T, int DH, bool SPARSE>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_BWD : 4))) void attn_bwd_res_kernel(AttnArgs a) {
+__global__ __launch_bounds__(RES_MAX_WAVES<DH> * 64) __attribute__((amdgpu_waves_per_eu(DH == 16 ? MST_ATT16_WAVES_BWD : (DH == 64 ? 2 : 4)))) void attn_bwd_res_kernel(AttnArgs a) {
   constexpr int KS = DH / 16, DB = (DH + 31) / 32, LD = LdsLd<DH>::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
   const int64_t S = a.S;
@@ -1547,7 +1555,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_chunk_kernel(AttnArgs a, int n
 // Waves per workgroup for the resident kernels, or 0 when the sequence does not fit: maximise (resident waves per CU)
 // x (balance of the 32-row owner blocks over the waves); 128 VGPRs per lane (launch bounds 1024) allow 16 waves per CU,
 // the 96 of the head-size-16 instantiations 20 (two 9-wave workgroups of a 257-row sequence: the decoder of configs[1]).
-static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_cu = 16, bool lone = false) {
+static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_cu = 16, bool lone = false, int max_nw = 16) {
   const char* force = getenv("MST_ATTN_PATH");  // "stream" / "resident": pin the path (tests cover both)
   if (force && force[0] == 's') return 0;
   const size_t LDS_CU = 160 * 1024;
@@ -1556,7 +1564,7 @@ static int choose_resident(int64_t S, int64_t n_wg, size_t lds_bytes, int waves_
   const int by_grid = (int)cdiv(n_wg, 256);
   int best = 0;
   double best_score = 0.0;
-  for (int nw = 1; nw <= 16 && nw <= NB; ++nw) {
+  for (int nw = 1; nw <= max_nw && nw <= NB; ++nw) {
     int wgs = waves_cu / nw;
     if ((size_t)wgs * lds_bytes > LDS_CU) wgs = (int)(LDS_CU / lds_bytes);
     if (wgs > by_grid) wgs = by_grid;
@@ -1619,7 +1627,8 @@ static int launch_fwd(const AttnArgs& a_in, hipStream_t s) {
       // ... nor K | V alone: one tile, the output phase in two chunks of keys (configs[4]'s encoder: S 1024, head size 32)
       const int NB = (int)cdiv(a.S, 32);
       const size_t lds1 = res_lds_fwd<DH>(a.S, 1);
-      const int nw1 = NB % 2 == 0 ? choose_resident(a.S, a.B * a.H, lds1, waves_cu, false) : 0;
+      constexpr int MAXW = FWD_MAX_WAVES<DH, true>;  // (the chunked instantiation's launch bounds)
+      const int nw1 = NB % 2 == 0 ? choose_resident(a.S, a.B * a.H, lds1, DH == 16 ? waves_cu : MAXW, false, MAXW) : 0;
       if (nw1 && NB <= 2 * nw1) {
         a.restage = 2;
         static size_t attr_lds1 = 64 * 1024;
@@ -1659,7 +1668,7 @@ template <typename T, int DH>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds = res_lds_bwd<DH>(a.S);
   const bool sparse_shape = a.q_limit > 0 && a.q_limit <= 32;
-  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_BWD : 16, lone_row_shape(a.S, DH) && !sparse_shape)) {
+  if (const int nw = choose_resident(a.S, a.B * a.H, lds, DH == 16 ? 4 * MST_ATT16_WAVES_BWD : RES_MAX_WAVES<DH>, lone_row_shape(a.S, DH) && !sparse_shape, RES_MAX_WAVES<DH>)) {
     const bool sparse = sparse_shape;
     static size_t attr_lds[2] = {64 * 1024, 64 * 1024};  // dynamic LDS above 64 KB has to be opted into, per kernel
     if (lds > attr_lds[sparse]) {
