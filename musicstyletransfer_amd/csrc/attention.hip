@@ -57,6 +57,23 @@ __device__ __forceinline__ void key_consts(bool in_range, bool valid_key, float 
   else { sk2 = scale * LOG2E; ck2 = -(rmax + logl) * LOG2E; }
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// (the tiles of a bit set, lowest first: scalar loop control)
+#define MST_FOR_TILES(kt, bits) for (uint64_t mst_m_ = (bits); mst_m_; mst_m_ &= mst_m_ - 1) if (const int kt = __builtin_ctzll(mst_m_); true)
+__device__ __forceinline__ uint64_t tile_bits(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+// Which 32-key tiles of a sequence hold a PADDED key (bit t: keys 32 t .. 32 t + 31), from the per-key constants in LDS: a padded
+// key has sk2 = 0 with a finite ck2 (a key beyond the sequence: ck2 = -inf, and its P = 0 needs no exact arithmetic). The
+// query-owner phases take the exact form for those tiles only; a padded batch used to pay it for every tile of every sequence
+// that holds a padded key at all (attention forward + backward at S 256, lengths uniform in [S/2, S]: +29 % over a full batch).
+// Scalar (wave-uniform) result; sequences of up to 64 tiles (the resident kernels' LDS bounds them far below that).
+__device__ __forceinline__ uint64_t padded_tile_mask(const float* sSk, const float* sCk, int n_tiles, int lane) {
+  uint32_t lo = 0u, hi = 0u;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int k = t * 32 + (lane & 31);
+    const bool p = sSk[k] == 0.f && sCk[k] > -INFINITY;
+    if (__any(p)) { if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32); }
+  }
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+}
 // the reference's arithmetic, step by step: t = fl(x*scale + madd); p = exp((t - rowmax) - log(rowsum))
 __device__ __forceinline__ float exact_prob(float x, float scale, float madd, float rmax, float logl) {
   return fast_exp2(((fmaf(x, scale, madd) - rmax) - logl) * LOG2E);
@@ -246,7 +263,9 @@ struct AttnArgs {
 // (madd = 0 for every lane): it tracks the maximum of the raw products and works in the exp2 domain,
 //   m2 = max(x) * c,  l += exp2(x * c - m2),  c = scale * log2(e)
 // i.e. max, fma, v_exp, add per element instead of fma, select, max, sub, mul, v_exp, select, add.
-template <typename T, int DH>
+// GUARD: the tile may hold query rows beyond the sequence (the last tile of a ragged sequence); a whole tile needs neither the
+// sixteen 64-bit row comparisons nor the selects around the exponentials (207 -> 110 issue slots; same values).
+template <typename T, int DH, bool GUARD>
 __device__ __forceinline__ void stats_tile_exact(const T* sQ, int r0, int64_t q_base, int64_t S, float scale, float madd,
                                                  const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane) {
   f32x16 x = zero16<DH>();
@@ -255,14 +274,14 @@ __device__ __forceinline__ void stats_tile_exact(const T* sQ, int r0, int64_t q_
   float t[16], tmax = NEG_BIG;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const bool valid = q_base + acc_row(r, lane) < S;
+    const bool valid = !GUARD || q_base + acc_row(r, lane) < S;
     t[r] = valid ? fmaf(x[r], scale, madd) : NEG_BIG;
     tmax = fmaxf(tmax, t[r]);
   }
   const float m_new = fmaxf(m, tmax);
   float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) sum += (t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
+  for (int r = 0; r < 16; ++r) sum += (!GUARD || t[r] > NEG_BIG) ? __expf(t[r] - m_new) : 0.f;
   l = l * __expf(m - m_new) + sum;
   m = m_new;
 }
@@ -306,7 +325,10 @@ template <typename T, int DH>
 __device__ __forceinline__ void stats_sweep(const T* sQ, int n_tiles, int64_t q0, int64_t S, float scale, float madd, bool exact_w,
                                             const typename Act<T>::vec8 (&kf)[DH / 16], float& m, float& l, int lane, bool thin_tail = false) {
   if (exact_w) {
-    for (int t = 0; t < n_tiles; ++t) stats_tile_exact<T, DH>(sQ, t * 32, q0 + t * 32, S, scale, madd, kf, m, l, lane);
+    for (int t = 0; t < n_tiles; ++t) {
+      if (q0 + t * 32 + 32 <= S) stats_tile_exact<T, DH, false>(sQ, t * 32, q0 + t * 32, S, scale, madd, kf, m, l, lane);
+      else stats_tile_exact<T, DH, true>(sQ, t * 32, q0 + t * 32, S, scale, madd, kf, m, l, lane);
+    }
     return;
   }
   const float c = scale * LOG2E;
@@ -1117,6 +1139,7 @@ __global__ __launch_bounds__((FWD_MAX_WAVES<DH, QKV || CHUNKED> * 64)) __attribu
     }
   }
   const bool exact = __syncthreads_or(padded);  // does this sequence hold a padded key?
+  const uint64_t pad_tiles = exact ? padded_tile_mask(sSk, sCk, NB, lane) : 0ull;  // ... and which of its key tiles do
   ATT_STAMP(3);
   if constexpr (CHUNKED) {
     // ---- phase B in C chunks of CR keys; this wave's owned query blocks are ob0 = wave and ob1 = wave + NW (host: NB <= 2 NW, no lone row)
@@ -1144,7 +1167,10 @@ __global__ __launch_bounds__((FWD_MAX_WAVES<DH, QKV || CHUNKED> * 64)) __attribu
       for (int i = 0; i < OBM; ++i) {
         if (!act[i]) continue;
         if (exact) {
-          for (int kt = 0; kt < nt; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
+          // (two loops, not a branch per tile: with both forms in one loop body the register allocator spilled 44 registers)
+          const uint64_t padc = (pad_tiles >> (c * tiles_c)) & tile_bits(nt);
+          MST_FOR_TILES(kt, ~padc & tile_bits(nt)) fwd_out_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
+          MST_FOR_TILES(kt, padc) fwd_out_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
         } else {
           for (int kt = 0; kt < nt; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, kt, a.scale, qf[i], o[i], lane);
         }
@@ -1174,7 +1200,8 @@ __global__ __launch_bounds__((FWD_MAX_WAVES<DH, QKV || CHUNKED> * 64)) __attribu
 #pragma unroll
     for (int d = 0; d < DB; ++d) o[d] = zero16<DH>();
     if (exact) {
-      for (int kt = 0; kt < NBo; ++kt) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+      MST_FOR_TILES(kt, ~pad_tiles & tile_bits(NBo)) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
+      MST_FOR_TILES(kt, pad_tiles & tile_bits(NBo)) fwd_out_tile<T, DH, true>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
     } else {
       for (int kt = 0; kt < NBo; ++kt) fwd_out_tile<T, DH, false>(sK, sV, sSk, sCk, sMadd, sMax, sLogl, kt, a.scale, qf, o, lane);
     }
@@ -1408,6 +1435,7 @@ __global__ __launch_bounds__(RES_MAX_WAVES<DH> * 64) __attribute__((amdgpu_waves
   __syncthreads();  // every wave is done with the staged Q and dO
   stage_pair<T, DH>(bufA, Kg, a.ld_qkv, S, bufB, Vg, a.ld_qkv, S, SP, tid, nthr);
   const bool exact = __syncthreads_or(padded);
+  const uint64_t pad_tiles = exact ? padded_tile_mask(sSk, sCk, NB, lane) : 0ull;  // (the barrier above: every key's constants are in LDS)
   ATT_STAMP(4);
 
   // ---- phase B: dQ for the owned queries (attn_bwd_q_kernel's tiles)
@@ -1424,10 +1452,13 @@ __global__ __launch_bounds__(RES_MAX_WAVES<DH> * 64) __attribute__((amdgpu_waves
 #pragma unroll
     for (int d = 0; d < DB; ++d) acc[d] = zero16<DH>();
     if (sparse && ob > 0) {  // this block's dO rows are zero
-      if (exact) for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
-      else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      if (exact) {
+        MST_FOR_TILES(kt, ~pad_tiles & tile_bits(NB)) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+        MST_FOR_TILES(kt, pad_tiles & tile_bits(NB)) bwd_q_tile<T, DH, true, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      } else for (int kt = 0; kt < NB; ++kt) bwd_q_tile<T, DH, false, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else if (exact) {
-      for (int kt = 0; kt < NBo; ++kt) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      MST_FOR_TILES(kt, ~pad_tiles & tile_bits(NBo)) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
+      MST_FOR_TILES(kt, pad_tiles & tile_bits(NBo)) bwd_q_tile<T, DH, true>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     } else {
       for (int kt = 0; kt < NBo; ++kt) bwd_q_tile<T, DH, false>(bufA, bufB, sSk, sCk, sMadd, sMax, sLogl, sNd, kt, a.scale, qf, dof, acc, lane);
     }
@@ -1522,6 +1553,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_chunk_kernel(AttnArgs a, int n
     padded |= (in && !vk);
   }
   const bool exact = __syncthreads_or(padded);
+  const uint64_t pad_tiles = exact ? padded_tile_mask(sSk, sCk, NB, lane) : 0ull;
   const int tiles_c = CR / 32;
   for (int c = 0; c < n_chunks; ++c) {
     if (c > 0) __syncthreads();  // every wave is done with the previous chunk
@@ -1535,10 +1567,15 @@ __global__ __launch_bounds__(512) void attn_bwd_q_chunk_kernel(AttnArgs a, int n
       if (!act[i]) continue;
       const bool light = sparse && (wave + i * NW) > 0;  // this block's dO rows are zero
       if (light) {
-        if (exact) for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, true, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
-        else for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, false, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+        if (exact) {
+          const uint64_t padc = (pad_tiles >> (c * tiles_c)) & tile_bits(nt);
+          MST_FOR_TILES(kt, ~padc & tile_bits(nt)) bwd_q_tile<T, DH, false, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+          MST_FOR_TILES(kt, padc) bwd_q_tile<T, DH, true, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+        } else for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, false, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
       } else if (exact) {
-        for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+        const uint64_t padc = (pad_tiles >> (c * tiles_c)) & tile_bits(nt);
+        MST_FOR_TILES(kt, ~padc & tile_bits(nt)) bwd_q_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
+        MST_FOR_TILES(kt, padc) bwd_q_tile<T, DH, true>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
       } else {
         for (int kt = 0; kt < nt; ++kt) bwd_q_tile<T, DH, false>(sK, sV, sSk + k0, sCk + k0, sMadd + k0, sMax + k0, sLogl + k0, sNd + k0, kt, a.scale, qf[i], dof[i], acc[i], lane);
       }

@@ -168,7 +168,13 @@ def _compare_step(gpu, kind, dims, B, T, seed, steps=2, lr=1e-3, dtype=torch.bfl
                     # score scale in dK / dQ): the norm must agree too — to the part the cosine allows for noise, sqrt(1 - c^2) of it
                     ratio = float(np.linalg.norm(gg.astype(np.float64)) / max(np.linalg.norm(rg.astype(np.float64)), 1e-300))
                     slack = 0.25 + (math.sqrt(max(0.0, 1.0 - min(c, 1.0) ** 2)) if noisy(name) else 0.0)
-                    if not (1.0 / (1.0 + slack) <= ratio <= 1.0 + slack):
+                    # ... except where the REFERENCE is chaotic: padded-key logits with |x| >= 32 (counted by the oracle,
+                    # vae_oracle.attention: FLIP_PRONE) make the logit-only gradients of that side depend on the last bits of
+                    # the weights — on this file's real-MIDI batch the oracle's own |dL/d latent2hid| moves 8.7 -> 15.2 between
+                    # two trajectories one rounding apart (tools/experiments/diag_noisy_grads.py). Direction check only there.
+                    side = name.split(".", 1)[0]
+                    chaotic = noisy(name) and any(n > 0 for k, n in ref.get("flip_prone", {}).items() if k.startswith(side + "."))
+                    if not chaotic and not (1.0 / (1.0 + slack) <= ratio <= 1.0 + slack):
                         bad.append(f"step {s} gradient of {name}: norm ratio {ratio:.3f} (cosine {c:.3f})")
                     scale = float(np.abs(rg).max())
                     if not noisy(name) and not np.abs(gg - rg).max() <= max_err * scale:
