@@ -54,6 +54,10 @@ class DecodePlan:
         self.x, self.att, self.h1, self.x1, self.h2, self.x2 = (act(B, D) for _ in range(6))
         self.a = act(B, 4 * D)
         self.mean, self.rstd = torch.zeros(B, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.float32, device=dev)
+        self.mean1, self.rstd1 = torch.zeros(B, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.float32, device=dev)
+        # W_proj + LN1 + feed-forward + LN3 of a position as ONE launch (the training step's mst_proj_ffn_ln_fwd) instead of
+        # five: a decoded position is launch-floor bound (MST_DECODE_FFN=0: the five launches)
+        self.fuse_ffn = o.can_fuse_ffn(D, 4 * D) and os.environ.get("MST_DECODE_FFN", "1") != "0"
         self.logits = act(B, cfg.out_dim)
         self.loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.npos = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -83,12 +87,21 @@ class DecodePlan:
             o.gemm_nt(x, st.fused(st.w16, pre, "weight"), cache.view(B * self.t_max, 3 * D), M=B, K=D, bias=st.fused(st.w, pre, "bias"),
                       c_remap=(1, self.t_max, t))
             o.attn_decode(cache, t + 1, H, D // H, 0, D, 2 * D, self.att, mode=self.mode)
-            o.gemm_nt(self.att, st.h(f"{pre}.att.W_proj.weight"), self.h1, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"), resid=x)
-            o.layernorm_fwd(self.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), self.x1, self.mean, self.rstd, D=D)
-            o.gemm_nt(self.x1, st.h(f"{pre}.ff1.weight"), self.a, K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU)
+            proj = dict(N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"), resid=x)
+            ff1 = dict(K=D, bias=st.p(f"{pre}.ff1.bias"), act=o.ACT_RELU)
             # transformer.py:199-200: LN3(ff + dropout(ff)) — dropout is the identity here, so 2 * ff
-            o.gemm_nt(self.a, st.h(f"{pre}.ff2.weight"), self.h2, K=4 * D, bias=st.p(f"{pre}.ff2.bias"), self_resid=True)
-            o.layernorm_fwd(self.h2, st.p(f"{pre}.ln3.gamma"), st.p(f"{pre}.ln3.beta"), self.x2, self.mean, self.rstd, D=D)
+            ff2 = dict(K=4 * D, bias=st.p(f"{pre}.ff2.bias"), self_resid=True)
+            if self.fuse_ffn:
+                head = dict(att=self.att, W=st.h(f"{pre}.att.W_proj.weight"), h1=self.h1, gamma=st.p(f"{pre}.ln1.gamma"),
+                            beta=st.p(f"{pre}.ln1.beta"), mean=self.mean1, rstd=self.rstd1, **proj)
+                o.ffn_ln_fwd(self.x1, st.h(f"{pre}.ff1.weight"), self.a, st.h(f"{pre}.ff2.weight"), self.h2, st.p(f"{pre}.ln3.gamma"),
+                             st.p(f"{pre}.ln3.beta"), self.x2, self.mean, self.rstd, ff1=ff1, ff2=ff2, proj=head)
+            else:
+                o.gemm_nt(self.att, st.h(f"{pre}.att.W_proj.weight"), self.h1, **proj)
+                o.layernorm_fwd(self.h1, st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), self.x1, self.mean, self.rstd, D=D)
+                o.gemm_nt(self.x1, st.h(f"{pre}.ff1.weight"), self.a, **ff1)
+                o.gemm_nt(self.a, st.h(f"{pre}.ff2.weight"), self.h2, **ff2)
+                o.layernorm_fwd(self.h2, st.p(f"{pre}.ln3.gamma"), st.p(f"{pre}.ln3.beta"), self.x2, self.mean, self.rstd, D=D)
             x = self.x2 if i == cfg.d_layers - 1 else self._keep(self.x2)
         return x
 
@@ -133,9 +146,10 @@ class DecodePlan:
         x = self._layers(self.x, t)
         o.gemm_nt(x, st.h("decoder.output_layer.weight"), self.logits, K=D, bias=st.p("decoder.output_layer.bias"))
         if cfg.kind == "token":
-            o.softmax_ce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, probs=self.probs)
+            # (pre_zeroed: only the probabilities are used here — no 4.7 us memset of a loss nobody reads in every position)
+            o.softmax_ce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, probs=self.probs, pre_zeroed=True)
         else:
-            o.sigmoid_bce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, npos=self.npos, probs=self.probs)
+            o.sigmoid_bce(self.logits, self.zero_labels, self.loss, B, 1, cfg.out_dim, npos=self.npos, probs=self.probs, pre_zeroed=True)
 
     def _run_position(self, t):
         """replay position t's graph (captured at first use; the very first position of a plan runs eagerly: HIP modules

@@ -26,7 +26,7 @@ def timeit(fn, reps=20, inner=20):
 
 
 if __name__ == "__main__":
-  for M, D, F, self_resid in [(16384, 256, 1024, False), (16448, 128, 512, True)]:
+  for M, D, F, self_resid in [(16384, 256, 1024, False), (16384, 128, 512, True), (16448, 128, 512, True)][(1 if os.environ.get("MST_BENCH_FFN_128") else 0):]:
       g = torch.Generator().manual_seed(1)
       r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
       x = r(M, D).to(BF)
