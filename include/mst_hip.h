@@ -540,6 +540,10 @@ int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t L, const f
                   int32_t eos, int32_t pad, mst_stream_t stream);
 int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
                     mst_stream_t stream);
+/* ... the same with bytes [skip_begin, skip_begin + skip_bytes) of every row left alone (whole 16-byte pieces): the Q third of the
+ * cache rows, which no later position reads (a decode step takes its query from the newest row only) — a third less traffic. */
+int mst_beam_gather_cols(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
+                         int64_t skip_begin, int64_t skip_bytes, mst_stream_t stream);
 /* Ancestral sampling on the device (sampler.py:155-190): every sequence n of N draws token i from probs[n, :V] (fp32, need not be
  * normalised) by inverse CDF with u = counter hash of (seed, i, n); written to seqs[n, i] (int32 rows of L) and word[n] (the next
  * position's input); scores[n] += -log p; a finished sequence (EOS, or PAD from position 2 on) continues with PAD at no cost;

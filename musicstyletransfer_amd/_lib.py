@@ -223,6 +223,7 @@ SIGNATURES = {
                                   vp, c_i64, c_f32, C.c_int, vp]),
     "mst_beam_step": (C.c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i32, vp]),
     "mst_beam_gather": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
+    "mst_beam_gather_cols": (C.c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, vp]),
     "mst_sample_step": (C.c_int, [c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_u64, c_i32, c_i32, vp]),
     "mst_loss_combine": (C.c_int, [c_i64, vp, vp, c_f32, vp, vp, vp]),
     "mst_loss_combine_v": (C.c_int, [C.POINTER(StepMetrics), vp]),

@@ -118,11 +118,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs q) {
 }
 
 // out[j, r, :] = in[src[j], r, :] for r < n_rows; rows of row_bytes bytes (a multiple of 16), t_max rows per hypothesis
+// (skip_begin, skip_bytes: a byte range of every row that is NOT copied — the Q third of a K | Q | V cache row: a past position's
+// query is never read again, attn_decode_kernel takes q from the newest row only)
 __global__ __launch_bounds__(256) void beam_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int32_t* __restrict__ src,
-                                                          int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max) {
-  const int64_t pieces = row_bytes / 16, total = N * n_rows * pieces;
+                                                          int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max, int64_t skip_begin,
+                                                          int64_t skip_bytes) {
+  const int64_t pieces = (row_bytes - skip_bytes) / 16, total = N * n_rows * pieces, skip_pc = skip_begin / 16, skip_n = skip_bytes / 16;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
-    const int64_t pc = p % pieces, rr = (p / pieces) % n_rows, j = p / (pieces * n_rows);
+    int64_t pc = p % pieces;
+    const int64_t rr = (p / pieces) % n_rows, j = p / (pieces * n_rows);
+    if (pc >= skip_pc) pc += skip_n;
     const int64_t s = src[j];
     reinterpret_cast<u32x4*>(out + (j * t_max + rr) * row_bytes)[pc] = reinterpret_cast<const u32x4*>(in + (s * t_max + rr) * row_bytes)[pc];
   }
@@ -204,17 +209,24 @@ extern "C" int mst_beam_step(int64_t B, int64_t K, int64_t V, int64_t i, int64_t
   return MST_OK;
 }
 
-extern "C" int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
-                               mst_stream_t stream) {
+extern "C" int mst_beam_gather_cols(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
+                                    int64_t skip_begin, int64_t skip_bytes, mst_stream_t stream) {
   MST_CHECK_ARG(in && out && src && in != out && N > 0 && n_rows > 0 && n_rows <= t_max && row_bytes > 0 && row_bytes % 16 == 0,
                 "mst_beam_gather: bad argument (rows of a multiple of 16 bytes, distinct buffers)");
   MST_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0), "mst_beam_gather: buffers must be 16-byte aligned");
-  const int64_t total = N * n_rows * (row_bytes / 16);
+  MST_CHECK_ARG(skip_begin >= 0 && skip_bytes >= 0 && skip_begin % 16 == 0 && skip_bytes % 16 == 0 && skip_begin + skip_bytes <= row_bytes &&
+                    skip_bytes < row_bytes,
+                "mst_beam_gather_cols: the skipped range must be whole 16-byte pieces inside the row and leave something to copy");
+  const int64_t total = N * n_rows * ((row_bytes - skip_bytes) / 16);
   int64_t grid = cdiv(total, 256 * 4);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(beam_gather_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)in, (uint8_t*)out, src, N,
-                     n_rows, row_bytes, t_max);
+                     n_rows, row_bytes, t_max, skip_begin, skip_bytes);
   MST_CHECK_LAUNCH("beam_gather_kernel");
   return MST_OK;
+}
+extern "C" int mst_beam_gather(const void* in, void* out, const int32_t* src, int64_t N, int64_t n_rows, int64_t row_bytes, int64_t t_max,
+                               mst_stream_t stream) {
+  return mst_beam_gather_cols(in, out, src, N, n_rows, row_bytes, t_max, 0, 0, stream);
 }

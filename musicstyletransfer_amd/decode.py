@@ -223,8 +223,9 @@ class BeamSearch:
         p._position(i)
         o.beam_step(p.probs, self.scores[cur], self.scores[nxt], self.seqs[cur], self.seqs[nxt], self.hyp, p.tokens, i, self.K, self.eos,
                     self.pad, active=self.active)
+        D = p.cfg.d_model
         for cin, cout in zip(p.cache_sets[cur], p.cache_sets[nxt]):
-            o.beam_gather(cin, cout, self.hyp, i + 1)
+            o.beam_gather(cin, cout, self.hyp, i + 1, skip_cols=(D, D))  # K and V only: a past position's Q is never read again
 
     def run(self, row0, check_every=8):
         """row0: [B * K, >= D] initial decoder rows (every sample's row repeated K times). Returns (token rows [B*K, n] int32,

@@ -454,10 +454,16 @@ def sample_step(probs, seqs, scores, word, i, seed, eos, pad, active=None):
          ptr(active), seed, eos, pad, stream())
 
 
-def beam_gather(cache_in, cache_out, src, n_rows):
-    """cache_out[j, :n_rows] = cache_in[src[j], :n_rows] for [N, t_max, width] caches (mst_beam_gather)"""
+def beam_gather(cache_in, cache_out, src, n_rows, skip_cols=None):
+    """cache_out[j, :n_rows] = cache_in[src[j], :n_rows] for [N, t_max, width] caches (mst_beam_gather);
+    skip_cols = (first, count): those columns of every row are left alone (mst_beam_gather_cols)"""
     N, t_max, width = cache_in.shape
-    call("mst_beam_gather", ptr(cache_in), ptr(cache_out), ptr(src), N, n_rows, width * cache_in.element_size(), t_max, stream())
+    es = cache_in.element_size()
+    if skip_cols is None:
+        call("mst_beam_gather", ptr(cache_in), ptr(cache_out), ptr(src), N, n_rows, width * es, t_max, stream())
+    else:
+        call("mst_beam_gather_cols", ptr(cache_in), ptr(cache_out), ptr(src), N, n_rows, width * es, t_max, skip_cols[0] * es,
+             skip_cols[1] * es, stream())
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, D=None, eps=1e-5, M=None, row_id_stride=1):

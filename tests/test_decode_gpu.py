@@ -229,3 +229,22 @@ def test_device_sampling_draws_from_the_distribution(gpu):
     o.sample_step(probs, seqs3, scores2, word, 2, 99, EOS_ID, PAD_ID)
     torch.cuda.synchronize()
     assert torch.equal(seqs2[:, 2], seqs[:, 2]) and not torch.equal(seqs3[:, 2], seqs[:, 2])
+
+
+def test_cache_gather_copies_the_reordered_rows_and_leaves_the_skipped_columns(gpu):
+    """mst_beam_gather / mst_beam_gather_cols (sampler.py:236-238): out[j, :n] = in[src[j], :n]; with a skipped column range
+    (the Q third of K | Q | V rows, which no later position reads) those columns of `out` keep what they held"""
+    from musicstyletransfer_amd import ops as o
+    N, t_max, D, n = 12, 9, 16, 6
+    g = torch.Generator().manual_seed(3)
+    cin = torch.randn(N, t_max, 3 * D, generator=g).to(torch.bfloat16).to(gpu)
+    src = torch.randint(0, N, (N,), generator=g).to(torch.int32).to(gpu)
+    full = torch.full_like(cin, 7.0)
+    o.beam_gather(cin, full, src, n)
+    part = torch.full_like(cin, 7.0)
+    o.beam_gather(cin, part, src, n, skip_cols=(D, D))
+    torch.cuda.synchronize()
+    want = cin[src.long()]
+    assert torch.equal(full[:, :n], want[:, :n]) and (full[:, n:] == 7.0).all()
+    assert torch.equal(part[:, :n, :D], want[:, :n, :D]) and torch.equal(part[:, :n, 2 * D:], want[:, :n, 2 * D:])
+    assert (part[:, :, D:2 * D] == 7.0).all() and (part[:, n:] == 7.0).all()
