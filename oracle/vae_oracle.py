@@ -37,6 +37,8 @@ import torch
 PAD_ID = 0  # MIDIUtil/defaults.py:39
 MASK_VALUE = -1e9  # transformer.py:111
 FLIP_PRONE = {}  # attention prefix -> flip-prone padded-key logits of the last call (diagnostic, see attention())
+QK_OVERRIDE = {}  # test hook: attention prefix -> (K [B,S,D], Q [B,S,D]) to evaluate the logits on (see attention())
+QK_SEEN = {}  # ... and this restatement's own K, Q of the layers that were overridden
 
 
 # ----------------------------------------------------------------------------------------------
@@ -151,9 +153,19 @@ def attention(P, prefix, x, key_valid, H, return_probs=False):
     def split(t):  # :91-93 reshape + swapaxes(1,2) -> [B,H,S,dh]
         return t.reshape(B, S, H, dh).transpose(1, 2)
 
-    K = split(dense(x, P[f"{prefix}.W_k.weight"], P[f"{prefix}.W_k.bias"]))
+    K = dense(x, P[f"{prefix}.W_k.weight"], P[f"{prefix}.W_k.bias"])
     V = split(dense(x, P[f"{prefix}.W_v.weight"], P[f"{prefix}.W_v.bias"]))
-    Q = split(dense(x, P[f"{prefix}.W_q.weight"], P[f"{prefix}.W_q.bias"]))
+    Q = dense(x, P[f"{prefix}.W_q.weight"], P[f"{prefix}.W_q.bias"])
+    if prefix in QK_OVERRIDE:
+        # test hook (not part of the reference): evaluate the logits on the K | Q values ANOTHER implementation produced (its
+        # 16-bit projections), gradients still flowing to this one's — a straight-through substitution. Both sides then put
+        # every padded-key logit on the same -1e9 + 64 n grid point, which removes the chaos described below from a
+        # gradient comparison without removing the comparison. QK_SEEN keeps this side's own values for the caller to check.
+        k_other, q_other = QK_OVERRIDE[prefix]
+        QK_SEEN[prefix] = (K.detach().clone(), Q.detach().clone())
+        K = K + (k_other.to(K.dtype) - K).detach()
+        Q = Q + (q_other.to(Q.dtype) - Q).detach()
+    K, Q = split(K), split(Q)
     logits = torch.matmul(K, Q.transpose(-1, -2))  # :96 gemm2(K, Q, transpose_b) -> [B,H,T_K,T_Q]
     logits = logits / torch.sqrt(torch.tensor(float(dh), dtype=x.dtype))  # :98
     # diagnostic (not part of the reference): padded-key logits with |x| >= 32 — fl(x - 1e9) lands on another multiple of 64
@@ -390,11 +402,18 @@ class OracleTrainer:
         if t is not None:
             self.t = int(t)
 
-    def step(self, batch, eps, masks=None, is_train=True):
+    def step(self, batch, eps, masks=None, is_train=True, qk_override=None):
+        """qk_override (tests only): attention prefix -> (K, Q) of another implementation, see attention()"""
         for p in self.P.values():
             p.grad = None
-        loss, recon, kl, probs, means, stds = step_losses(self.P, self.cfg, batch, eps.to(self.dtype), self.kl_weight, self.ls,
-                                                          self.nld, masks)
+        QK_OVERRIDE.clear()
+        QK_SEEN.clear()
+        QK_OVERRIDE.update(qk_override or {})
+        try:
+            loss, recon, kl, probs, means, stds = step_losses(self.P, self.cfg, batch, eps.to(self.dtype), self.kl_weight, self.ls,
+                                                              self.nld, masks)
+        finally:
+            QK_OVERRIDE.clear()
         grads = None
         if is_train:
             loss.sum().backward()  # :176 head gradient of ones
@@ -411,7 +430,7 @@ class OracleTrainer:
         self.total_sum += float(loss.detach().sum())
         self.count += loss.numel()
         return {"loss": loss.detach(), "recon": recon.detach(), "kl": kl.detach(), "probs": probs.detach(),
-                "means": means.detach(), "stds": stds.detach(), "grads": grads, "flip_prone": dict(FLIP_PRONE)}
+                "means": means.detach(), "stds": stds.detach(), "grads": grads, "flip_prone": dict(FLIP_PRONE), "qk_seen": dict(QK_SEEN)}
 
     def metrics(self):
         return {"kl_loss": self.kl_sum / max(1, self.count), "total_loss": self.total_sum / max(1, self.count)}

@@ -154,28 +154,58 @@ def _compare_step(gpu, kind, dims, B, T, seed, steps=2, lr=1e-3, dtype=torch.bfl
         if check_grads:
             g = store.to_numpy("g")
             gmax = max(float(np.abs(r.numpy()).max()) for r in ref["grads"].values())
+            # Padded-key logits with |x| >= 32 (counted by the oracle, vae_oracle.attention: FLIP_PRONE): fl(x - 1e9) leaves the
+            # -1e9 grid point there and WHICH point it lands on depends on the last bits of x, so the logit-only gradients of
+            # two evaluations that differ by one rounding differ in scale (tools/experiments/diag_noisy_grads.py: the oracle's
+            # own |dL/d latent2hid| 8.7 vs 15.2). Instead of dropping the norm check there (round 3), the oracle is evaluated a
+            # second time from the same state ON THE ENGINE'S 16-bit K | Q (straight-through: vae_oracle.QK_OVERRIDE), so both
+            # sides put every padded-key logit on the same grid point, and the logit-only gradients of that side are compared —
+            # direction and norm — against that evaluation. The engine's K | Q themselves are checked against the oracle's own.
+            flip_sides = sorted({k.split(".", 1)[0] for k, n in ref.get("flip_prone", {}).items() if n > 0})
+            ref_sync = None
+            if flip_sides:
+                ov = {}
+                for side, layers_, S_, D_ in (("encoder", plan.enc, plan.T, ecfg.e_model), ("decoder", plan.dec, plan.T + 1, ecfg.d_model)):
+                    for i, L in enumerate(layers_):
+                        q3 = L.qkv.float().cpu().view(B, S_, -1)
+                        ov[f"{side}.layer{i}.att"] = (q3[:, :, :D_].contiguous(), q3[:, :, D_:2 * D_].contiguous())
+                ot2 = O.OracleTrainer(ocfg, w_before, lr=lr, clip_gradient=1.0, kl_weight=hyper.get("kl_weight", 1.0),
+                                      label_smoothing=hyper.get("label_smoothing", 0.0),
+                                      negative_label_downscaling=hyper.get("negative_label_downscaling", False))
+                ref_sync = ot2.step(batch, torch.from_numpy(eps), qk_override=ov)
+                for pre, (k_o, q_o) in ref_sync["qk_seen"].items():
+                    for nm, mine, theirs in (("K", ov[pre][0], k_o), ("Q", ov[pre][1], q_o)):
+                        e = float((mine - theirs).norm() / theirs.norm().clamp(min=1e-30))
+                        if not e <= (2.5e-2 if bf else 6e-3):
+                            bad.append(f"step {s} {pre} {nm} projection: relative rms error {e:.3g} against the oracle's own")
             num = den_a = den_b = 0.0
             for name, rg in ref["grads"].items():
                 rg = rg.numpy()
                 gg = g[name] / (plan.gscale_enc if name.startswith("encoder.") else plan.gscale)
                 # W_q.bias has an analytically zero gradient (a constant along the softmax axis): compare
                 # tensors whose reference gradient is below 1e-4 of the largest one on absolute error only
+                side = name.split(".", 1)[0]
+                synced = ref_sync is not None and noisy(name) and side in flip_sides
+                if synced:  # (see above: the evaluation whose padded-key logits sit on the engine's grid points)
+                    rg_free = rg
+                    rg = ref_sync["grads"][name].numpy()
+                    if os.environ.get("MST_TEST_NOTES"):  # what the synchronisation changes, for the record (profiles/)
+                        n_e, n_f, n_s = (float(np.linalg.norm(t.astype(np.float64))) for t in (gg, rg_free, rg))
+                        with open(os.environ["MST_TEST_NOTES"], "a") as fh:
+                            fh.write(f"{dtype} step {s} {name}: flip-prone logits {ref['flip_prone']} |g| engine {n_e:.4g} oracle {n_f:.4g} "
+                                     f"(ratio {n_e / max(n_f, 1e-300):.3f}, cos {_cos(gg, rg_free):.3f}) grid-synchronised oracle {n_s:.4g} "
+                                     f"(ratio {n_e / max(n_s, 1e-300):.3f}, cos {_cos(gg, rg):.3f})\n")
                 if np.abs(rg).max() > 1e-4 * gmax:
                     c = _cos(gg, rg)
-                    if not c >= (noisy_cos if noisy(name) else grad_cos):
+                    # (grid-synchronised: measured cosine >= 0.995 / ratio within 4 % in bf16, 1.000 / 0.1 % in fp16 — profiles/r04_flip_sync_notes.txt)
+                    if not c >= ((0.97 if bf else 0.99) if synced else noisy_cos if noisy(name) else grad_cos):
                         bad.append(f"step {s} gradient of {name}: cosine {c:.4f} (|ref| {np.abs(rg).max():.3g})")
                     # ... and a direction check alone would let a SCALE error through (a wrong 1/sqrt(dh), a dropped factor of the
                     # score scale in dK / dQ): the norm must agree too — to the part the cosine allows for noise, sqrt(1 - c^2) of it
                     ratio = float(np.linalg.norm(gg.astype(np.float64)) / max(np.linalg.norm(rg.astype(np.float64)), 1e-300))
-                    slack = 0.25 + (math.sqrt(max(0.0, 1.0 - min(c, 1.0) ** 2)) if noisy(name) else 0.0)
-                    # ... except where the REFERENCE is chaotic: padded-key logits with |x| >= 32 (counted by the oracle,
-                    # vae_oracle.attention: FLIP_PRONE) make the logit-only gradients of that side depend on the last bits of
-                    # the weights — on this file's real-MIDI batch the oracle's own |dL/d latent2hid| moves 8.7 -> 15.2 between
-                    # two trajectories one rounding apart (tools/experiments/diag_noisy_grads.py). Direction check only there.
-                    side = name.split(".", 1)[0]
-                    chaotic = noisy(name) and any(n > 0 for k, n in ref.get("flip_prone", {}).items() if k.startswith(side + "."))
-                    if not chaotic and not (1.0 / (1.0 + slack) <= ratio <= 1.0 + slack):
-                        bad.append(f"step {s} gradient of {name}: norm ratio {ratio:.3f} (cosine {c:.3f})")
+                    slack = 0.10 if synced else 0.25 + (math.sqrt(max(0.0, 1.0 - min(c, 1.0) ** 2)) if noisy(name) else 0.0)
+                    if not (1.0 / (1.0 + slack) <= ratio <= 1.0 + slack):
+                        bad.append(f"step {s} gradient of {name}: norm ratio {ratio:.3f} (cosine {c:.3f}{', grid-synchronised oracle' if synced else ''})")
                     scale = float(np.abs(rg).max())
                     if not noisy(name) and not np.abs(gg - rg).max() <= max_err * scale:
                         bad.append(f"step {s} gradient of {name}: max err {np.abs(gg - rg).max():.3g} vs scale {scale:.3g}")
@@ -479,14 +509,14 @@ def test_raw_xavier_init_is_loosely_matched(gpu):
                   steps=1, check_grads=False, ragged=False)
 
 
-def test_full_size_config2_elbo(gpu):
+def test_full_size_configs1_elbo(gpu):
     """BASELINE.json configs[1]: single-track piano-roll T=256, pitch=128, latent=64, batch=64, bf16;
     widths from scripts/train-vae.sh (D_e 256 x 2 layers x 8 heads, D_d 128 x 1 layer x 8 heads)."""
     plan, store, ot = _compare_step(gpu, "pianoroll", (128, 128, 2, 64, 256, 2, 8, 128, 1, 8), B=64, T=256, seed=1234, steps=1,
                                     lr=3e-4)
 
 
-def test_full_size_config2_elbo_fp16(gpu):
+def test_full_size_configs1_elbo_fp16(gpu):
     """same configuration on the fp16 MFMA path (loss-scaled gradients): ELBO within 1e-3 relative"""
     _compare_step(gpu, "pianoroll", (128, 128, 2, 64, 256, 2, 8, 128, 1, 8), B=64, T=256, seed=99, steps=1, lr=3e-4,
                   dtype=torch.float16)
