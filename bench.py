@@ -31,6 +31,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -433,6 +434,47 @@ def run_decode(args):
     return 0
 
 
+class CandidateRejected(RuntimeError):
+    """a data-parallel candidate that is clearly slower than the baseline (decided on MAX-reduced numbers: every rank alike)"""
+
+
+def run_candidates(baseline_name, baseline, candidates, budget_s, clock=time.monotonic, log=lambda msg: None, on_best=None):
+    """The N > 1 bench line must not depend on anything that has never met RCCL: `baseline` (the result of the plainest
+    schedule, already measured AND already written out by the caller) stays the answer unless a candidate measures
+    faster. candidates: [(name, fn)], fn() -> result dict with 'ms_per_step' or raises. A candidate that raises is
+    recorded and ends the experiments (after a failed collective the communicator's state is unknown); candidates are not
+    started once `budget_s` of wall clock is spent. Returns (name, result, report). Pure host logic: tests/test_bench_launcher.py."""
+    t0 = clock()
+    report = {"baseline": baseline_name, "baseline_ms": baseline["ms_per_step"], "candidates": {}, "errors": {}, "not_run": []}
+    best_name, best = baseline_name, baseline
+    stop = False
+    for name, fn in candidates:
+        if stop or clock() - t0 > budget_s:
+            report["not_run"].append(name)
+            continue
+        try:
+            r = fn()
+        except CandidateRejected as e:  # slower, decided alike on every rank: the next candidate may still run
+            report["candidates"][name] = None
+            report["errors"][name] = f"rejected: {e}"
+            log(f"candidate '{name}' rejected: {e}")
+            continue
+        except Exception as e:  # noqa: BLE001 — anything: the baseline number stands
+            report["candidates"][name] = None
+            report["errors"][name] = f"{type(e).__name__}: {str(e).splitlines()[0][:300] if str(e) else ''}"
+            log(f"candidate '{name}' failed ({report['errors'][name]}); keeping '{best_name}'")
+            stop = True
+            continue
+        report["candidates"][name] = r["ms_per_step"]
+        if r["ms_per_step"] < best["ms_per_step"]:
+            best_name, best = name, r
+            if on_best is not None:  # (a later candidate may build on the best schedule so far)
+                on_best(name, r)
+    report["chosen"] = best_name
+    report["wall_s"] = clock() - t0
+    return best_name, best, report
+
+
 def run_rank(args):
     import torch
     c = CONFIGS[args.config]
@@ -458,6 +500,9 @@ def run_rank(args):
     from musicstyletransfer_amd.VarAutoEncoder.utils import limit_host_threads
     limit_host_threads()
 
+    log = lambda msg: print(f"bench.py [rank {rank}]: {msg}", file=sys.stderr, flush=True)
+    if world > 1:
+        os.environ.setdefault("MST_RCCL_DEBUG", "1")  # communicator set-up lines only (INIT, ENV): nothing is logged per collective
     dist = parallel.init_process_group(world, rank) if world > 1 else None
     adt = torch.bfloat16 if dtype == "bf16" else torch.float16
     md = model_dims(c)
@@ -467,28 +512,16 @@ def run_rank(args):
     plan = E.StepPlan(store, B, T, lr=3e-4, clip_gradient=1.0, kl_weight=1.0, global_batch=B * world, internal_eps=True, seed=1000,
                       sample_offset=rank * B, site_base=64 * rank)
     host = synthetic_batches(4, B, T, P, seed=1234 + rank)
-    # MST_DP_OVERLAP: "1" = two gradient ranges, the early one all-reduced while the rest of backward runs; "0" = one all-reduce
-    # between backward and Adam; unset = MEASURED on this job's ranks before anything is timed (below): cutting the step into
-    # a third graph and flushing the early weight gradients apart costs ~60 us on one MI355X, which the overlap has to win back
-    ov_env = os.environ.get("MST_DP_OVERLAP")
-    overlap = world > 1 and ov_env != "0" and plan.grad_cut() > 0
-    sched_tune = None
-    group, tune = None, None
-    if world > 1:
-        # which RCCL algorithm carries the step's gradient ranges: measured on this job's own ranks before anything is timed
-        cut = plan.grad_cut() if overlap else 0
-        group, tune = parallel.autotune_allreduce(dist, [store.n - cut, cut] + ([store.n] if overlap and ov_env is None else []), dev)
-    reduce_fn = parallel.make_grad_allreduce(dist, group) if world > 1 else None
-    # data parallel: the early part of the gradient bucket is all-reduced while the rest of backward runs
-    reducer = parallel.GradReducer(dist, group) if overlap else None
+    reduce_fn = parallel.make_grad_allreduce(dist, None) if world > 1 else None
 
+    ms_of = lambda r: r["ms_per_step"]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         if args.data == "resident":
             # synthetic piano-rolls, uploaded once: inputs are resident in HBM before the timed region. One captured step
             # per resident batch buffer, each reading its batch in place (StepPlan.bind_inputs)
             blobs = [plan.pack_batch(hb["x"], hb["seq_lens"], hb["classes"], hb["labels"]).to(dev) for hb in host]
-            feed = None
+            pipe = batches = None
         else:
             # every step's batch goes pinned host -> HBM inside the timed region: the Trainer's batcher, three ring slots
             from musicstyletransfer_amd.pianoroll import PinnedBatchPipeline
@@ -501,93 +534,188 @@ def run_rank(args):
         plan.bind_inputs(blobs[0])
         plan.step_kernels(True, reduce_fn=reduce_fn)  # first step eager (HIP module loads), then capture
         torch.cuda.synchronize()
-        if world > 1 and overlap and ov_env is None:
-            # the data-parallel schedule, measured: a few steps of each form on the first batch buffer, MAX over the ranks
-            def time_schedule(ov, steps=12, warm=4):
-                plan.capture(True, split_optimizer=True, overlap=ov)
-                for i in range(warm + steps):
-                    if i == warm:
-                        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                    plan.run(reduce_fn=reduce_fn, reducer=reducer if ov else None)
-                torch.cuda.synchronize()
-                t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+
+        def timed_run(overlap, group=None, limit_ms=None):
+            """capture the step in the given data-parallel form for every batch buffer, W untimed warm-up steps, then EXACTLY
+            K steps between barrier + synchronize; MAX over the ranks. limit_ms: give up (CandidateRejected, on every rank
+            alike) when the warm-up steps already average above it."""
+            rfn = parallel.make_grad_allreduce(dist, group) if world > 1 else None
+            reducer = parallel.GradReducer(dist, group) if (world > 1 and overlap) else None
+            graphs = {}
+            for buf in blobs:
+                plan.bind_inputs(buf)
+                plan.capture(True, split_optimizer=world > 1, overlap=reducer is not None)
+                graphs[buf.data_ptr()] = (plan.graph, plan.graph_late, plan.graph_opt)
+            # data parallel: HIP events on the step's stream around the gap between the end of the backward graph and the
+            # start of the optimizer graph = the part of the gradient all-reduce that nothing hides
+            gaps = [(o.Event(), o.Event()) for _ in range(args.steps)] if world > 1 else None
+
+            def launch(buf, stamps=None):
+                plan.graph, plan.graph_late, plan.graph_opt = graphs[buf.data_ptr()]
+                plan.run(reduce_fn=rfn, reducer=reducer, stamps=stamps)
+
+            if args.data == "resident":
+                def one_step(i, stamps=None):
+                    launch(blobs[i % len(blobs)], stamps)
+            else:
+                feed = pipe.feed((batches[i % len(batches)] for i in range(args.warmup + args.steps)))
+
+                def one_step(i, stamps=None):
+                    s = next(feed)  # batch i was staged while step i-1 ran; the generator stages batch i+1 at the next call
+                    stream.wait_event(s.slot.uploaded)
+                    launch(s.slot.dev, stamps)
+                    s.slot.consumed.record(stream)
+
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            for i in range(args.warmup):
+                one_step(i)
+            torch.cuda.synchronize()
+            if dist is not None and limit_ms is not None and args.warmup > 0:
+                w = torch.tensor([(time.perf_counter() - w0) / args.warmup * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                if float(w[0].item()) > limit_ms:
+                    raise CandidateRejected(f"warm-up steps average {float(w[0].item()):.3f} ms > {limit_ms:.3f} ms")
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev = [o.Event() for _ in range(args.steps + 1)]
+            host_loop = []
+            if args.data == "host":
+                pipe.stamps = []
+            t0 = time.perf_counter()
+            ev[0].record()
+            for i in range(args.steps):
+                h0 = time.perf_counter()
+                one_step(args.warmup + i, gaps[i] if gaps else None)
+                ev[i + 1].record()
+                host_loop.append(time.perf_counter() - h0)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            raw_steps = [ev[i].elapsed_ms(ev[i + 1]) for i in range(args.steps)]
+            per_step = sorted(raw_steps)
+            median_ms = per_step[len(per_step) // 2]
+            host_pipeline = None
+            if args.data == "host":
+                # where a slow step came from: the host's three legs of stage() (wait for the ring slot's previous upload, pack into
+                # the page-locked blob, enqueue the copy) and the whole loop iteration, per step, next to the step's own duration
+                def spread(v):
+                    v = sorted(v)
+                    return {"median_ms": v[len(v) // 2] * 1e3, "p99_ms": v[int(0.99 * (len(v) - 1))] * 1e3, "max_ms": v[-1] * 1e3}
+                legs = list(zip(*pipe.stamps)) if pipe.stamps else ([0.0], [0.0], [0.0])
+                worst = max(range(args.steps), key=lambda i: raw_steps[i])
+                host_pipeline = {"ring_slots": pipe.n_slots, "slot_wait": spread(legs[0]), "pack": spread(legs[1]), "enqueue": spread(legs[2]),
+                                 "host_loop": spread(host_loop), "slowest_step": {"index": worst, "gpu_ms": raw_steps[worst],
+                                                                                 "host_loop_ms": [t * 1e3 for t in host_loop[max(0, worst - 3): worst + 2]]},
+                                 "max_over_median": per_step[-1] / median_ms}
+            exposed_us = None
+            if dist is not None:
+                gap = sorted(a.elapsed_ms(b) * 1e3 for a, b in gaps)
+                t = torch.tensor([elapsed, median_ms, gap[len(gap) // 2]], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t[0].item())
-            sched_tune = {"overlapped_ms": time_schedule(True), "single_allreduce_ms": time_schedule(False)}
-            overlap = sched_tune["overlapped_ms"] <= sched_tune["single_allreduce_ms"]
-            sched_tune["chosen"] = "overlapped" if overlap else "single all-reduce"
-            if not overlap:
-                reducer = None
-        graphs = {}
-        for buf in blobs:
-            plan.bind_inputs(buf)
-            plan.capture(True, split_optimizer=world > 1, overlap=reducer is not None)
-            graphs[buf.data_ptr()] = (plan.graph, plan.graph_late, plan.graph_opt)
-        # data parallel: HIP events on the step's stream around the gap between the end of the backward graph and the
-        # start of the optimizer graph = the part of the gradient all-reduce that nothing hides
-        gaps = [(o.Event(), o.Event()) for _ in range(args.steps)] if world > 1 else None
+                elapsed, median_ms, exposed_us = float(t[0].item()), float(t[1].item()), float(t[2].item())
+            cut = plan.grad_cut() if reducer is not None else 0
+            return {"elapsed": elapsed, "ms_per_step": elapsed / args.steps * 1e3, "median_ms": median_ms, "per_step": per_step,
+                    "host_pipeline": host_pipeline, "exposed_us": exposed_us, "cut": cut}
 
-        def launch(buf, stamps=None):
-            plan.graph, plan.graph_late, plan.graph_opt = graphs[buf.data_ptr()]
-            plan.run(reduce_fn=reduce_fn, reducer=reducer, stamps=stamps)
+        step_flops = 3.0 * fwd_flops(md, B, T)
+        exec_flops = 3.0 * executed_fwd_flops(md, B, T)
 
-        if args.data == "resident":
-            def one_step(i, stamps=None):
-                launch(blobs[i % len(blobs)], stamps)
-        else:
-            feed = pipe.feed((batches[i % len(batches)] for i in range(args.warmup + args.steps)))
+        def bench_line(r, extra=None):
+            """the contract's JSON object from one timed run's result"""
+            ms = r["ms_per_step"]
+            per_step = r["per_step"]
+            out = {
+                "metric": "piano-roll frames/s (VAE train step)", "value": B * T * world * args.steps / r["elapsed"], "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_median": r["median_ms"],
+                "ms_per_step_max": per_step[-1], "ms_per_step_p90": per_step[int(0.9 * (len(per_step) - 1))],
+                "value_at_median": B * T * world / (r["median_ms"] * 1e-3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": dtype,
+                "data": "synthetic" if args.data == "resident" else "synthetic (host batches through the pinned pipeline inside the timed region)",
+                "config": {"workload": f"{c['name']}, T={T}, pitch={P}, latent={c['Z']}, batch={B}/GPU, {dtype}; encoder 256x2x8h, decoder "
+                                       f"128x1x8h (scripts/train-vae.sh), dropout {args.dropout}; Xavier-initialised weights",
+                           "baseline_config_index": args.config if world == 1 or args.config != 1 else 3,
+                           "global_batch": B * world, "seq_len": T, "pitches": P, "latent": c["Z"], "parallelism": f"dp{world}",
+                           "params": store.n_params},
+                "step_tflops": step_flops / (ms * 1e-3) / 1e12,
+                "step_mfma_frac": step_flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                "executed_flops_per_step": exec_flops, "algorithmic_flops_per_step": step_flops,
+                "executed_tflops": exec_flops / (ms * 1e-3) / 1e12,
+            }
+            out.update(extra or {})
+            return out
 
-            def one_step(i, stamps=None):
-                s = next(feed)  # batch i was staged while step i-1 ran; the generator stages batch i+1 at the next call
-                stream.wait_event(s.slot.uploaded)
-                launch(s.slot.dev, stamps)
-                s.slot.consumed.record(stream)
+        # ---- the plainest form first: the default communicator, ONE all-reduce between backward and Adam (N = 1: the whole step
+        # as one graph). It is measured and WRITTEN OUT (stderr + a file) before anything else touches RCCL.
+        base_name = "one all-reduce between backward and Adam, default communicator" if world > 1 else "one captured graph"
+        best_name, best = base_name, timed_run(False, None)
+        dp_report = None
+        final_lock, final_done = threading.Lock(), [False]
+        if world > 1:
+            partial_path = os.environ.get("MST_BENCH_PARTIAL") or os.path.join(tempfile.gettempdir(), f"mst_bench_partial_n{world}.json")
+            if rank == 0:
+                line = json.dumps(bench_line(best, {"partial": True, "schedule": base_name}))
+                print("bench.py partial result (baseline schedule, before any experiment): " + line, file=sys.stderr, flush=True)
+                try:
+                    with open(partial_path, "w") as fh:
+                        fh.write(line + "\n")
+                except OSError as e:
+                    log(f"could not write {partial_path}: {e}")
 
-        for i in range(args.warmup):
-            one_step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev = [o.Event() for _ in range(args.steps + 1)]
-        host_loop = []
-        if args.data == "host":
-            pipe.stamps = []
-        t0 = time.perf_counter()
-        ev[0].record()
-        for i in range(args.steps):
-            h0 = time.perf_counter()
-            one_step(args.warmup + i, gaps[i] if gaps else None)
-            ev[i + 1].record()
-            host_loop.append(time.perf_counter() - h0)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        raw_steps = [ev[i].elapsed_ms(ev[i + 1]) for i in range(args.steps)]
-        per_step = sorted(raw_steps)
-        median_ms = per_step[len(per_step) // 2]
-        host_pipeline = None
-        if args.data == "host":
-            # where a slow step came from: the host's three legs of stage() (wait for the ring slot's previous upload, pack into
-            # the page-locked blob, enqueue the copy) and the whole loop iteration, per step, next to the step's own duration
-            def spread(v):
-                v = sorted(v)
-                return {"median_ms": v[len(v) // 2] * 1e3, "p99_ms": v[int(0.99 * (len(v) - 1))] * 1e3, "max_ms": v[-1] * 1e3}
-            legs = list(zip(*pipe.stamps)) if pipe.stamps else ([0.0], [0.0], [0.0])
-            worst = max(range(args.steps), key=lambda i: raw_steps[i])
-            host_pipeline = {"ring_slots": pipe.n_slots, "slot_wait": spread(legs[0]), "pack": spread(legs[1]), "enqueue": spread(legs[2]),
-                             "host_loop": spread(host_loop), "slowest_step": {"index": worst, "gpu_ms": raw_steps[worst],
-                                                                             "host_loop_ms": [t * 1e3 for t in host_loop[max(0, worst - 3): worst + 2]]},
-                             "max_over_median": per_step[-1] / median_ms}
-        exposed_us = None
-        if dist is not None:
-            gap = sorted(a.elapsed_ms(b) * 1e3 for a, b in gaps)
-            t = torch.tensor([elapsed, median_ms, gap[len(gap) // 2]], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, median_ms, exposed_us = float(t[0].item()), float(t[1].item()), float(t[2].item())
+            # ---- a collective that never returns cannot be caught: if the experiments below do not finish in time, the baseline
+            # line is the bench line and every rank leaves (os._exit: nothing of a stuck communicator is waited for)
+            def give_up():
+                with final_lock:
+                    if final_done[0]:
+                        return
+                    final_done[0] = True
+                    if rank == 0:
+                        rep = {"baseline": base_name, "baseline_ms": ms_of(best), "chosen": base_name, "timed_out_after_s": exp_timeout}
+                        print(json.dumps(bench_line(best, {"roofline": None, "rccl": {"nranks": world, "experiments": rep}})), flush=True)
+                    sys.stderr.write(f"bench.py [rank {rank}]: data-parallel experiments did not finish in {exp_timeout:.0f} s; "
+                                     "the baseline schedule's number stands\n")
+                    sys.stderr.flush()
+                    os._exit(0)
+            exp_timeout = float(os.environ.get("MST_BENCH_EXPERIMENT_TIMEOUT", "240"))
+            watchdog = threading.Timer(exp_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+
+            cands = []
+            limit = 3.0 * ms_of(best)
+            if os.environ.get("MST_DP_OVERLAP", "1") != "0" and plan.grad_cut() > 0:
+                def overlapped():
+                    hook = os.environ.get("MST_BENCH_TEST_CANDIDATE")  # rehearsals of the guard rails (docs/switches.md)
+                    if hook == "raise":
+                        raise RuntimeError("MST_BENCH_TEST_CANDIDATE=raise: a candidate that fails")
+                    if hook == "hang":
+                        time.sleep(1e6)
+                    return timed_run(True, None, limit_ms=limit)
+                cands.append(("two ranges, the early one on the wire during the rest of backward, default communicator", overlapped))
+            tune_box = {}
+            if os.environ.get("MST_RCCL_AUTOTUNE", "0") == "1" or os.environ.get("MST_RCCL_ALGO"):
+                def with_tuned_group():
+                    cut = plan.grad_cut()
+                    g, rep = parallel.autotune_allreduce(dist, [store.n - cut, cut, store.n] if cut else [store.n], dev)
+                    tune_box["report"] = rep
+                    if g is None:
+                        raise CandidateRejected(f"no communicator beat the default one by the margin ({rep.get('candidates')})")
+                    ov = best_name.startswith("two ranges")
+                    r = timed_run(ov, g, limit_ms=limit)
+                    r["group"] = rep["chosen"]
+                    return r
+                cands.append(("best schedule so far on the communicator parallel.autotune_allreduce picked", with_tuned_group))
+
+            def on_best(name, res):
+                nonlocal best_name, best
+                best_name, best = name, res
+            _, _, dp_report = run_candidates(base_name, best, cands, exp_timeout * 0.75, log=log, on_best=on_best)
+            if tune_box.get("report"):
+                dp_report["communicator_autotune"] = tune_box["report"]
+            watchdog.cancel()
         m = plan.metrics()
         if args.data == "host":
             plan.bind_inputs(blobs[0])
@@ -595,54 +723,59 @@ def run_rank(args):
 
     rccl = None
     if dist is not None:
-        cut = plan.grad_cut() if reducer is not None else 0
+        cut = best["cut"]
         rccl = {"nranks": world, "backend": dist.get_backend(), "bucket_bytes": 4 * store.n,
                 "ranges_bytes": {"overlapped_with_backward": 4 * (store.n - cut), "exposed": 4 * cut} if cut else {"exposed": 4 * store.n},
-                "schedule": "two ranges, the early one on the wire during the rest of backward" if cut else "one all-reduce between backward and Adam",
-                "exposed_allreduce_us": exposed_us, "autotune": tune, "schedule_autotune": sched_tune, "log": parallel.rccl_report()}
-        dist.barrier()
-        dist.destroy_process_group()
+                "schedule": best_name, "exposed_allreduce_us": best["exposed_us"], "baseline_ms": dp_report["baseline_ms"],
+                "experiments": dp_report, "log": parallel.rccl_report(cleanup=True)}
+
+        def leave():
+            """the job's last collective comes AFTER rank 0 has printed its line (below), and a communicator that a failed
+            experiment left in an unknown state may never finish it: bounded, then every rank just exits"""
+            bye = threading.Timer(30.0, lambda: os._exit(0))
+            bye.daemon = True
+            bye.start()
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception as e:  # noqa: BLE001
+                log(f"shutdown of the process group failed: {e}")
+            bye.cancel()
+    else:
+        leave = lambda: None
     if rank != 0:
+        leave()
         return 0
-    ms = elapsed / args.steps * 1e3
-    frames = B * T * world * args.steps
-    step_flops = 3.0 * fwd_flops(md, B, T)
-    exec_flops = 3.0 * executed_fwd_flops(md, B, T)
-    out = {
-        "metric": "piano-roll frames/s (VAE train step)", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_median": median_ms,
-        "ms_per_step_max": per_step[-1], "ms_per_step_p90": per_step[int(0.9 * (len(per_step) - 1))],
-        "value_at_median": B * T * world / (median_ms * 1e-3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype,
-        "data": "synthetic" if args.data == "resident" else "synthetic (host batches through the pinned pipeline inside the timed region)",
-        "config": {"workload": f"{c['name']}, T={T}, pitch={P}, latent={c['Z']}, batch={B}/GPU, {dtype}; encoder 256x2x8h, decoder "
-                               f"128x1x8h (scripts/train-vae.sh), dropout {args.dropout}; Xavier-initialised weights",
-                   "baseline_config_index": args.config if world == 1 or args.config != 1 else 3,
-                   "global_batch": B * world, "seq_len": T, "pitches": P, "latent": c["Z"], "parallelism": f"dp{world}",
-                   "params": store.n_params},
-        "step_tflops": step_flops / (ms * 1e-3) / 1e12,
-        "step_mfma_frac": step_flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
-        "executed_flops_per_step": exec_flops, "algorithmic_flops_per_step": step_flops,
-        "executed_tflops": exec_flops / (ms * 1e-3) / 1e12,
+    with final_lock:
+        if final_done[0]:
+            return 0
+        final_done[0] = True
+    nonfinite = int(m.get("nonfinite_steps", 0))
+    out = bench_line(best, {
         "elbo": m["total_loss"], "kl": m["kl_loss"],
-        # steps of the timed run + warm-up whose loss was not finite: the optimizer left the model alone in them (mst_step_metrics'
-        # non-finite guard; seen in long free-running fp16 runs at T = 1024, never in the default run)
-        "nonfinite_steps": m.get("nonfinite_steps", 0),
+        # steps (timed runs + warm-up) whose loss was not finite: the optimizer left the model alone in them (mst_step_metrics'
+        # non-finite guard; seen in long free-running fp16 runs at T = 1024, never in the default run). They are not work done:
+        # a run that has any reports value = null.
+        "nonfinite_steps": nonfinite,
         # what precision meets what tolerance against the CPU oracle on identical weights / inputs / eps, dropout 0
         # (tests/test_configs_gpu.py, tests/test_step_gpu.py; DESIGN.md §4): KL = 0.5 sum(sigma^2 + mu^2 - 1 - log sigma^2) has
         # no epsilon and sigma straddles 0 at Xavier init, where a handful of |sigma| < 1e-2 elements carry the error
         "elbo_tolerance": {"bf16_raw_init": 4e-3, "fp16_raw_init": 1e-3, "bf16_conditioned": 1e-3, "fp16_conditioned": 1e-3,
                            "reconstruction_loss_any": 1e-3, "this_run": dtype + "_raw_init"},
         "roofline": roof,
-    }
+    })
+    if nonfinite:
+        out["invalid"] = f"{nonfinite} steps were skipped by the non-finite guard: the timed region did less work than {args.steps} steps"
+        out["value_if_all_steps_counted"], out["value"] = out["value"], None
     if rccl is not None:
         out["rccl"] = rccl
-    if host_pipeline is not None:
-        out["host_pipeline"] = host_pipeline
+    if best["host_pipeline"] is not None:
+        out["host_pipeline"] = best["host_pipeline"]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(c, args.dropout)
     print(json.dumps(out), flush=True)
-    return 0
+    leave()
+    return 1 if nonfinite else 0
 
 
 if __name__ == "__main__":

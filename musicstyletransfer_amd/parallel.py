@@ -64,14 +64,23 @@ _PROTOS = {"0": "LL", "1": "LL128", "2": "Simple", "SIMPLE": "Simple"}
 
 
 def rccl_debug_env(rank):
-    """Ask RCCL (before its first communicator exists) to log its set-up and tuning decisions to a file of this
-    process. MST_RCCL_DEBUG=0 leaves the environment alone; an NCCL_DEBUG the caller exported wins."""
-    if os.environ.get("MST_RCCL_DEBUG", "1") == "0" or "NCCL_DEBUG" in os.environ:
+    """OPT-IN (MST_RCCL_DEBUG=1; bench.py sets it for its own runs, a training run leaves RCCL's environment alone): ask
+    RCCL, before its first communicator exists, to log its SET-UP (subsystems INIT and ENV: version, channels, transports
+    per channel, the NCCL_* variables it read) to a file of this process. Nothing is logged per collective, so nothing
+    lands inside a timed loop or grows with the run. MST_RCCL_DEBUG=tuning adds the TUNING subsystem (one line per
+    all-reduce with the algorithm / protocol chosen: for a short diagnostic run, not for timing). An NCCL_DEBUG the
+    caller exported wins. The log directory is MST_RCCL_LOG_DIR or a fresh temporary one, which rccl_report(cleanup=True)
+    removes again."""
+    mode = os.environ.get("MST_RCCL_DEBUG", "0")
+    if mode in ("0", "") or "NCCL_DEBUG" in os.environ:
         return None
-    d = os.environ.get("MST_RCCL_LOG_DIR") or tempfile.mkdtemp(prefix="mst_rccl_")
+    d = os.environ.get("MST_RCCL_LOG_DIR")
+    if not d:
+        d = tempfile.mkdtemp(prefix="mst_rccl_")
+        os.environ["MST_RCCL_LOG_TMP"] = d  # ours to remove
     os.makedirs(d, exist_ok=True)
     os.environ["NCCL_DEBUG"] = "INFO"
-    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING,ENV"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,ENV,TUNING" if mode == "tuning" else "INIT,ENV"
     os.environ["NCCL_DEBUG_FILE"] = os.path.join(d, f"rank{rank}.%p.log")
     os.environ["MST_RCCL_LOG_DIR"] = d
     return d
@@ -106,16 +115,28 @@ def parse_rccl_log(text):
     return out
 
 
-def rccl_report():
-    """parse this process's RCCL log(s) (rccl_debug_env); {} when logging is off or nothing was written"""
+def rccl_report(cleanup=False):
+    """parse this process's RCCL log(s) (rccl_debug_env); {} when logging is off or nothing was written. cleanup: remove
+    this rank's log files, and the directory if rccl_debug_env created it and it is empty."""
     d = os.environ.get("MST_RCCL_LOG_DIR")
     if not d:
         return {}
     text = ""
-    for f in sorted(glob.glob(os.path.join(d, f"rank{os.environ.get('RANK', '0')}.*log*"))):
+    files = sorted(glob.glob(os.path.join(d, f"rank{os.environ.get('RANK', '0')}.*log*")))
+    for f in files:
         try:
             with open(f, errors="replace") as fh:
                 text += fh.read()
+        except OSError:
+            pass
+    if cleanup and os.environ.get("MST_RCCL_LOG_TMP") == d:
+        for f in files:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)  # (the last rank to leave removes it; fails harmlessly while other ranks' files are there)
         except OSError:
             pass
     return parse_rccl_log(text) if text else {}
@@ -124,8 +145,6 @@ def rccl_report():
 def _time_allreduce(dist, group, tensors, iters, sync):
     """average microseconds of one round of SUM all-reduces over `tensors` on `group`, wall clock around `iters` rounds
     bracketed by sync() (a device synchronize for nccl), MAX over ranks so that every rank sees the same number"""
-    for t in tensors:  # warm-up: lazy communicator creation, first-call set-up
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     sync()
     dist.barrier(group=group)
     sync()
@@ -139,41 +158,45 @@ def _time_allreduce(dist, group, tensors, iters, sync):
     return float(us.item())
 
 
-def autotune_allreduce(dist, range_numels, device, candidates=None, iters=20):
-    """Measure, on this job's own ranks and links, the all-reduce of the step's gradient ranges under each candidate RCCL
-    algorithm and return (group, report): the process group whose communicator was created under the fastest setting
-    (None = the default group) and {'candidates': {name: microseconds per step's worth of all-reduces}, 'chosen': name}.
+def autotune_allreduce(dist, range_numels, device, candidates=None, iters=10, rounds=5, margin=0.07):
+    """OPT-IN (MST_RCCL_AUTOTUNE=1, or MST_RCCL_ALGO=<name> to pin without measuring; off by default until it has been
+    measured once on an 8-GPU node). Measure, on this job's own ranks and links, the all-reduce of the step's gradient
+    ranges under each candidate RCCL algorithm and return (group, report): the process group whose communicator was
+    created under the chosen setting (None = the default group) and {'candidates': {name: median microseconds per
+    step's worth of all-reduces}, 'samples': {...}, 'chosen': name}.
 
     RCCL reads NCCL_ALGO when a communicator is created, so each candidate is a dist.new_group() made under that
-    environment value; "default" leaves the choice to RCCL's tuner. xGMI on an MI355X node is a full mesh (7 links per
-    GPU): RCCL's ring set spreads its channels over all links, its tree is a depth-1..3 reduction + broadcast — which of
-    them wins for a 3-4 MB latency-dominated range is a property of the node, hence measured, not assumed.
-    Every rank runs the same sequence and the timings are MAX-reduced, so all ranks choose alike. MST_RCCL_ALGO=<name>
-    pins the choice (no measurement); MST_RCCL_AUTOTUNE=0 keeps the default group."""
+    environment value; "default" leaves the choice to RCCL's tuner (per message size). The candidates are timed in
+    INTERLEAVED rounds (default, Tree, Ring, default, ...) after a warm-up of each, and compared by their MEDIANS: one
+    sequential pass per candidate measured order and warm-up instead (profiles/r03_dp2_rehearsal_gloo_v2.json: 5240 / 3619 /
+    3502 us for three functionally identical gloo groups). The default communicator is kept unless a candidate beats it
+    by `margin` (7 %): a pinned algorithm overrides the tuner for every message size, so it has to earn that. Every rank
+    runs the same sequence and every timing is MAX-reduced, so all ranks choose alike."""
     backend = dist.get_backend()
     sync = torch.cuda.synchronize if backend == "nccl" else (lambda: None)
     pinned = os.environ.get("MST_RCCL_ALGO")
     if candidates is None:
         candidates = [pinned] if pinned else ["default", "Tree", "Ring"]
-    report = {"candidates": {}, "chosen": "default", "range_bytes": [4 * n for n in range_numels]}
-    if os.environ.get("MST_RCCL_AUTOTUNE", "1") == "0" and not pinned:
+    report = {"candidates": {}, "chosen": "default", "range_bytes": [4 * n for n in range_numels], "margin": margin}
+    if os.environ.get("MST_RCCL_AUTOTUNE", "0") != "1" and not pinned:
+        report["skipped"] = "MST_RCCL_AUTOTUNE is not 1"
         return None, report
     bufs = [torch.zeros(n, dtype=torch.float32, device=device) for n in range_numels if n > 0]
-    groups = {}
+    groups, usable = {}, []
     saved = os.environ.get("NCCL_ALGO")
     try:
         for name in candidates:
-            if name == "default":
-                os.environ.pop("NCCL_ALGO", None)
-                groups[name] = None if saved is None else dist.new_group()
-            else:
-                os.environ["NCCL_ALGO"] = name
-                groups[name] = dist.new_group()
-            if pinned:
-                report["candidates"][name] = None
-                continue
             try:
-                report["candidates"][name] = _time_allreduce(dist, groups[name], bufs, iters, sync)
+                if name == "default":
+                    os.environ.pop("NCCL_ALGO", None)
+                    groups[name] = None if saved is None else dist.new_group()
+                else:
+                    os.environ["NCCL_ALGO"] = name
+                    groups[name] = dist.new_group()
+                for t in bufs:  # warm-up: lazy communicator creation, first-call set-up
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=groups[name])
+                sync()
+                usable.append(name)
             except RuntimeError as e:  # an algorithm this RCCL build refuses for all-reduce: drop the candidate, on every rank alike
                 report["candidates"][name] = None
                 report.setdefault("errors", {})[name] = str(e).splitlines()[0][:200]
@@ -182,11 +205,27 @@ def autotune_allreduce(dist, range_numels, device, candidates=None, iters=20):
             os.environ.pop("NCCL_ALGO", None)
         else:
             os.environ["NCCL_ALGO"] = saved
-    timed = {k: v for k, v in report["candidates"].items() if v is not None}
     if pinned:
-        report["chosen"] = pinned
-    elif timed:
-        report["chosen"] = min(timed, key=timed.get)
+        report["candidates"][pinned] = None
+        report["chosen"] = pinned if pinned in usable else "default"
+        return groups.get(report["chosen"]), report
+    samples = {name: [] for name in usable}
+    for _ in range(rounds):
+        for name in usable:
+            samples[name].append(_time_allreduce(dist, groups[name], bufs, iters, sync))
+    report["samples"] = samples
+    for name, v in samples.items():
+        report["candidates"][name] = sorted(v)[len(v) // 2]
+    timed = {k: v for k, v in report["candidates"].items() if v is not None}
+    if timed:
+        fastest = min(timed, key=timed.get)
+        ref = timed.get("default")
+        if ref is None or (fastest != "default" and timed[fastest] <= (1.0 - margin) * ref):
+            report["chosen"] = fastest
+        else:
+            report["chosen"] = "default"
+            if fastest != "default":
+                report["kept_default"] = f"{fastest} was faster by less than the margin ({timed[fastest]:.1f} vs {ref:.1f} us)"
     return groups.get(report["chosen"]), report
 
 

@@ -84,7 +84,10 @@ def _tune_worker(rank, world, port, q):
     torch.set_num_threads(1)
     from musicstyletransfer_amd import parallel
     dist = parallel.init_process_group(world, rank, backend="gloo")
-    group, rep = parallel.autotune_allreduce(dist, [1000, 600], torch.device("cpu"), iters=3)
+    _, off = parallel.autotune_allreduce(dist, [1000, 600], torch.device("cpu"), iters=3)  # opt-in: nothing is measured by default
+    assert off["chosen"] == "default" and off["candidates"] == {} and "skipped" in off
+    os.environ["MST_RCCL_AUTOTUNE"] = "1"
+    group, rep = parallel.autotune_allreduce(dist, [1000, 600], torch.device("cpu"), iters=3, rounds=3)
     flat = torch.full((1600,), float(rank + 1))
     red = parallel.GradReducer(dist, group)
     red.finish([red.start(flat[600:]), red.start(flat[:600])])
@@ -113,5 +116,71 @@ def test_autotune_picks_one_group_on_every_rank_and_the_reducer_uses_it():
     assert rep0["chosen"] == rep1["chosen"] and rep0["candidates"] == rep1["candidates"]  # MAX-reduced timings: same choice everywhere
     assert set(rep0["candidates"]) == {"default", "Tree", "Ring"} and all(v > 0 for v in rep0["candidates"].values())
     assert rep0["range_bytes"] == [4000, 2400]
+    assert all(len(v) == 3 for v in rep0["samples"].values())  # interleaved rounds, compared by their medians
+    if rep0["chosen"] != "default":  # the default communicator is kept unless a candidate beats it by the margin
+        assert rep0["candidates"][rep0["chosen"]] <= (1 - rep0["margin"]) * rep0["candidates"]["default"]
     assert pin0["chosen"] == "Tree" and pin0["candidates"] == {"Tree": None} and g0 and g1
     assert env0 is None and env1 is None  # the caller's NCCL_ALGO is restored
+
+
+# ---------------------------------------------------------------------------------- the N > 1 bench line cannot come back empty
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_a_raising_candidate_leaves_the_baseline_number_intact_and_ends_the_experiments():
+    b = _bench()
+    base = {"ms_per_step": 1.0, "tag": "baseline"}
+    ran = []
+
+    def boom():
+        ran.append("boom")
+        raise RuntimeError("NCCL error: unhandled system error\nsecond line")
+
+    def never():
+        ran.append("never")
+        return {"ms_per_step": 0.1}
+    name, res, rep = b.run_candidates("plain", base, [("overlap", boom), ("tuned", never)], budget_s=100.0)
+    assert (name, res) == ("plain", base) and ran == ["boom"]  # after a failed collective nothing else is tried
+    assert rep["chosen"] == "plain" and rep["baseline_ms"] == 1.0 and rep["candidates"] == {"overlap": None}
+    assert rep["errors"]["overlap"].startswith("RuntimeError: NCCL error") and rep["not_run"] == ["tuned"]
+
+
+def test_candidates_replace_the_baseline_only_when_faster_and_within_the_budget():
+    b = _bench()
+    base = {"ms_per_step": 1.0}
+    clock = iter([0.0, 1.0, 2.0, 50.0, 51.0, 52.0]).__next__
+    seen = []
+    cands = [("slower", lambda: {"ms_per_step": 1.2}), ("faster", lambda: {"ms_per_step": 0.8}),
+             ("rejected", lambda: (_ for _ in ()).throw(b.CandidateRejected("warm-up 9 ms > 3 ms"))),
+             ("too late", lambda: {"ms_per_step": 0.1})]
+    name, res, rep = b.run_candidates("plain", base, cands, budget_s=10.0, clock=clock, on_best=lambda n, r: seen.append(n))
+    assert name == "faster" and res["ms_per_step"] == 0.8 and seen == ["faster"]
+    assert rep["candidates"] == {"slower": 1.2, "faster": 0.8}
+    assert rep["not_run"] == ["rejected", "too late"] and rep["chosen"] == "faster"
+    # a rejection (decided alike on every rank) does not end the experiments
+    name, res, rep = b.run_candidates("plain", base, cands[2:], budget_s=1e9)
+    assert name == "too late" and rep["errors"]["rejected"].startswith("rejected:") and rep["candidates"]["rejected"] is None
+
+
+def test_rccl_logging_is_opt_in_and_cleans_up(tmp_path, monkeypatch):
+    from musicstyletransfer_amd import parallel as P
+    for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE", "MST_RCCL_LOG_DIR", "MST_RCCL_LOG_TMP", "MST_RCCL_DEBUG"):
+        monkeypatch.delenv(k, raising=False)
+    assert P.rccl_debug_env(0) is None and "NCCL_DEBUG" not in os.environ  # a training run leaves RCCL's environment alone
+    monkeypatch.setenv("MST_RCCL_DEBUG", "1")
+    monkeypatch.setenv("RANK", "0")
+    d = P.rccl_debug_env(0)
+    try:
+        assert os.environ["NCCL_DEBUG_SUBSYS"] == "INIT,ENV"  # nothing per collective: no TUNING lines inside a timed loop
+        with open(os.path.join(d, "rank0.123.log"), "w") as fh:
+            fh.write("NCCL INFO NCCL version 2.22.3+hip7.0\n")
+        assert P.rccl_report(cleanup=True)["version"].startswith("2.22")
+        assert not os.path.exists(d)
+    finally:
+        for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE", "MST_RCCL_LOG_DIR", "MST_RCCL_LOG_TMP"):
+            os.environ.pop(k, None)
