@@ -402,9 +402,11 @@ def run_decode(args):
         t0 = time.perf_counter()
         reps = 0
         n_pos = 0
+        n_tok = 0
         while reps < 3 or n_pos < positions:
             smp.sample(batch)
             n_pos += smp.positions_decoded
+            n_tok += smp.tokens_decoded  # live continuations only (the device's `active` counters), not B * K per position
             reps += 1
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -419,7 +421,7 @@ def run_decode(args):
             e1.record()
             e1.sync()
             dev_us = e0.elapsed_ms(e1) * 1e3 / max(len(ts), 1)
-    tok_s = B * K * n_pos / elapsed
+    tok_s = n_tok / elapsed
     out = {"metric": "decoded tokens/s (beam search, KV-cache decode step)", "value": tok_s, "unit": "tokens/s", "n_gpus": 1,
            "steps": n_pos, "warmup": warm, "ms_per_step": elapsed / n_pos * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -427,7 +429,9 @@ def run_decode(args):
                                   f"input length {T + 1}, up to {2 * (T + 1)} positions, token ends V={NUM_EVENTS}, decoder 128x1x8h, latent {Z}; "
                                   "a step = one position of all hypotheses = ONE captured graph: decode step, ranking (mst_beam_step) and cache gather "
                                   "(mst_beam_gather) on the device; the host launches graphs and polls a device counter every 8 positions",
-                      "hypotheses": B * K, "beam": K, "positions_per_sequence": smp.positions_decoded},
+                      "hypotheses": B * K, "beam": K, "positions_per_sequence": smp.positions_decoded,
+                      "tokens_counted": "live continuations per position (device counters); PAD continuations of finished hypotheses excluded"},
+           "hypothesis_positions_per_s": B * K * n_pos / elapsed,
            "device_us_per_position": dev_us, "host_share": 1.0 - dev_us * 1e-6 * n_pos / elapsed,
            "graphs_captured": len(bs._graphs), "ranking": "device" if smp.on_device else "host"}
     print(json.dumps(out), flush=True)

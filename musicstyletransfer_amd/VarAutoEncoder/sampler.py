@@ -140,6 +140,7 @@ class BeamSearchSampler(SamplerBase):
             bs = self.model.beam_search_plan(B, K, i_max, self.attention)
             seqs, scores = bs.run(dec.initial_rows(tokens, seq_lens, classes, beam=K))
             self.positions_decoded = bs.positions
+            self.tokens_decoded = bs.tokens_decoded
             self.scores = scores.astype(np.float64).reshape(B, K)
             self.hypotheses = seqs.astype(np.int64).reshape(B, K, -1)
             return self.hypotheses[:, 0]
@@ -167,6 +168,7 @@ class BeamSearchSampler(SamplerBase):
             if ((seqs[:, i] == EOS_ID) | (seqs[:, i] == PAD_ID)).all():
                 break
         self.positions_decoded = i  # (bench.py --decode)
+        self.tokens_decoded = int(((seqs[:, 1:i + 1] != PAD_ID)).sum())
         self.scores = scores.reshape(B, K)
         self.hypotheses = seqs.reshape(B, K, -1)
         return self.hypotheses[:, 0]  # best hypothesis of every sample

@@ -127,6 +127,15 @@ class Trainer:
             plan._trainer_set = True
         return plan
 
+    GUARD_POLL_STEPS = 4  # steps between two non-blocking looks at the step guard's status words
+
+    def _poll_guard(self):
+        """ParamStore.poll_status every few steps: a failed one-launch tail switches the run to the five-launch form within
+        2 x GUARD_POLL_STEPS steps instead of at the next periodic log (each step in between is a skipped batch). Data
+        parallel: the words are summed over the ranks first (one 8-byte all-reduce per poll), and every rank stops."""
+        with torch.cuda.stream(self.stream):
+            self.model.store.poll_status(reduce=(lambda t: self.dist.all_reduce(t)) if self.dist is not None else None)
+
     def _on_tail_failure(self):
         self._graphs.clear()
         self._tail_gen += 1
@@ -196,6 +205,8 @@ class Trainer:
                 batch = staged.batch
                 self._step(batch, staged=staged)
                 self.train_state.n_batches += 1
+                if self.train_state.n_batches % self.GUARD_POLL_STEPS == 0:
+                    self._poll_guard()
                 if self.train_state.n_batches % 50 == 0:
                     self._periodic_log(epoch, start_time)
                 if self.config.checkpoint_frequency > 0 and self.train_state.n_batches % self.config.checkpoint_frequency == 0:

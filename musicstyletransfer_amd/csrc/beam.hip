@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs q) {
   auto score = [&](int c) {
     const int k = c / V, w = c - k * V;
     if (s_fin[k]) return (w == q.pad) ? s_score[k] : INFINITY;
-    return s_score[k] - logf(fmaxf(q.probs[(b * K + k) * q.ldp + w], 1e-30f));
+    const float v = s_score[k] - logf(fmaxf(q.probs[(b * K + k) * q.ldp + w], 1e-30f));
+    return v == v ? v : INFINITY;  // a NaN (from a NaN score or probability) never wins and never leaves the selection without a winner
   };
   if (in_regs) {
 #pragma unroll
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs q) {
       float bv = r_val[0]; int bi = r_idx[0];
       for (int wv = 1; wv < 4; ++wv)
         if (r_val[wv] < bv || (r_val[wv] == bv && r_idx[wv] < bi)) { bv = r_val[wv]; bi = r_idx[wv]; }
-      s_val[r] = bv; s_idx[r] = bi;
+      // (with NaN mapped to +inf above some candidate always wins, ties included; the clamp keeps the index arithmetic below
+      // inside seqs / hyp_src whatever happens)
+      s_val[r] = bv; s_idx[r] = ((unsigned)bi < (unsigned)n_cand) ? bi : 0;
     }
     __syncthreads();
     if (in_regs) {  // the winner leaves its owner's registers

@@ -50,10 +50,15 @@ __device__ __forceinline__ void grid_sync(uint32_t* ctr, uint32_t target, uint32
     uint32_t spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > MST_TAIL_SPIN_TICKS) {
-        // never in a correct launch; a bound instead of a hung GPU — and a flag instead of a silently wrong step
-        if (status) __hip_atomic_fetch_or(status, spin_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+      if ((++spins & 255u) == 0u) {  // (a healthy barrier waits microseconds and never gets here)
+        // a run that is ALREADY flagged (this launch's earlier barrier, or a step before it that the host has not looked at
+        // yet) does not sit out the bound again at every barrier of every following step: its result is discarded anyway
+        if (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > MST_TAIL_SPIN_TICKS) {
+          // never in a correct launch; a bound instead of a hung GPU — and a flag instead of a silently wrong step
+          if (status) __hip_atomic_fetch_or(status, spin_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
     }
   }

@@ -257,10 +257,17 @@ class BeamSearch:
                 if i % check_every == 0 and int(self.active[i].item()) == 0:
                     break                            # every hypothesis has ended (sampler.py: the loop's exit test)
             res = (last + 1) & 1
-            seqs = self.seqs[res][:, : last + 1].cpu().numpy()
+            got = self.seqs[res][:, : last + 1].cpu().numpy()
             scores = self.scores[res].cpu().numpy()
+            live = self.active[: last + 1].cpu().numpy()
         p._leave()
+        # rows of width i_max like the host loop's (sampler.py:203): PAD behind the last decoded position
+        seqs = np.full((got.shape[0], self.i_max), self.pad, got.dtype)
+        seqs[:, : last + 1] = got
         self.positions = last
+        # live continuations chosen per position (mst_beam_step's `active` counters): what was DECODED — a finished hypothesis's PAD
+        # continuations and the up to check_every - 1 positions run after the last one ended are not tokens
+        self.tokens_decoded = int(live[1:].sum())
         return seqs, scores
 
 

@@ -260,6 +260,43 @@ class ParamStore:
         for cb in self._tail_listeners:
             cb()
 
+    def poll_status(self, reduce=None):
+        """Cheap, NON-BLOCKING look at the step guard's sticky words, for the training loop to call every few steps (the
+        words are otherwise read only with the metrics — at the periodic log — and after one failed tail every following
+        step is a skipped batch until then). Two halves per call, no synchronisation in either: (1) if the copy the previous
+        call started has arrived (event query), look at it: a set flag goes to handle_step_status() — fall back to the
+        five-launch form at once, or raise; (2) start the next asynchronous copy of the words into page-locked memory
+        behind everything launched so far on the current stream. reduce(tensor): data parallel — an in-place SUM over the
+        ranks applied to a float copy of the words first, so that every rank sees a failure of ANY rank at the same poll
+        and all of them stop together (handle_step_status raises there: a skipped update on one rank lets the replicas drift).
+        Returns True when a failure was handled."""
+        if getattr(self, "_poll_host", None) is None:
+            self._poll_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._poll_dev = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._poll_event = torch.cuda.Event()
+            self._poll_pending = False
+        handled = False
+        if self._poll_pending and self._poll_event.query():
+            self._poll_pending = False
+            flags, skipped = (int(v) for v in self._poll_host.tolist())
+            if flags or skipped:
+                if reduce is not None:  # (summed over the ranks: only "non-zero" means anything)
+                    self.tail_fused = False
+                    raise RuntimeError(f"a one-launch position-0 tail failed on at least one rank (status words summed over the ranks: "
+                                       f"{flags}, {skipped} skipped step(s)); the replicas are no longer identical — restart from the "
+                                       "last checkpoint with MST_ROW_TAIL=0")
+                cur = self.step_status[:2].tolist()  # (one small blocking read, on the failure path only: the words as they are NOW)
+                self.handle_step_status(cur[0] or flags, cur[1] or skipped)
+                handled = True
+        if not self._poll_pending:
+            self._poll_dev.copy_(self.step_status[:2])
+            if reduce is not None:
+                reduce(self._poll_dev)
+            self._poll_host.copy_(self._poll_dev, non_blocking=True)
+            self._poll_event.record()
+            self._poll_pending = True
+        return handled
+
     def read_metrics(self, reset=True):
         """one device->host read of the running sums: {'kl_sum', 'total_sum', 'count'} and, for the token ends,
         {'nll_sum', 'acc_hits', 'topk_hits', 'n_tokens'} (the caller orders this after the steps it wants included).

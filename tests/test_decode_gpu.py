@@ -136,6 +136,8 @@ def test_samplers_on_the_toy_model(gpu, tmp_path):
         for smp_k in (dev_s, host_s):
             smp_k.update_parameters(t.model)
             smp_k.sample(batch)
+        assert dev_s.hypotheses.shape == host_s.hypotheses.shape  # both of width i_max (the device path returned last + 1 columns)
+        assert 0 < dev_s.tokens_decoded <= dev_s.hypotheses.shape[0] * K * dev_s.positions_decoded
         n = min(dev_s.hypotheses.shape[2], host_s.hypotheses.shape[2])
         np.testing.assert_allclose(dev_s.scores, host_s.scores, rtol=2e-4, atol=2e-4)
         assert np.array_equal(dev_s.hypotheses[:, :, :n], host_s.hypotheses[:, :, :n]), K

@@ -591,6 +591,38 @@ def test_a_failed_position0_tail_is_flagged_skipped_and_replaced_by_the_five_lau
     assert int(store.step_state[0].item()) == 3 and m2["count"] == 2 * B and m2["skipped_steps"] == 0
     assert abs(m["total_sum"] + m2["total_sum"] - ref_m["total_sum"]) <= 1e-4 * abs(ref_m["total_sum"])
     _close_after_adam(store.w.cpu().numpy(), ref_store.w.cpu().numpy(), lr, 3)
+    # ParamStore.poll_status(): the non-blocking look the training loop takes every few steps (the words were
+    # read only with the metrics, so one failed tail meant skipped batches until the next periodic log)
+    store.tail_fused = True
+    fired.clear()
+    assert store.poll_status() is False          # starts an asynchronous copy of clean words
+    torch.cuda.synchronize()
+    assert store.poll_status() is False and fired == []
+    torch.cuda.synchronize()
+    store.step_status[0:1].fill_(2)              # a backward-tail barrier time-out, as the kernel leaves it
+    store.step_status[1:2].fill_(3)
+    store.poll_status()                          # (the copy in flight is older than the flag or not: at most one more poll)
+    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        handled = store.poll_status()
+        if not handled:
+            torch.cuda.synchronize()
+            handled = store.poll_status()
+    assert handled and fired == [1] and not store.tail_fused and store.tail_failures[-1] == (2, 3)
+    assert store.step_status.tolist()[:2] == [0, 0]
+    torch.cuda.synchronize()
+    assert store.poll_status() is False          # handled once
+    # data parallel: the words are summed over the ranks first and every rank stops
+    torch.cuda.synchronize()
+    store.poll_status(reduce=lambda t: t.mul_(2))
+    store.step_status[0:1].fill_(1)
+    torch.cuda.synchronize()
+    store.poll_status(reduce=lambda t: t.mul_(2))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="at least one rank"):
+        store.poll_status(reduce=lambda t: t.mul_(2))
+    store.step_status[0:2].fill_(0)
     # MST_TAIL_FAILURE=raise: the same flag stops the run instead
     store.tail_policy, store.tail_fused = "raise", True
     store.step_status[0:1].fill_(1)
