@@ -180,19 +180,49 @@ def kernel_families(plan, o, iters=30):
                                     resid=t.dh, partials=plan._ln_part[f"{pre}.ln1"]),
             flops=2.0 * 2.0 * M * 4 * De * De, bytes=2.0 * (M * De + 8 * De * De + 2 * M * 4 * De + 3 * M * De),
             launches_per_step=full_e, pmc_key="ffn_ln_kernel<%d,2,4,2,@%d" % (De, ((M + 63) // 64) * 512)))
-    # the K | Q | V projection runs inside the attention forward launch (mst_attn_qkv_fwd): x and the weights in, qkv (kept for the
-    # backward pass) and the attention output out
-    fams.append(dict(
-        kernel=f"attention fwd with the K,Q,V projection inside [B*H={B * H}, S={T}, dh={De // H}, D={De}]",
-        fn=lambda: o.attn_qkv_fwd(plan.x0_e, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, plan.keymask_e, L.lse, L.att,
-                                  B, T, H, De // H, 0, De, 2 * De),
-        flops=4.0 * B * T * T * De + 2.0 * M * 3 * De * De, bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + M * De),
-        launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
-    fams.append(dict(
-        kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
-        fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),
-        flops=2.0 * 4 * B * T * T * De, bytes=2.0 * M * (3 * De + De + 3 * De), launches_per_step=full_e,
-        pmc_key="attn_bwd_res_kernel<%d,0>@%d" % (De // H, B * H * 512)))
+    # ---- attention: all six launches of the step (VERDICT r03 #4c: the family owns ~29 % of the kernel time)
+    # encoder layers below the top one: the K | Q | V projection runs inside the forward launch (mst_attn_qkv_fwd): x and the weights
+    # in, qkv (kept for the backward pass) and the attention output out
+    Hd, Sd, Md = cfg.d_heads, T + 1, plan.Md
+    qkv_flops = lambda M_, D_: 2.0 * M_ * 3 * D_ * D_
+    if full_e:
+        fams.append(dict(
+            kernel=f"attention fwd with the K,Q,V projection inside [B*H={B * H}, S={T}, dh={De // H}, D={De}]",
+            fn=lambda: o.attn_qkv_fwd(plan.x0_e, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, plan.keymask_e, L.lse, L.att,
+                                      B, T, H, De // H, 0, De, 2 * De),
+            flops=4.0 * B * T * T * De + qkv_flops(M, De), bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + M * De),
+            launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+        fams.append(dict(
+            kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
+            fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),
+            flops=2.0 * 4 * B * T * T * De, bytes=2.0 * M * (3 * De + De + 3 * De), launches_per_step=full_e,
+            pmc_key="attn_bwd_res_kernel<%d,0>@%d" % (De // H, B * H * 512)))
+    if cfg.e_layers >= 1:
+        # the top encoder layer is read at position 0 only (model.py:97): projection and key-row statistics over every query, the
+        # output for ONE query per sample; backward with dO zero beyond it. Algorithmic work = the reference's dense layer.
+        Lt, tt, pt = plan.enc[-1], plan.be_l[-1], f"encoder.layer{cfg.e_layers - 1}"
+        x_top = plan.enc[-2].x2 if cfg.e_layers > 1 else plan.x0_e
+        fams.append(dict(
+            kernel=f"attention fwd, top encoder layer (projection inside, one query per sample out) [B*H={B * H}, S={T}, dh={De // H}]",
+            fn=lambda: o.attn_qkv_fwd(x_top, st.fused(st.w16, pt, "weight"), st.fused(st.w, pt, "bias"), Lt.qkv, plan.keymask_e, Lt.lse, Lt.att,
+                                      B, T, H, De // H, 0, De, 2 * De, q_limit=1),
+            flops=4.0 * B * T * T * De + qkv_flops(M, De), bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + B * De),
+            launches_per_step=1, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+        fams.append(dict(
+            kernel=f"attention bwd, top encoder layer (dO zero beyond query 0) [B*H={B * H}, S={T}, dh={De // H}]",
+            fn=lambda: o.attn_bwd(Lt.qkv, plan.keymask_e, Lt.lse, plan.sp_datt, tt.dqkv, tt.delta, B, T, H, De // H, 0, De, 2 * De, q_limit=1),
+            flops=2.0 * 4 * B * T * T * De, bytes=2.0 * (M * 3 * De + B * De + M * 3 * De), launches_per_step=1,
+            pmc_key="attn_bwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+    if cfg.d_layers >= 1:
+        Ld, td = plan.dec[0], plan.bd_l[0]
+        fams.append(dict(
+            kernel=f"attention fwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}] (its projection is a GEMM launch)",
+            fn=lambda: o.attn_fwd(Ld.qkv, plan.keymask_d, Ld.lse, Ld.att, B, Sd, Hd, Dd // Hd, 0, Dd, 2 * Dd),
+            flops=4.0 * B * Sd * Sd * Dd, bytes=2.0 * (Md * 3 * Dd + Md * Dd), launches_per_step=cfg.d_layers, pmc_key=None))
+        fams.append(dict(
+            kernel=f"attention bwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}]",
+            fn=lambda: o.attn_bwd(Ld.qkv, plan.keymask_d, Ld.lse, td.datt, td.dqkv, td.delta, B, Sd, Hd, Dd // Hd, 0, Dd, 2 * Dd),
+            flops=2.0 * 4 * B * Sd * Sd * Dd, bytes=2.0 * Md * (3 * Dd + Dd + 3 * Dd), launches_per_step=cfg.d_layers, pmc_key=None))
     wg, ps = plan.last_wgrad_launch
     if wg:
         fl = sum(2.0 * w.M * w.N * w.K for w in wg)
@@ -221,7 +251,11 @@ def roofline(plan, o, config_id):
     try:  # HBM bytes per launch from the committed PMC passes (tools/make_profile_summary.py), not measured here
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             j = json.load(f)
-        if config_id == 1 and best["pmc_key"]:
+        if str(config_id) in j.get("configs", {}):  # (per BASELINE config: tools/profile_round.sh <config>)
+            j = j["configs"][str(config_id)]
+        elif config_id != 1:
+            j = {}
+        if best["pmc_key"] and "bytes_per_launch" in j:
             table, src = j["bytes_per_launch"], j.get("source")
 
             def lookup(key):  # "name<args>@grid"; "@*": whatever the grid; a template list may be a prefix ("kernel<256,2,4,1")
@@ -232,8 +266,11 @@ def roofline(plan, o, config_id):
                 hits = [v for k, v in table.items() if k.rsplit("@", 1)[0].startswith(stem) and (grid == "*" or k.endswith("@" + grid))]
                 return max(hits) if hits else None
 
-            parts = [lookup(k) for k in best["pmc_key"].split("+")]
-            traffic = sum(parts) if all(v is not None for v in parts) else None
+            for alt in best["pmc_key"].split("|"):  # alternatives (the library picks the kernel form by shape): the first one found whole
+                parts = [lookup(k.strip()) for k in alt.split("+")]
+                if all(v is not None for v in parts):
+                    traffic = sum(parts)
+                    break
     except (OSError, ValueError, KeyError):
         pass
     hbm = best["bound"] == "hbm"
@@ -244,6 +281,8 @@ def roofline(plan, o, config_id):
             "algorithmic_flops_per_launch": best["algorithmic_flops_per_launch"], "tflops": best["tflops"], "mfma_frac": best["mfma_frac"],
             "intensity_flop_per_byte": best["algorithmic_flops_per_launch"] / best["algorithmic_bytes_per_launch"],
             "ridge_flop_per_byte": ridge,
+            "attention_share_ms": sum(f["share_ms"] for f in fams if f["kernel"].startswith("attention")),
+            "attention_launches_per_step": sum(f["launches_per_step"] for f in fams if f["kernel"].startswith("attention")),
             "families": [{k: v for k, v in f.items() if k != "pmc_key"} for f in sorted(fams, key=lambda f: -f["share_ms"])]}
 
 

@@ -209,17 +209,12 @@ int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgra
                         const mst_ln_args* ln, mst_stream_t stream);
 /* The attention output projection joins the block (MultiHeadDotAttention's W_proj Dense, transformer.py:65-68,105-106, and the
  * residual LayerNorm behind it, transformer.py:154-156 / 191-193):
- * forward, in FRONT of mst_ffn_ln_fwd —
+ * in FRONT of mst_ffn_ln_fwd —
  *     mst_gemm_nt_ln(proj, ln1) mode 1     h1 = epi(att Wp^T + bp) (+ dropout, + residual), x1 = LayerNorm(h1), mean1, rstd1
- * with x1 (= ln1->out, which must be ff1->A) handed to the block on chip and stored, with h1 and the statistics, for backward;
- * backward, BEHIND mst_ffn_ln_bwd / mst_ffn_ln_bwd_lead (lead may be NULL) —
- *     mst_gemm_nt(proj_dgrad)              datt = d(h1)[masked] Wp          (a plain product: no bias, residual or scale)
- * proj_dgrad->A must be the LayerNorm backward's masked result (ln->out, mask_mode 1) or its plain one (ff1_dgrad->C).
+ * with x1 (= ln1->out, which must be ff1->A) handed to the block on chip and stored, with h1 and the statistics, for backward.
  * The projection is width x width (N = K = the model width) on the same M rows. Same results as the separate launches. */
 int mst_proj_ffn_ln_fwd(const mst_gemm_args* proj, const mst_ln_args* ln1, const mst_gemm_args* ff1, const mst_gemm_args* ff2,
                         const mst_ln_args* ln2, mst_stream_t stream);
-int mst_ffn_ln_bwd_tail(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
-                        const mst_ln_args* ln, const mst_gemm_args* proj_dgrad, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Deferred column sums: dst[0..len) += scale * sum_{p < n_parts} src[p*stride + 0..len), parts added in index order
@@ -409,22 +404,6 @@ int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const float* pos_d, float alpha_d,
                    float* mu, float* sigma, float* z, float* kl,
                    void* dec_in, int64_t dec_sample_stride, mst_stream_t stream);
-
-/* mst_latent_fwd with the decoder's FIRST K | Q | V projection (transformer.py:88-93 applied to model.py:241-245's input) on the
- * same launch: `proj` is that Dense as a GEMM over the B * T rows 1..T of every sample (a_remap = c_remap = (T, T + 1, 1),
- * A = the decoder input, B = the [3 Dd, Dd] 16-bit weight shadow, bias, C = qkv) — rows the embedding GEMM produced at the start
- * of the step, so their projection is independent of the latent block and runs as extra workgroups beside its B workgroups;
- * row 0 of a sample (dec_in[b, 0, :], produced here) is projected by its own latent workgroup (fp32 dot products over the same
- * 16-bit operands). mst_latent_fwd_qkv_ok: 1 for the shapes this form takes (T a multiple of 128, Dd 128 or 256); for the others run mst_latent_fwd and the projection as mst_gemm_nt. */
-int mst_latent_fwd_qkv_ok(int64_t B, int64_t T, int64_t De, int64_t Z, int64_t Dd);
-int mst_latent_fwd_qkv(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
-                       const void* enc_out, int64_t enc_sample_stride,
-                       const float* Wl, const float* bl, const float* eps,
-                       const float* Wh, const float* bh,
-                       const int32_t* classes, const float* cls_d, int64_t ld_cls,
-                       const float* pos_d, float alpha_d,
-                       float* mu, float* sigma, float* z, float* kl,
-                       void* dec_in, int64_t dec_sample_stride, const mst_gemm_args* proj, mst_stream_t stream);
 
 int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const void* enc_out, int64_t enc_sample_stride,

@@ -176,7 +176,6 @@ SIGNATURES = {
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_proj_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
-    "mst_ffn_ln_bwd_tail": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), C.POINTER(GemmArgs), vp]),
     "mst_gemm_nt_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_gemm_nt_ln_parts": (c_i64, [c_i64]),
     "mst_partial_sums": (C.c_int, [C.POINTER(PartialSum), C.c_int, vp]),
@@ -208,9 +207,6 @@ SIGNATURES = {
                                     vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp, vp]),
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
-    "mst_latent_fwd_qkv_ok": (C.c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
-    "mst_latent_fwd_qkv": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
-                                     vp, c_f32, vp, vp, vp, vp, vp, c_i64, C.POINTER(GemmArgs), vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
                                  vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),

@@ -15,7 +15,6 @@
 #include <type_traits>
 #include "common.hpp"
 #include "bce_math.hpp"
-#include "latent_fwd.hpp"
 #include "step_begin.hpp"
 #include "shadows.hpp"
 
@@ -45,60 +44,6 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int frow = lane & 15, fq = lane >> 4;
-  if constexpr (PATH == 3) {
-    // Direct form (interior tiles, 16-bit output, only bias / alpha / ReLU / residual / gate): finished in accumulator
-    // layout — a quad is 4 consecutive columns of one row, so every access is 8 bytes and the four column blocks of a
-    // wave complete 32-byte sectors of the same lines back to back. No LDS round trip and no barrier: a wave leaves as
-    // soon as its own MFMAs are done (the staged form costs a workgroup ~3.5 us of its ~10 us life at K = 256).
-    // Off by default: it measured slower at step level (launch_gemm).
-    const T* resid = reinterpret_cast<const T*>(a.resid);
-    const T* gate = reinterpret_cast<const T*>(a.gate);
-    const int64_t mrow = m0 + wm * WTM + frow;
-    const int ncol = (int)n0 + wn * WTN + fq * 4;
-    u32x2 rv[TN][TM], gv[TN][TM];
-    if (resid) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) rv[j][i] = *reinterpret_cast<const u32x2*>(resid + (mrow + i * 16) * a.ldr + ncol + j * 16);
-    }
-    if (gate) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) gv[j][i] = *reinterpret_cast<const u32x2*>(gate + (mrow + i * 16) * a.ldg + ncol + j * 16);
-    }
-    const bool relu = a.act == MST_ACT_RELU;
-    const float alpha = a.alpha;
-    T* cbase = reinterpret_cast<T*>(a.C) + mrow * a.ldc + ncol;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ncol + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float t[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          t[e] = (acc[j][i][e] + b4[e]) * alpha;
-          if (relu) t[e] = fmaxf(t[e], 0.f);
-        }
-        if (resid) {
-          t[0] += bits_to_f32<T>((uint16_t)(rv[j][i][0] & 0xFFFFu)); t[1] += bits_to_f32<T>((uint16_t)(rv[j][i][0] >> 16));
-          t[2] += bits_to_f32<T>((uint16_t)(rv[j][i][1] & 0xFFFFu)); t[3] += bits_to_f32<T>((uint16_t)(rv[j][i][1] >> 16));
-        }
-        if (gate) {
-          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][0] & 0xFFFFu)) > 0.f)) t[0] = 0.f;
-          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][0] >> 16)) > 0.f)) t[1] = 0.f;
-          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][1] & 0xFFFFu)) > 0.f)) t[2] = 0.f;
-          if (!(bits_to_f32<T>((uint16_t)(gv[j][i][1] >> 16)) > 0.f)) t[3] = 0.f;
-        }
-        *reinterpret_cast<u32x2*>(cbase + (int64_t)i * 16 * a.ldc + j * 16) =
-            u32x2{(uint32_t)f32_to_bits<T>(t[0]) | ((uint32_t)f32_to_bits<T>(t[1]) << 16),
-                  (uint32_t)f32_to_bits<T>(t[2]) | ((uint32_t)f32_to_bits<T>(t[3]) << 16)};
-      }
-    }
-    return;
-  }
   // ------------------------------------------------------------------ epilogue
   // The accumulators go to LDS as fp32 (one wave-row group of the tile per pass) and every thread then finishes
   // 8 consecutive columns of a row at a time: bias / residual / gate / output move as 16-byte, row-contiguous
@@ -791,35 +736,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_ln_kernel(mst_gemm_arg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// mst_latent_fwd_qkv: the latent block's forward launch (B workgroups of dependent dot products — 8 us with 192 CUs idle) also
-// runs the decoder's FIRST K | Q | V projection (transformer.py:88-93 on model.py:241-245's input): rows 1..T of every sample are
-// the embedding GEMM's output, ready since the step's first launch, so their projection is independent of the latent block and
-// rides here as 128 x 128 tiles behind the B latent workgroups (16 waves each, the launch's block size); row 0 of a sample is
-// what the latent workgroup itself produces, and it projects that row too (LatentFwdArgs.Wq). As a launch of its own the
-// projection stood between latent_fwd and the decoder's attention in the dependent chain (12.4 us).
-template <typename T, bool PRE>
-// MEASURED, NOT THE DEFAULT (engine: MST_LATENT_QKV=1 selects it): 18.9 us for the launch against 6.9 + 11.6 us for the two — a
-// 16-wave workgroup is a poor GEMM tile at K = 128 (two stages: the tile is one dependent chain of load, load, epilogue, ~12 us, and a
-// CU holds one or two of them where it overlaps five or six 4-wave workgroups of the 64 x 64 kernel: the tiles alone take 16.9 us),
-// and at the 64 VGPRs that let two such workgroups share a CU the latent role spills 19 registers and takes 14.3 us alone.
-__global__ __launch_bounds__(LAT_THREADS) void latent_qkv_kernel(LatentFwdArgs la, mst_gemm_args g, int n_lat) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if ((int)blockIdx.x < n_lat) {
-    latent_fwd_wg<T, PRE>(la, (int64_t)blockIdx.x, reinterpret_cast<float*>(smem));
-    return;
-  }
-  constexpr int BM = 128, BN = 128, WGM = 2, WGN = 8;  // (the fast epilogue walks NT / 16 = 64 rows per pass: a wave-row block is 64 rows)
-  static_assert(WGM * WGN * 64 == LAT_THREADS, "one block size per launch");
-  f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
-  int64_t m0, n0;
-  float bias_pre[8];
-  const int64_t tile = (int64_t)blockIdx.x - n_lat;
-  gemm_bias_preload<BM, BN>(g, bias_pre, tile);
-  gemm_mainloop<T, BM, BN, WGM, WGN, 64, true, false>(g, smem, acc, m0, n0, tile);
-  gemm_epilogue<T, BM, BN, WGM, WGN, false, true, 1, false>(g, smem, acc, m0, n0, bias_pre);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Output layer + per-pitch BCE in ONE launch (mst_gemm_sigmoid_bce): the decoder's Dense[D -> P] (model.py:253-256) with
 // sigmoid + BinaryCrossEntropy (loss.py:27-80) in its epilogue. A tile is 64 frames x BN pitches (128 or 256: the LDS-staged
 // (time x pitch) tile) — the whole row of pitches at configs[1], one of P / 256 column tiles of it at configs[2]'s 2048 (the
@@ -1014,31 +930,21 @@ static int launch_gemm_bce(const mst_gemm_args& a, const mst_bce_args& q, hipStr
 // weight ring — the launch is bound by a single workgroup's serial latency (35 us for ONE workgroup, 42 for 256), so
 // every such drain is a full L2 round trip on the critical path. Hence also: bias of the first GEMM read from LDS
 // (it was a global load + vmcnt(0) inside the chunk epilogue), prefetches issued unconditionally (clamped).
-// DW ("direct weights", WGM = 1): a wave owns ALL 64 rows and BN / WGN columns of both GEMMs, so every weight fragment has
-// exactly one consumer — the wave loads it from global memory straight into the MFMA operand registers (a ring of RING
-// stages per wave), the weight stages in LDS, their ds_writes and the barrier per stage disappear: the waves free-run
-// between the two barriers of a chunk (hidden chunk produced / double-buffered, so none before it is overwritten), LDS
-// carries only the activation fragments (64 x k x 2 B per wave and k step instead of (32 + 64) x k x 2 plus the stage
-// writes). Same MFMA order per output element as the staged form.
-// Measured (tools/experiments/ab_ffn_dw.sh, width 256 forward, staged form 42.5 us): reading the weights where they lie —
-// 16 rows x 64 B per load instruction — 52.9 us; reading them from a fragment-ordered copy (1 KB contiguous per
-// instruction; timing experiment MST_FFN_DW_FAKE, wrong numbers) 37.7 us with a 4-stage ring, 59 us with 8 stages (spills),
-// 43 us with 16 waves of 16 columns. Not enabled (MST_FFN_DW=1 selects it): the 5 us need a third weight shadow layout.
 // EXTRA: one more width x width GEMM on the workgroup's rows in the same launch (gx; its weights are extra stages of the
 // same stream). Forward (mst_proj_ffn_ln_fwd): the attention output projection + residual + LayerNorm in FRONT — the input
 // tile is the attention output, the block's input x1 = LayerNorm(h1) is computed by mst_gemm_nt_ln's forward epilogue
-// (gx, lnx) into the x tile (and stored, with h1 and the statistics, for the backward pass). Backward (mst_ffn_ln_bwd_tail):
-// the projection's dgrad BEHIND the LayerNorm-1 backward — its (masked) result tile is the extra GEMM's A operand.
-template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD, bool FULL, bool DW = false, bool EXTRA = false>
+// (gx, lnx) into the x tile (and stored, with h1 and the statistics, for the backward pass). (The mirror image — the projection's
+// dgrad behind the backward block — and a form with every wave loading its own weight fragments straight into MFMA operand
+// registers were built, measured slower / not worth a third shadow layout, and removed: docs/kernel_notes.md.)
+template <typename T, int BN, int WGM, int WGN, int MODE, bool LEAD, bool FULL, bool EXTRA = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1, mst_gemm_args g2, mst_ln_args ln, mst_ln_bwd_in lead,
                                                                 mst_gemm_args gx, mst_ln_args lnx) {
-  constexpr bool HEAD = EXTRA && MODE == 1, TAIL = EXTRA && MODE == 2;
-  static_assert(!(EXTRA && DW), "the extra GEMM rides on the staged weight stream");
+  constexpr bool HEAD = EXTRA;
+  static_assert(!EXTRA || MODE == 1, "the extra GEMM is the forward form's head");
   constexpr int BM = 64, BK = 64, CHUNKS = BK / 8;
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
-  static_assert(!DW || WGM == 1, "direct weights: a wave must own every row of its columns");
-  constexpr int B_CH = DW ? TN * (BK / 32) : BN * CHUNKS / NT;  // 16-byte pieces of a weight stage per thread
+  constexpr int B_CH = BN * CHUNKS / NT;  // 16-byte pieces of a weight stage per thread
   constexpr int LDA = BN + 8;                  // row stride (elements) of the two activation tiles: conflict-free b128 reads
   constexpr int KST = BN / BK;                 // K stages of one GEMM of a chunk (K = BN for both)
   static_assert(BN * CHUNKS % NT == 0 && (BM * BN / 8) % NT == 0, "tile/threads mismatch");
@@ -1046,10 +952,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [weight stages 2 x BN x 64][hidden chunk 64 x LDA][x tile 64 x LDA]; the LayerNorm epilogue's fp32 staging tile reuses
   // the first two regions (both dead by then)
-  // (DW: [hidden chunk, two buffers][x tile])
   u32x4* sB = reinterpret_cast<u32x4*>(smem);
-  T* sH = reinterpret_cast<T*>(smem + (DW ? (size_t)0 : (size_t)2 * BN * BK * 2));
-  T* sX = sH + (DW ? 2 : 1) * BM * LDA;
+  T* sH = reinterpret_cast<T*>(smem + (size_t)2 * BN * BK * 2);
+  T* sX = sH + BM * LDA;
   float* sBias1 = reinterpret_cast<float*>(sX + BM * LDA);  // [F] the first GEMM's bias (zeros without one)
   float* sPar = sBias1 + g1.N;   // [2][3 BN]: bias | gamma | beta of the final epilogue, then of the head's (EXTRA forward)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1058,7 +963,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #define MST_XCD_ROWS 1
 #endif
   // (row tiles in XCD-contiguous eighths, like the GEMMs' tiles and the attention workgroups: common.hpp xcd_chunk)
-  const int64_t m0 = (MST_XCD_ROWS ? xcd_chunk(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x) * BM;
+  int64_t m0 = (MST_XCD_ROWS ? xcd_chunk(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x) * BM;
+  // Row groups (g1's A remap, the only remap the block takes): the block's M rows are rows [offset, offset + rows_per_group) of
+  // every group of `stride` physical rows — the last decoder layer skips each sample's position-0 row, whose output is dropped
+  // before the loss (model.py:253): 64 x 256 rows are 256 tiles, one resident round, where 64 x 257 were 257. Groups are whole
+  // tiles (host check), so the tile moves as a block and every row address below is m0 + row as before; the dropout counters and
+  // the LayerNorm statistics stay indexed by the PHYSICAL row.
+  if (g1.a_rows_per_group > 0) {
+    const uint32_t grp = (uint32_t)m0 / (uint32_t)g1.a_rows_per_group;
+    m0 += (int64_t)grp * (g1.a_group_stride - g1.a_rows_per_group) + g1.a_group_offset;
+    // (the epilogues' row guards compare physical rows against M: every row of a whole tile exists)
+    g1.M = g2.M = gx.M = (g1.M / g1.a_rows_per_group) * g1.a_group_stride;
+  }
   const int64_t F = g1.N;
   FFN_STAMP(0); FFN_RT(190);
   const int64_t Mg = FULL ? (int64_t)1 << 62 : g1.M;  // row guards compare against this (FULL: always true, folded away)
@@ -1107,9 +1023,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   int b_lds[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
-    // (DW: piece i = fragment (j, ks) of the wave's own columns, in the MFMA operand's lane order)
     const int c = tid + i * NT;
-    const int row = DW ? wn * WTN + (i / (BK / 32)) * 16 + frow : c / CHUNKS, ch = DW ? (i % (BK / 32)) * 4 + fq : c % CHUNKS;
+    const int row = c / CHUNKS, ch = c % CHUNKS;
     off1[i] = (uint32_t)row * (uint32_t)g1.ldb + (uint32_t)ch * 8u;
     off2[i] = (uint32_t)row * (uint32_t)g2.ldb + (uint32_t)ch * 8u;
     offx[i] = EXTRA ? (uint32_t)row * (uint32_t)gx.ldb + (uint32_t)ch * 8u : 0u;
@@ -1119,22 +1034,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   // 133 KB of LDS) nothing else hides a weight load's ~1.5 us, and a single stage of lookahead (gemm_mainloop's scheme,
   // which relies on 2-5 co-resident workgroups) made every stage as long as that latency: 52 us for the launch.
   constexpr int SPC = 2 * KST;                 // stages per chunk (a multiple of the ring: slots are compile-time)
-#ifndef MST_FFN_DW_RING
-#define MST_FFN_DW_RING 8
-#endif
-  constexpr int RING = DW ? (BN >= 256 ? MST_FFN_DW_RING : 4) : (BN >= 256 ? 4 : 2), AHEAD = RING - 1;
+  constexpr int RING = BN >= 256 ? 4 : 2, AHEAD = RING - 1;
   static_assert(SPC % RING == 0, "ring slots must repeat per chunk");
   u32x4 ring[RING][B_CH];
   auto load_stage = [&](int c, int s, u32x4 (&rb)[B_CH]) {  // (c, s) uniform
-#ifdef MST_FFN_DW_FAKE  /* timing experiment only (wrong numbers): what a fragment-ordered weight copy would cost to read */
-    if constexpr (DW) {
-      const T* base = (s < KST ? W1 : W2) + (int64_t)phys(c) * BN * BN + (int64_t)((kstage(s < KST ? s : s - KST) * WGN + wn) * B_CH) * 512 + lane * 8;
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + i * 512);
-      return;
-    }
-#endif
-    if (EXTRA && (HEAD ? c < 0 : c >= n_chunks)) {  // the extra GEMM's K stage s
+    if (HEAD && c < 0) {  // the extra GEMM's K stage s
       const T* base = WX + kstage(s) * BK;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(base + offx[i]);
@@ -1152,7 +1056,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     constexpr int i = decltype(ic)::value;
     const T* base;
     uint32_t off;
-    if (EXTRA && (HEAD ? c < 0 : c >= n_chunks)) { base = WX + kstage(s) * BK; off = offx[i]; }
+    if (HEAD && c < 0) { base = WX + kstage(s) * BK; off = offx[i]; }
     else if (s < KST) { base = W1 + (int64_t)phys(c) * BN * g1.ldb + kstage(s) * BK; off = off1[i]; }
     else { base = W2 + (int64_t)phys(c) * BN + kstage(s - KST) * BK; off = off2[i]; }
     rb[i] = *reinterpret_cast<const u32x4*>(base + off);
@@ -1242,7 +1146,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     }
     // dgamma / dbeta: the RSTEP row groups summed through LDS (the weight-stage region is not in use yet)
     float* red = reinterpret_cast<float*>(smem);  // [2][RSTEP][BN]
-    static_assert((size_t)2 * RSTEP * BN * 4 <= (DW ? (size_t)2 * BM * LDA * 2 : (size_t)2 * BN * BK * 2), "reduction scratch must fit the weight stages");
+    static_assert((size_t)2 * RSTEP * BN * 4 <= (size_t)2 * BN * BK * 2, "reduction scratch must fit the weight stages");
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[row0 * BN + nc + e] = dg8[e];
@@ -1287,8 +1191,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 16 + frow;
-        if constexpr (DW) wf[j] = __builtin_bit_cast(vec8, rb[j * (BK / 32) + ks]);
-        else wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
+        wf[j] = __builtin_bit_cast(vec8, cB[row * CHUNKS + (kc ^ (row & 7))]);
       }
       auto row = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -1318,7 +1221,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   const bool relu1 = g1.act == MST_ACT_RELU;
   T* Aout = reinterpret_cast<T*>(g1.C);
 
-  // the KST stages of the extra GEMM (stream position `cx`: -1 in front of the chunks, n_chunks behind them) into acc1
+  // the KST stages of the extra GEMM (stream position `cx` = -1: in front of the chunks) into acc1
   auto extra_gemm = [&](int cx) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -1347,13 +1250,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
     gemm_epilogue_ln<T, BM, BN, WGM, WGN, 1>(gx, lnx, smem, acc1, m0, nullptr, 0, sX, LDA, sPar + 3 * BN, &seedx);
     __syncthreads();  // the staging tile (over the weight stages) is dead, the x tile complete
   }
-  if constexpr (!DW) store_stage(0, ring[0]);
+  store_stage(0, ring[0]);
   __syncthreads();  // (also publishes the x tile)
   FFN_STAMP(1);
-  T* const sH0 = sH;
   for (int c = 0; c < n_chunks; ++c) {
     const int pc = phys(c);  // the hidden chunk this iteration computes
-    if constexpr (DW) sH = sH0 + (c & 1) * BM * LDA;  // double-buffered: chunk c - 1's readers may still be in their second GEMM
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1376,12 +1277,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #ifndef MST_FFN_IL
 #define MST_FFN_IL 1
 #endif
-        constexpr bool IL = MST_FFN_IL && BN >= 256 && !DW && !MST_FFN_EARLY_STORE && B_CH <= 2 * TN;  // (width 128, two workgroups per CU: measured 1 us slower)
+        constexpr bool IL = MST_FFN_IL && BN >= 256 && !MST_FFN_EARLY_STORE && B_CH <= 2 * TN;  // (width 128, two workgroups per CU: measured 1 us slower)
         // request stage s + AHEAD of the stream (it may belong to the next chunk)
         constexpr int t = s + AHEAD;
         // (unconditional: past the last chunk the clamped load fetches a stage nobody stores)
-        // (TAIL: past the last chunk come the extra GEMM's stages)
-        const int tc = t < SPC ? c : (TAIL || c + 1 < n_chunks ? c + 1 : c);
+        const int tc = t < SPC ? c : (c + 1 < n_chunks ? c + 1 : c);
         const bool more = s + 1 < SPC || c + 1 < n_chunks;  // a next stage exists: its weights go to the other LDS buffer
         // interleaved form: piece k of { load of stage s + AHEAD, LDS store of stage s + 1 } behind the k-th row of MFMAs
 #ifndef MST_FFN_COPY_IL
@@ -1389,7 +1289,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #endif
         // (experiment) forward: the finished chunk's copy to `a` rides behind the last MFMA rows of the second GEMM's first
         // stage, a 16-byte piece of a row at a time, instead of standing between the barrier and that stage
-        constexpr bool COPY_IL = MST_FFN_COPY_IL && MODE == 1 && !DW && OUT_CH <= 2 * TN;
+        constexpr bool COPY_IL = MST_FFN_COPY_IL && MODE == 1 && OUT_CH <= 2 * TN;
         auto piece = [&](auto kc) {
           constexpr int k = decltype(kc)::value;
           if constexpr (IL && k < B_CH) {
@@ -1445,14 +1345,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
           }
         }
         // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
-        if constexpr (!DW) {
-          if (!IL && !MST_FFN_EARLY_STORE && more) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
-          FFN_STAMP(8 + (c * SPC + s) * 4 + 2);
-          __syncthreads();
-          FFN_STAMP(8 + (c * SPC + s) * 4 + 3);
-        } else if constexpr (s == KST - 1) {
-          __syncthreads();  // the chunk is complete in LDS
-        }
+        if (!IL && !MST_FFN_EARLY_STORE && more) store_stage((s + 1) & 1, ring[(s + 1) % RING]);
+        FFN_STAMP(8 + (c * SPC + s) * 4 + 2);
+        __syncthreads();
+        FFN_STAMP(8 + (c * SPC + s) * 4 + 3);
         if constexpr (s == KST - 1 && !COPY_IL) {
           // the finished chunk goes out to `a` (the backward pass needs it) as whole 16-byte pieces of rows, while the
           // second GEMM's stages run
@@ -1486,35 +1382,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
   // (a residual that IS the block's input — the encoder's x1 + dropout(ff) — is taken from the x tile in LDS)
   const bool resid_is_x = g2.resid == g1.A && g2.ldr == g1.lda;
   FFN_STAMP(2);
-  if constexpr (DW) __syncthreads();  // the staging tile overlays the hidden chunks other waves may still be reading
-  if constexpr (!TAIL) {
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA, nullptr, 0, sPar, &seed2);
-  } else {
-    // the LayerNorm-1 backward result (masked copy, if any) -> x tile (dead: the residual is read from global memory here),
-    // then datt = that tile x Wp (the transposed shadow, [BN, BN] K-contiguous), stored as 16-bit rows
-    gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, nullptr, 0, sX, LDA, sPar, &seed2);
-    __syncthreads();  // the reduction scratch (over the weight stages) is dead, the tile complete
-    extra_gemm(n_chunks);
-    constexpr int LDS_F = BN + 4, CPR = BN / 8, RSTEP = NT / CPR, ITERS = BM / RSTEP;
-    float* sF = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        *reinterpret_cast<f32x4*>(sF + (wm * WTM + i * 16 + frow) * LDS_F + wn * WTN + j * 16 + fq * 4) = acc1[j][i];
-    __syncthreads();
-    const int ch = tid % CPR, nc = ch * 8, row0 = tid / CPR;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int row = row0 + it * RSTEP;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sF + row * LDS_F + nc + 4);
-      Pack8 ob;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { ob.h[e] = f32_to_bits<T>(v0[e]); ob.h[4 + e] = f32_to_bits<T>(v1[e]); }
-      if (m0 + row < Mg) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(gx.C) + (m0 + row) * gx.ldc + nc) = ob.u;
-    }
-  }
+  gemm_epilogue_ln<T, BM, BN, WGM, WGN, MODE>(g2, ln, smem, acc2, m0, resid_is_x ? sX : nullptr, LDA, nullptr, 0, sPar, &seed2);
   FFN_STAMP(3); FFN_RT(191);
 }
 
@@ -1522,30 +1390,19 @@ template <typename T, int BN>
 static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const mst_ln_args& ln, const mst_ln_bwd_in* lead, hipStream_t s,
                          const mst_gemm_args* gx = nullptr, const mst_ln_args* lnx = nullptr) {
   constexpr int BM = 64;
-#ifndef MST_FFN_DW_WGN256
-#define MST_FFN_DW_WGN256 8
-#endif
-  constexpr int DWN = BN >= 256 ? MST_FFN_DW_WGN256 : 8;  // waves of the direct-weight form
-  static const int dw_env = getenv("MST_FFN_DW") ? 1 : 0;  // experiment, off: see the DW note above ffn_ln_kernel
-  const int dw = gx ? 0 : dw_env, ex = gx ? 1 : 0;
-  const size_t lds_loop = (dw ? (size_t)3 * BM * (BN + 8) * 2 : (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2) + (size_t)g1.N * 4 +
-                          (size_t)6 * BN * 4;
+  const int ex = gx ? 1 : 0;
+  const size_t lds_loop = (size_t)2 * BN * 64 * 2 + (size_t)2 * BM * (BN + 8) * 2 + (size_t)g1.N * 4 + (size_t)6 * BN * 4;
   const size_t lds_epi = (size_t)BM * (BN + 4) * 4;
   const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   const int full = g1.M % BM == 0 ? 1 : 0;
-  const int mi = (dw + 2 * ex) * 6 + (lead ? 2 : (ln.mode == 2 ? 1 : 0)) * 2 + full;
+  // [forward | backward | backward with the leading LayerNorm] x [row guards | whole tiles], then the forward form with the projection head
+  const int mi = ex ? 6 + full : (lead ? 2 : (ln.mode == 2 ? 1 : 0)) * 2 + full;
   typedef void (*kern_t)(mst_gemm_args, mst_gemm_args, mst_ln_args, mst_ln_bwd_in, mst_gemm_args, mst_ln_args);
-  const kern_t fns[18] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true>,
-                          &ffn_ln_kernel<T, BN, 2, 4, 2, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true>,
-                          &ffn_ln_kernel<T, BN, 2, 4, 2, true, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true>,
-                          &ffn_ln_kernel<T, BN, 1, DWN, 1, false, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 1, false, true, true>,
-                          &ffn_ln_kernel<T, BN, 1, DWN, 2, false, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 2, false, true, true>,
-                          &ffn_ln_kernel<T, BN, 1, DWN, 2, true, false, true>, &ffn_ln_kernel<T, BN, 1, DWN, 2, true, true, true>,
-                          &ffn_ln_kernel<T, BN, 2, 4, 1, false, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true, false, true>,
-                          &ffn_ln_kernel<T, BN, 2, 4, 2, false, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true, false, true>,
-                          &ffn_ln_kernel<T, BN, 2, 4, 2, true, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true, false, true>};
-  static size_t opted[18] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024,
-                             64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // LDS each kernel is opted in for
+  const kern_t fns[8] = {&ffn_ln_kernel<T, BN, 2, 4, 1, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true>,
+                         &ffn_ln_kernel<T, BN, 2, 4, 2, false, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, false, true>,
+                         &ffn_ln_kernel<T, BN, 2, 4, 2, true, false>, &ffn_ln_kernel<T, BN, 2, 4, 2, true, true>,
+                         &ffn_ln_kernel<T, BN, 2, 4, 1, false, false, true>, &ffn_ln_kernel<T, BN, 2, 4, 1, false, true, true>};
+  static size_t opted[8] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // LDS each kernel is opted in for
   if (lds > opted[mi]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[mi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("ffn_ln_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
@@ -1554,7 +1411,7 @@ static int launch_ffn_ln(const mst_gemm_args& g1, const mst_gemm_args& g2, const
   const mst_ln_bwd_in none = {};
   const mst_gemm_args no_gemm = {};
   const mst_ln_args no_ln = {};
-  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(dw ? DWN * 64 : 512), lds, s, g1, g2, ln, lead ? *lead : none,
+  hipLaunchKernelGGL(fns[mi], dim3((unsigned)cdiv(g1.M, BM)), dim3(512), lds, s, g1, g2, ln, lead ? *lead : none,
                      gx ? *gx : no_gemm, lnx ? *lnx : no_ln);
   MST_CHECK_LAUNCH("ffn_ln_kernel");
   return MST_OK;
@@ -1626,23 +1483,17 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   const bool fast = gemm_fast_form<BM, BN>(a);
   const bool drop = a.dropout_p > 0.f || a.self_resid;
   // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
-  // (measured, in-call A/B at configs[1]: 0.787 ms per step with the direct form on its 8 eligible launches against 0.783
-  // with the staged one — 8-byte accesses in accumulator layout lose to 16-byte row-contiguous ones by more than the LDS
-  // round trip costs; kept behind MST_GEMM_DIRECT=1)
-  static const bool direct_ok = getenv("MST_GEMM_DIRECT") && getenv("MST_GEMM_DIRECT")[0] == '1';
-  const bool direct = direct_ok && fast && !drop && !rowops && !a.a_u8 && (!a.bias || (uintptr_t)a.bias % 16 == 0);
-  const int variant = direct ? 10 : a.a_u8 ? (fast ? 8 : 9) : (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
+  // (an epilogue finished in accumulator layout — 8-byte accesses, no LDS round trip — measured +4 us per step and was removed)
+  const int variant = a.a_u8 ? (fast ? 8 : 9) : (a.c_f32 ? 3 : (fast ? (drop ? 1 : 0) : 2)) + (rowops ? 4 : 0);
   typedef void (*kern_t)(mst_gemm_args);
   // [8], [9]: uint8 A operand (the piano-roll embedding GEMMs: row ops, 16-bit C, no dropout), fast / general
-  // [10]: the direct epilogue (no LDS staging)
-  const kern_t fns[11] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
+  const kern_t fns[10] = {&gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 1, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, false, 2, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, true>,
                          &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, true, BK, true, 2, true>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, false, true>,
-                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, false, 3, false>};
+                         &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 1, false, true>, &gemm_nt_kernel<T, BM, BN, WGM, WGN, false, BK, true, 2, false, true>};
   if (lds > 64 * 1024) {  // dynamic LDS above 64 KB has to be opted into, once per kernel
-    static bool opted[11] = {false, false, false, false, false, false, false, false, false, false, false};
+    static bool opted[10] = {false, false, false, false, false, false, false, false, false, false};
     if (!opted[variant]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("gemm_nt_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
@@ -1690,8 +1541,14 @@ static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_ge
   MST_CHECK_ARG(a.N == b.K && a.N % b.N == 0, "%s: the hidden width (first N = second K) must be a multiple of the model width", who);
   MST_CHECK_ARG(b.A == a.C && b.lda == a.ldc, "%s: the second GEMM's A operand must be the first one's output (it is consumed on chip)", who);
   MST_CHECK_ARG(!a.c_f32 && !b.c_f32 && !b.gate && !a.rowadd && !b.rowadd && !a.grpadd && !b.grpadd && !a.resid && !a.self_resid &&
-                b.act == MST_ACT_NONE && a.a_rows_per_group <= 0 && a.c_rows_per_group <= 0 && b.a_rows_per_group <= 0 && b.c_rows_per_group <= 0,
+                b.act == MST_ACT_NONE && a.c_rows_per_group <= 0 && b.a_rows_per_group <= 0 && b.c_rows_per_group <= 0,
                 "%s: fp32 outputs, row-indexed adds, row remaps, a gate or activation on the second GEMM and a residual on the first are not supported", who);
+  // ... except the first GEMM's A remap, which stands for the whole block: its M rows are rows [offset, offset + rows_per_group)
+  // of every `stride` physical rows, in every operand of the launch (groups and M in whole 64-row tiles)
+  MST_CHECK_ARG(a.a_rows_per_group <= 0 || (a.a_rows_per_group % 64 == 0 && a.M % a.a_rows_per_group == 0 && a.a_group_offset >= 0 &&
+                                            a.a_group_stride >= a.a_rows_per_group + a.a_group_offset && a.M < (1ll << 31)),
+                "%s: row groups must be whole 64-row tiles (rows per group %lld, stride %lld, offset %lld, M %lld)", who,
+                (long long)a.a_rows_per_group, (long long)a.a_group_stride, (long long)a.a_group_offset, (long long)a.M);
   MST_CHECK_ARG(a.lda % 8 == 0 && a.ldc % 8 == 0 && a.ldc >= a.N && b.ldc % 8 == 0 && b.ldc >= b.N, "%s: leading dimensions must be multiples of 8", who);
   MST_CHECK_ARG((uint64_t)a.N * (uint64_t)a.ldb < (1ull << 32) && (uint64_t)b.N * (uint64_t)b.ldb < (1ull << 32), "%s: weight matrices too large", who);
   MST_CHECK_ARG(!b.resid || (b.ldr % 8 == 0 && b.ldr >= b.N && (uintptr_t)b.resid % 16 == 0), "%s: bad residual layout", who);
@@ -1732,18 +1589,11 @@ static int ffn_ln_impl(const char* who, const mst_gemm_args* first, const mst_ge
     MST_CHECK_ARG(!x.c_f32 && !x.gate && !x.rowadd && !x.grpadd && x.act == MST_ACT_NONE && x.a_rows_per_group <= 0 && x.c_rows_per_group <= 0 &&
                   x.ldc % 8 == 0 && x.ldc >= x.N && (uint64_t)x.N * (uint64_t)x.ldb < (1ull << 32),
                   "%s: the extra GEMM takes no gate, activation, row-indexed add or row remap", who);
-    if (mode == 1) {
-      MST_CHECK_ARG(extra_ln != nullptr, "%s: the projection needs its LayerNorm", who);
-      const mst_ln_args& q = *extra_ln;
-      MST_CHECK_ARG(q.mode == 1 && q.gamma && q.beta && q.mean && q.rstd && q.out == a.A && q.ld_out == a.lda,
-                    "%s: the leading LayerNorm's output must be the first GEMM's A operand", who);
-      MST_CHECK_ARG(!x.resid || (x.ldr % 8 == 0 && x.ldr >= x.N && (uintptr_t)x.resid % 16 == 0), "%s: bad residual layout", who);
-    } else {
-      const void* tile = l.mask_mode == 1 ? l.out : b.C;
-      const int64_t tile_ld = l.mask_mode == 1 ? l.ld_out : b.ldc;
-      MST_CHECK_ARG(x.A == tile && x.lda == tile_ld, "%s: the trailing GEMM's A operand must be the LayerNorm backward's (masked) result", who);
-      MST_CHECK_ARG(!x.bias && !x.resid && !x.self_resid && x.dropout_p == 0.f && x.alpha == 1.f, "%s: the trailing GEMM is a plain product", who);
-    }
+    MST_CHECK_ARG(mode == 1 && extra_ln != nullptr, "%s: the projection (with its LayerNorm) rides in front of the forward form", who);
+    const mst_ln_args& q = *extra_ln;
+    MST_CHECK_ARG(q.mode == 1 && q.gamma && q.beta && q.mean && q.rstd && q.out == a.A && q.ld_out == a.lda,
+                  "%s: the leading LayerNorm's output must be the first GEMM's A operand", who);
+    MST_CHECK_ARG(!x.resid || (x.ldr % 8 == 0 && x.ldr >= x.N && (uintptr_t)x.resid % 16 == 0), "%s: bad residual layout", who);
   }
   hipStream_t s = (hipStream_t)stream;
   return dispatch_act(a.dtype, [&](auto tag) -> int {
@@ -1757,11 +1607,6 @@ extern "C" int mst_proj_ffn_ln_fwd(const mst_gemm_args* proj, const mst_ln_args*
                                    const mst_ln_args* ln2, mst_stream_t stream) {
   MST_CHECK_ARG(proj != nullptr && ln1 != nullptr, "mst_proj_ffn_ln_fwd: null args");
   return ffn_ln_impl("mst_proj_ffn_ln_fwd", ff1, ff2, ln2, 1, stream, nullptr, proj, ln1);
-}
-extern "C" int mst_ffn_ln_bwd_tail(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
-                                   const mst_ln_args* ln, const mst_gemm_args* proj_dgrad, mst_stream_t stream) {
-  MST_CHECK_ARG(proj_dgrad != nullptr, "mst_ffn_ln_bwd_tail: null args");
-  return ffn_ln_impl("mst_ffn_ln_bwd_tail", ff2_dgrad, ff1_dgrad, ln, 2, stream, lead, proj_dgrad);
 }
 
 extern "C" int mst_ffn_ln_bwd_lead(const mst_ln_bwd_in* lead, const mst_gemm_args* ff2_dgrad, const mst_gemm_args* ff1_dgrad,
@@ -1918,65 +1763,6 @@ extern "C" int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream) {
     // (32-deep K stages for launches of 1281..2048 64 x 64 tiles — eight workgroups per CU, one resident round for the decoder's
     // 257 x 6 projection tiles — measured no faster: +2 us per step)
     return launch_gemm<T, 64, 64, 2, 2>(a, s);
-  });
-}
-
-extern "C" int mst_latent_fwd_qkv_ok(int64_t B, int64_t T, int64_t De, int64_t Z, int64_t Dd) {
-  // shapes mst_latent_fwd_qkv takes: whole 128-row tiles inside a sample's rows 1..T, whole 128-column tiles of the 3 Dd outputs,
-  // 64-deep K stages, a decoder width the row-0 matvec is laid out for (128 or 256)
-  return B > 0 && T > 0 && T % 128 == 0 && (3 * Dd) % 128 == 0 && (Dd == 128 || Dd == 256) && De > 0 && Z > 0 &&
-         sizeof(float) * (size_t)(De + 3 * Z + Dd) <= 60000;
-}
-
-extern "C" int mst_latent_fwd_qkv(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out, int64_t enc_sample_stride,
-                                  const float* Wl, const float* bl, const float* eps, const float* Wh, const float* bh,
-                                  const int32_t* classes, const float* cls_d, int64_t ld_cls, const float* pos_d, float alpha_d, float* mu,
-                                  float* sigma, float* z, float* kl, void* dec_in, int64_t dec_sample_stride, const mst_gemm_args* proj,
-                                  mst_stream_t stream) {
-  MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_fwd_qkv: sizes must be positive");
-  MST_CHECK_ARG(enc_out && Wl && bl && eps && Wh && bh && classes && cls_d && pos_d && mu && sigma && z && kl && dec_in && proj,
-                "mst_latent_fwd_qkv: null pointer");
-  const mst_gemm_args& g = *proj;
-  int rc = check_gemm_common(g);
-  if (rc) return rc;
-  // the projection of rows 1..T: logical row m of B * T -> physical row (m / T) * (T + 1) + 1 + m % T on both sides
-  const int64_t T = g.c_rows_per_group;
-  MST_CHECK_ARG(T > 0 && g.a_rows_per_group == T && g.c_group_offset == 1 && g.a_group_offset == 1 && g.c_group_stride == T + 1 &&
-                    g.a_group_stride == T + 1 && g.M == B * T,
-                "mst_latent_fwd_qkv: proj must map the B * T rows 1..T of T + 1 on both sides (a_remap = c_remap = (T, T + 1, 1))");
-  MST_CHECK_ARG(g.dtype == dtype && g.N == 3 * Dd && g.K == Dd && mst_latent_fwd_qkv_ok(B, T, De, Z, Dd),
-                "mst_latent_fwd_qkv: shape not taken (mst_latent_fwd_qkv_ok): run mst_latent_fwd and the projection GEMM");
-  MST_CHECK_ARG(!g.c_f32 && !g.a_u8 && !g.resid && !g.gate && !g.rowadd && !g.grpadd && g.act == MST_ACT_NONE && g.dropout_p == 0.f &&
-                    !g.self_resid && g.alpha == 1.f && g.ldc % 8 == 0 && g.ldb >= Dd && (uint64_t)(B * (T + 1)) * (uint64_t)g.N < (1ull << 32),
-                "mst_latent_fwd_qkv: the projection takes a bias only");
-  MST_CHECK_ARG(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && ((uintptr_t)g.C % 16 == 0), "mst_latent_fwd_qkv: operands must be 16-byte aligned");
-  LatentFwdArgs la = {};
-  la.De = (int)De; la.Z = (int)Z; la.Dd = (int)Dd; la.enc_out = enc_out; la.enc_stride = enc_sample_stride;
-  la.Wl = Wl; la.bl = bl; la.eps = eps; la.Wh = Wh; la.bh = bh; la.classes = classes; la.cls_d = cls_d; la.ld_cls = ld_cls;
-  la.pos_d = pos_d; la.alpha_d = alpha_d; la.mu = mu; la.sigma = sigma; la.z = z; la.kl = kl; la.dec_in = dec_in;
-  la.dec_stride = dec_sample_stride;
-  la.Wq = g.B; la.ld_wq = g.ldb; la.bq = g.bias; la.qkv0 = g.C; la.qkv_stride = (T + 1) * g.ldc; la.nq = (int)g.N;
-  const size_t lds_lat = sizeof(float) * (size_t)(De + 3 * Z + Dd);
-  const size_t lds_gemm = (size_t)2 * (128 + 128) * 64 * 2, lds_epi = (size_t)128 * (128 + 4) * 4;
-  size_t lds = lds_lat;
-  if (lds_gemm > lds) lds = lds_gemm;
-  if (lds_epi > lds) lds = lds_epi;
-  const int64_t tiles = (g.M / 128) * (g.N / 128), n_lat = B;
-  hipStream_t s = (hipStream_t)stream;
-  return dispatch_act(dtype, [&](auto tag) -> int {
-    typedef decltype(tag) TT;
-    const bool pre = latent_fwd_pre_shape(De, Z, Dd);
-    const void* fn = pre ? reinterpret_cast<const void*>(&latent_qkv_kernel<TT, true>) : reinterpret_cast<const void*>(&latent_qkv_kernel<TT, false>);
-    static bool opted[2] = {false, false};
-    if (!opted[pre]) {
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_epi);
-      if (e != hipSuccess) { set_error("latent_qkv_kernel: LDS opt-in of %zu bytes: %s", lds_epi, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
-      opted[pre] = true;
-    }
-    if (pre) hipLaunchKernelGGL((latent_qkv_kernel<TT, true>), dim3((unsigned)(n_lat + tiles)), dim3(LAT_THREADS), lds, s, la, g, (int)n_lat);
-    else hipLaunchKernelGGL((latent_qkv_kernel<TT, false>), dim3((unsigned)(n_lat + tiles)), dim3(LAT_THREADS), lds, s, la, g, (int)n_lat);
-    MST_CHECK_LAUNCH("latent_qkv_kernel");
-    return MST_OK;
   });
 }
 

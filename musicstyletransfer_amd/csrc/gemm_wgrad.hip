@@ -640,6 +640,9 @@ extern "C" int mst_gemm_wgrad_batch_flush(const mst_wgrad_args* list, int n, flo
   if (out_elems >= (int64_t)256 * 256 * 24) big = 3;
   else if (out_elems >= (int64_t)256 * 128 * 36) big = 2;  // (a 0.79 M-output batch measured 58 us with 128x128, 62 with 256x128)
   else if (out_elems >= (int64_t)128 * 128 * 24) big = 1;
+  // (128 x 128 tiles with at most TWO M-slabs per tile added into dW by fp32 atomics — deterministic, because dW starts at zero and
+  // fl(0 + s1) + s2 == fl(0 + s2) + s1; no slab scratch, no reduction pass — measured 170 us against 70 + 17: with one 4-wave
+  // workgroup per CU a 64-row stage is a dependent chain of ~1.3 us whatever the tile size. docs/kernel_notes.md, round 4)
   const int bn = big >= 2 ? 256 : (big ? 128 : 64), bk = big == 3 ? 256 : (big ? 128 : 64);
   static const bool mixed = !(getenv("MST_WGRAD_MIXED") && getenv("MST_WGRAD_MIXED")[0] == '0');
   b.tile_prefix[0] = 0;

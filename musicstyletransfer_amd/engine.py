@@ -595,12 +595,17 @@ class StepPlan:
         fb = os.environ.get("MST_FUSE_BCE", "1")  # "0": never, "all": wherever the launch exists (A/B runs), default: where it pays
         self.fuse_bce = (cfg.kind == "pianoroll" and o.can_fuse_bce(cfg.out_dim, T, negative_label_downscaling) and fb != "0" and
                          (fb == "all" or o.bce_fusion_pays(cfg.out_dim)))
-        # the attention output projection inside the feed-forward launches: "head" = W_proj + LayerNorm-1 in front of the
-        # forward block (two launches less per layer at equal time), "all" = also its dgrad behind the backward block
-        # (measured slower: +14 us on a launch that is already one latency-bound workgroup per CU), "0" = neither
+        # the attention output projection + LayerNorm-1 in front of the forward feed-forward launch (two launches less per layer
+        # at equal time; its dgrad behind the backward block measured +14 us and was removed): MST_FUSE_PROJ=0 keeps them apart
         self.fuse_tail_bwd = os.environ.get("MST_TAIL_BWD", "1") != "0"  # the top layer's position-0 backward chain in one launch
-        fp = os.environ.get("MST_FUSE_PROJ", "head")
-        self.fuse_proj, self.fuse_proj_bwd = fp != "0", fp == "all"
+        self.fuse_proj = os.environ.get("MST_FUSE_PROJ", "1") != "0"
+        # The LAST decoder layer's row-wise part (W_proj, LayerNorm-1, feed-forward, LayerNorm-3 and their backward) skips every
+        # sample's position-0 row: its output is dropped before the loss (model.py:253), so nothing it computes there is ever
+        # read and every gradient there is zero — the buffers' position-0 rows simply stay at the zeros they were allocated with.
+        # B x T rows are B T / 64 tiles of the one-workgroup-per-CU feed-forward launches: ONE resident round at configs[1]
+        # (256 tiles) where B (T + 1) rows were 257 (measured: forward 22.8 -> 18.9 us, backward 24.6 -> 20.3).
+        self.skip_row0 = (cfg.d_layers > 0 and T % 64 == 0 and o.ffn_fusion_pays(Dd, 4 * Dd) and
+                          os.environ.get("MST_SKIP_ROW0", "1") != "0")
         self.logits = None if self.fuse_bce else act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
         if cfg.kind == "token":
@@ -834,11 +839,8 @@ class StepPlan:
         dh = D // H
         if side == "encoder" and i == self.cfg.e_layers - 1:
             return self._top_encoder_layer_fwd(i, L, x_in)
-        if side == "decoder" and i == 0 and getattr(self, "_dec_qkv_done", False):  # (projected on the latent block's launch: forward())
-            o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
-        else:
-            o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
-                           0, D, 2 * D)
+        o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
+                       0, D, 2 * D)
         # (Dense + LayerNorm in one launch, ops.gemm_nt_ln_fwd, does not pay in the forward pass: graph-replay timings at
         # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
         # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM
@@ -859,12 +861,19 @@ class StepPlan:
                 head = dict(att=L.att, W=st.h(f"{pre}.att.W_proj.weight"), h1=L.h1, gamma=st.p(f"{pre}.ln1.gamma"),
                             beta=st.p(f"{pre}.ln1.beta"), mean=L.mean1, rstd=L.rstd1, **proj)
             o.ffn_ln_fwd(L.x1, st.h(f"{pre}.ff1.weight"), L.a, st.h(f"{pre}.ff2.weight"), L.h2, st.p(f"{pre}.{ln}.gamma"),
-                         st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, ff1=ff1, ff2=ff2, proj=head)
+                         st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, ff1=ff1, ff2=ff2, proj=head,
+                         row_groups=self._row0_groups(side, i))
             return L.x2
         o.gemm_nt(L.x1, st.h(f"{pre}.ff1.weight"), L.a, **ff1)
         o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, **ff2)
         o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
         return L.x2
+
+    def _row0_groups(self, side, i):
+        """row groups of the last decoder layer's row-wise launches (skip_row0): rows 1..T of every T + 1, else None"""
+        if side == "decoder" and i == self.cfg.d_layers - 1 and self.skip_row0:
+            return (self.T, self.T + 1, 1)
+        return None
 
     def forward(self, inference=False):
         """inference=True: the forward pass as the reference runs it OUTSIDE autograd.record() (Model(...) called directly, the
@@ -913,16 +922,9 @@ class StepPlan:
                st.p("decoder.latent2hid.weight"), st.p("decoder.latent2hid.bias"), self.classes,
                st.p("decoder.class2hid.weight"), self.pos_d, sq_d, self.mu, self.sigma, self.z, self.kl,
                self.x0_d.view(B, Sd, -1))
-        # piano-roll ends: rows 1..T of the decoder input exist since the step's first launch, so the decoder's first K | Q | V
-        # projection does not have to wait for the latent block — MST_LATENT_QKV=1 lets it ride on its launch (mst_latent_fwd_qkv).
-        # Off by default: measured at parity at step level (0.661 vs 0.661 ms) — 16-wave workgroups make poor GEMM tiles at K = 128
-        self._dec_qkv_done = (cfg.kind != "token" and cfg.d_layers > 0 and os.environ.get("MST_LATENT_QKV", "0") == "1" and
-                              o.can_latent_fwd_qkv(B, T, De, cfg.latent_dim, Dd))
-        if self._dec_qkv_done:
-            o.latent_fwd_qkv(*lat, self.x0_d, st.fused(st.w16, "decoder.layer0", "weight"), st.fused(st.w, "decoder.layer0", "bias"),
-                             self.dec[0].qkv)
-        else:
-            o.latent_fwd(*lat)
+        # (the decoder's first K | Q | V projection riding on this launch — rows 1..T exist since the step's first launch — was
+        # built and measured at parity: 16-wave workgroups make poor GEMM tiles at K = 128; removed, docs/kernel_notes.md)
+        o.latent_fwd(*lat)
         # ---- decoder positions 1..T (model.py:241-245, transformer.py:237)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos_d, self.x0_d.view(B, Sd, -1), 1, sq_d)
@@ -1049,14 +1051,12 @@ class StepPlan:
             resid_ff = None
         # FFN: d(pre-relu) = (dff W2) * 1[a > 0] / (1-p)   (a is stored post-dropout, so a > 0 <=> relu on and kept)
         ln1 = dict(dx_masked=t.dh1m, mask_mode=1, dropout_site=site0, **dk) if p > 0 else {}
-        proj_done = False
         if ffn_fused:  # both dgrads of the block + LayerNorm-1 backward in one launch (mst_ffn_ln_bwd)
-            # ... and the attention output projection's dgrad behind them (mst_ffn_ln_bwd_tail)
-            tail = (st.t(f"{pre}.att.W_proj.weight"), t.datt) if self.fuse_proj_bwd else None
-            proj_done = tail is not None
+            rows = self._row0_groups(side, i)
             o.ffn_ln_bwd(dff, st.t(f"{pre}.ff2.weight"), t.dpre, L.a, st.t(f"{pre}.ff1.weight"), t.dh1, L.h1, st.p(f"{pre}.ln1.gamma"),
                          L.mean1, L.rstd1, st.grad(f"{pre}.ln1.gamma"), st.grad(f"{pre}.ln1.beta"), alpha=inv_keep, resid=resid_ff,
-                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(M)), lead=lead, tail=tail, **ln1)
+                         partials=self._ln_partials(f"{pre}.ln1", o.gemm_nt_ln_parts(self.B * self.T if rows else M)), lead=lead,
+                         row_groups=rows, **ln1)
         else:
             o.gemm_nt(dff, st.t(f"{pre}.ff2.weight"), t.dpre, N=4 * D, K=D, gate=L.a, alpha=inv_keep)
             if fuse:  # FFN1 dgrad + LayerNorm-1 backward in one launch (the gradient in between is never stored)
@@ -1069,8 +1069,7 @@ class StepPlan:
                                 st.grad(f"{pre}.ln1.beta"), D=D, partials=self._ln_partials(f"{pre}.ln1", o.layernorm_bwd_parts(M, D)),
                                 **ln1)
         dproj = t.dh1m if p > 0 else t.dh1
-        if not proj_done:
-            o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
+        o.gemm_nt(dproj, st.t(f"{pre}.att.W_proj.weight"), t.datt, N=D, K=D)
         o.attn_bwd(L.qkv, keymask, L.lse, t.datt, t.dqkv, t.delta, self.B, S, H, dhd, 0, D, 2 * D)
         if next_ln is not None:  # the layer below starts its backward pass with a LayerNorm backward: run it here
             kw, t_below = next_ln

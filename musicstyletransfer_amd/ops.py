@@ -217,14 +217,30 @@ def ffn_fusion_pays(D, F):
     return can_fuse_ffn(D, F)
 
 
-def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5, ff1=None, ff2=None, proj=None):
+def _row_groups(n_rows, row_groups):
+    """(M, remap) of a block that works on rows [offset, offset + rows_per_group) of every `stride` physical rows"""
+    rpg, stride, off = row_groups
+    assert n_rows % stride == 0 and rpg % 64 == 0 and off + rpg <= stride
+    return (n_rows // stride) * rpg, (rpg, stride, off)
+
+
+def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5, ff1=None, ff2=None, proj=None, row_groups=None):
     """a_out = epilogue1(x @ W1^T), h_out = epilogue2(a_out @ W2^T), y_out = LayerNorm(h_out) in one launch
     (mst_ffn_ln_fwd); ff1 / ff2: the keyword arguments gemm_nt would get for the two GEMMs.
     proj: dict(att, W, h1, gamma, beta, mean, rstd, **gemm_nt keywords) -> the attention output projection and its
     LayerNorm run in front, in the same launch (mst_proj_ffn_ln_fwd): h1 = epilogue(att @ W^T), x = LayerNorm(h1) (x is then
-    an OUTPUT as well as the block's input)"""
-    g1 = _gemm_args(x, W1, a_out, **(ff1 or {}))
-    g2 = _gemm_args(a_out, W2, h_out, **(ff2 or {}))
+    an OUTPUT as well as the block's input)
+    row_groups = (rows_per_group, stride, offset): the launch works on those rows of every operand only (the last decoder
+    layer without each sample's position-0 row); the other rows are neither read nor written"""
+    ff1, ff2 = dict(ff1 or {}), dict(ff2 or {})
+    if row_groups is not None:
+        M, remap = _row_groups(x.shape[0], row_groups)
+        ff1.update(M=M, a_remap=remap)
+        ff2.update(M=M)
+        if proj is not None:
+            proj = dict(proj, M=M)
+    g1 = _gemm_args(x, W1, a_out, **ff1)
+    g2 = _gemm_args(a_out, W2, h_out, **ff2)
     l = LnArgs()
     l.mode, l.gamma, l.beta, l.eps = 1, ptr(gamma), ptr(beta), eps
     l.out, l.ld_out = ptr(y_out), ld(y_out)
@@ -242,15 +258,17 @@ def ffn_ln_fwd(x, W1, a_out, W2, h_out, gamma, beta, y_out, mean, rstd, eps=1e-5
 
 
 def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgamma, dbeta, alpha=1.0, dx_masked=None, mask_mode=0,
-               partials=None, lead=None, tail=None, **kw):
+               partials=None, lead=None, row_groups=None, **kw):
     """dpre_out = ((dff @ W2t^T) * alpha) gated by gate > 0; dx_out = LayerNorm-backward(dpre_out @ W1t^T + resid; x, mean, rstd,
     gamma) in one launch (mst_ffn_ln_bwd). W2t / W1t: the transposed 16-bit weights ([F, D] and [D, F]); **kw: resid and the
     dropout fields of the LayerNorm-backward mask, as for gemm_nt_ln_bwd.
     lead: dict(dy, x, gamma, mean, rstd, dx, [dx_masked, dropout_*], [dgamma, dbeta | partials]) -> the layer's leading
-    LayerNorm backward runs in the prologue (mst_ffn_ln_bwd_lead); dff must then be lead's dx_masked (or dx).
-    tail: (Wt, datt_out) -> datt_out = (dx_masked if mask_mode == 1 else dx_out) @ Wt^T, the attention output projection's
-    dgrad, in the same launch (mst_ffn_ln_bwd_tail)"""
-    g1 = _gemm_args(dff, W2t, dpre_out, gate=gate, alpha=alpha)
+    LayerNorm backward runs in the prologue (mst_ffn_ln_bwd_lead); dff must then be lead's dx_masked (or dx)."""
+    rg = {}
+    if row_groups is not None:  # (as in ffn_ln_fwd: the same rows of every operand)
+        M, remap = _row_groups(dff.shape[0], row_groups)
+        rg, kw = dict(M=M, a_remap=remap), dict(kw, M=M)
+    g1 = _gemm_args(dff, W2t, dpre_out, gate=gate, alpha=alpha, **rg)
     g2 = _gemm_args(dpre_out, W1t, dx_out, **kw)
     l = LnArgs()
     l.mode, l.gamma = 2, ptr(gamma)
@@ -262,15 +280,8 @@ def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgam
     l.partials = ptr(partials)
     if partials is not None:
         assert partials.shape[0] >= gemm_nt_ln_parts(g1.M) and partials.shape[1] == 2 * g2.N and partials.is_contiguous()
-    gt = None
-    if tail is not None:
-        src = dx_masked if mask_mode == 1 else dx_out
-        gt = _gemm_args(src, tail[0], tail[1], N=g2.N, K=g2.N)
     if lead is None:
-        if gt is not None:
-            call("mst_ffn_ln_bwd_tail", None, C.byref(g1), C.byref(g2), C.byref(l), C.byref(gt), stream())
-        else:
-            call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
+        call("mst_ffn_ln_bwd", C.byref(g1), C.byref(g2), C.byref(l), stream())
         return
     q = LnBwdIn()
     q.dy, q.ld_dy = ptr(lead["dy"]), ld(lead["dy"])
@@ -285,10 +296,7 @@ def ffn_ln_bwd(dff, W2t, dpre_out, gate, W1t, dx_out, x, gamma, mean, rstd, dgam
     q.dropout_seed_ptr, q.dropout_site = ptr(lead.get("dropout_seed_ptr")), lead.get("dropout_site", 0)
     if lead.get("partials") is not None:
         assert lead["partials"].shape[0] >= gemm_nt_ln_parts(g1.M) and lead["partials"].shape[1] == 2 * g2.N
-    if gt is not None:
-        call("mst_ffn_ln_bwd_tail", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), C.byref(gt), stream())
-    else:
-        call("mst_ffn_ln_bwd_lead", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), stream())
+    call("mst_ffn_ln_bwd_lead", C.byref(q), C.byref(g1), C.byref(g2), C.byref(l), stream())
 
 
 def gemm_nt_ln_bwd(A, B, dX_out, x, gamma, mean, rstd, dgamma, dbeta, dx_masked=None, mask_mode=0, partials=None, **kw):
@@ -520,24 +528,6 @@ def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu
     call("mst_latent_fwd", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
          ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
          ptr(kl), ptr(dec_in3), dec_in3.stride(0), stream())
-
-
-def can_latent_fwd_qkv(B, T, De, Z, Dd):
-    """shapes mst_latent_fwd_qkv takes (the decoder's first K | Q | V projection on the latent block's launch)"""
-    return bool(_lib.load().mst_latent_fwd_qkv_ok(B, T, De, Z, Dd))
-
-
-def latent_fwd_qkv(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in3, x0_d, Wq, bq, qkv):
-    """latent_fwd, and on the same launch qkv = x0_d @ Wq^T + bq for the decoder's first layer: rows 1..T of every sample as GEMM
-    tiles beside the latent workgroups, row 0 by the latent workgroup that produces it (mst_latent_fwd_qkv).
-    x0_d: [B * (T + 1), ld] decoder input (dec_in3 is its [B, T + 1, ld] view), Wq: [3 Dd, Dd] 16-bit shadow, qkv: [B * (T + 1), ld]"""
-    B, Sd = dec_in3.shape[0], dec_in3.shape[1]
-    T = Sd - 1
-    De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
-    g = _gemm_args(x0_d, Wq, qkv, M=B * T, N=3 * Dd, K=Dd, bias=bq, a_remap=(T, Sd, 1), c_remap=(T, Sd, 1))
-    call("mst_latent_fwd_qkv", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
-         ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
-         ptr(kl), ptr(dec_in3), dec_in3.stride(0), C.byref(g), stream())
 
 
 def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d, kl_weight, gscale, dWl, dbl, dWh, dbh,

@@ -567,6 +567,87 @@ def test_ffn_ln_fwd_equals_the_three_launches(gpu, M, D, F, p, self_resid):
     assert ((y1 != y0).float().mean().item()) < 5e-2
 
 
+@pytest.mark.parametrize("B,T,D,F,p", [(64, 256, 128, 512, 0.2), (3, 64, 256, 1024, 0.0), (5, 128, 128, 512, 0.1)])
+def test_ffn_ln_row_groups_skip_position_0_of_every_sample(gpu, B, T, D, F, p):
+    """row_groups = (T, T + 1, 1): the feed-forward launches (forward with the projection head, and backward) of the LAST decoder
+    layer work on rows 1..T of every sample only (engine skip_row0: position 0's output is dropped before the loss, model.py:253).
+    Against the same launches over all B (T + 1) rows: the rows they share agree — hidden activation and gated gradient bit for
+    bit, the rest to a rounding of the activation type (the fp32 sum over the hidden chunks runs in an order that depends on the
+    workgroup's place in the launch) — dropout masks included (their counters are the PHYSICAL row), and position-0 rows are
+    neither read nor written (a sentinel survives)."""
+    o = ops()
+    S, M = T + 1, B * (T + 1)
+    att, xres = rnd((M, D), gpu, seed=500), rnd((M, D), gpu, seed=501)
+    Wp, W1, W2 = rnd((D, D), gpu, seed=502, scale=0.06), rnd((F, D), gpu, seed=503, scale=0.06), rnd((D, F), gpu, seed=504, scale=0.03)
+    bp, b1, b2 = (rnd((n,), gpu, dtype=torch.float32, seed=505 + i, scale=0.1) for i, n in enumerate((D, F, D)))
+    g1, be1 = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=510), rnd((D,), gpu, dtype=torch.float32, seed=511, scale=0.1)
+    g3, be3 = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=512), rnd((D,), gpu, dtype=torch.float32, seed=513, scale=0.1)
+    seedp = torch.tensor([77, 0, 0, 0], dtype=torch.int64, device=gpu)
+    drop = lambda site: dict(dropout_p=p, dropout_seed_ptr=seedp, dropout_site=site) if p > 0 else {}
+    SENT = 7.0
+
+    def fwd(rows):
+        bufs = dict(h1=(M, D), x1=(M, D), a=(M, F), h2=(M, D), y=(M, D))
+        t = {k: torch.full(v, SENT, dtype=BF, device=gpu) for k, v in bufs.items()}
+        st = {k: torch.full((M,), SENT, device=gpu) for k in ("m1", "r1", "m2", "r2")}
+        head = dict(att=att, W=Wp, h1=t["h1"], gamma=g1, beta=be1, mean=st["m1"], rstd=st["r1"], N=D, K=D, bias=bp, resid=xres, **drop(3))
+        o.ffn_ln_fwd(t["x1"], W1, t["a"], W2, t["h2"], g3, be3, t["y"], st["m2"], st["r2"], ff1=dict(K=D, bias=b1, act=o.ACT_RELU, **drop(4)),
+                     ff2=dict(K=F, bias=b2, self_resid=True, **drop(5)), proj=head, row_groups=rows)
+        torch.cuda.synchronize()
+        return t, st
+
+    full, fst = fwd(None)
+    part, pst = fwd((T, S, 1))
+    ulp = 2.0 ** -7
+    for k in ("h1", "x1", "a", "h2", "y"):
+        a3, b3 = part[k].view(B, S, -1).float(), full[k].view(B, S, -1).float()
+        assert (a3[:, 0] == SENT).all(), f"{k}: a position-0 row was written"
+        if k in ("h1", "x1", "a"):  # one GEMM each, K in the same order
+            assert torch.equal(a3[:, 1:], b3[:, 1:]), k
+        else:
+            d = (a3[:, 1:] - b3[:, 1:]).abs()
+            assert (d <= 2 * ulp * b3[:, 1:].abs().clamp(min=1.0)).all() and (d > 0).float().mean().item() < 0.05, k
+    for k in ("m1", "r1", "m2", "r2"):
+        a2, b2_ = pst[k].view(B, S), fst[k].view(B, S)
+        assert (a2[:, 0] == SENT).all()
+        close(a2[:, 1:], b2_[:, 1:], 2e-3, 5e-4, k)
+
+    # backward: FFN2 dgrad + ReLU gate + FFN1 dgrad + LayerNorm-1 backward, dff zero at position 0 as in the step
+    dff = rnd((M, D), gpu, seed=520)
+    dff.view(B, S, D)[:, 0] = 0
+    W2t, W1t = W2.t().contiguous(), W1.t().contiguous()
+    nparts = o.gemm_nt_ln_parts(M)
+
+    def bwd(rows):
+        dpre, dh1, dh1m = (torch.full(sh, SENT, dtype=BF, device=gpu) for sh in ((M, F), (M, D), (M, D)))
+        parts = torch.zeros(nparts, 2 * D, device=gpu)
+        dg, db = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+        kw = dict(dx_masked=dh1m, mask_mode=1, **drop(3)) if p > 0 else {}
+        o.ffn_ln_bwd(dff, W2t, dpre, full["a"], W1t, dh1, full["h1"], g1, fst["m1"], fst["r1"], dg, db, alpha=1.0 / (1.0 - p) if p > 0 else 1.0,
+                     partials=parts, row_groups=rows, **kw)
+        torch.cuda.synchronize()
+        return dpre, dh1, dh1m, parts.sum(0)
+
+    fb, pb = bwd(None), bwd((T, S, 1))
+    for nm, a, b in (("dpre", pb[0], fb[0]), ("dh1", pb[1], fb[1])) + ((("dh1m", pb[2], fb[2]),) if p > 0 else ()):
+        a3, b3 = a.view(B, S, -1).float(), b.view(B, S, -1).float()
+        assert (a3[:, 0] == SENT).all(), f"{nm}: a position-0 row was written"
+        if nm == "dpre":
+            assert torch.equal(a3[:, 1:], b3[:, 1:]), nm
+        else:
+            d = (a3[:, 1:] - b3[:, 1:]).abs()
+            assert (d <= 2 * ulp * b3[:, 1:].abs().clamp(min=1.0)).all(), nm
+    # the LayerNorm parameter gradients: position-0 rows contribute nothing on either side (dff = 0 there gives a zero dx ... but
+    # d gamma sums dy * xhat of the block's OUTPUT gradient, which is non-zero at position 0 in the full launch's garbage rows): compare
+    # against the full launch's sums minus its position-0 rows, i.e. recompute from the shared rows
+    dy = (fb[0].float() @ W1t.float().t())  # d(x1) before the LayerNorm backward, all rows
+    xh = (full["h1"].float() - fst["m1"][:, None]) * fst["r1"][:, None]
+    keep = torch.ones(B, S, 1, device=gpu)
+    keep[:, 0] = 0
+    ref = torch.cat([(dy * xh).view(B, S, D).mul(keep).sum((0, 1)), dy.view(B, S, D).mul(keep).sum((0, 1))])
+    close(pb[3], ref, 2e-2, 2e-2 * ref.abs().max().item(), "dgamma | dbeta partial sums over rows 1..T")
+
+
 @pytest.mark.parametrize("M,D,F,p", [(16384, 256, 1024, 0.2), (16448, 128, 512, 0.2), (200, 256, 512, 0.0), (77, 128, 128, 0.1)])
 def test_proj_ffn_ln_fwd_equals_projection_then_block(gpu, M, D, F, p):
     """mst_proj_ffn_ln_fwd == mst_gemm_nt_ln(proj, ln1) + mst_ffn_ln_fwd, bit for bit in every output (h1, x1 and its
@@ -604,46 +685,6 @@ def test_proj_ffn_ln_fwd_equals_projection_then_block(gpu, M, D, F, p):
     o.gemm_nt(att, Wp, h1u, **proj)
     torch.cuda.synchronize()
     assert torch.equal(h1u, res[1][0])
-
-
-@pytest.mark.parametrize("M,D,F,mode,lead", [(16384, 256, 1024, 1, True), (16448, 128, 512, 1, False), (200, 256, 512, 0, False),
-                                               (77, 128, 128, 1, True)])
-def test_ffn_ln_bwd_tail_equals_block_then_projection_dgrad(gpu, M, D, F, mode, lead):
-    """mst_ffn_ln_bwd_tail == mst_ffn_ln_bwd(_lead) + mst_gemm_nt(datt = d(h1)[masked] Wp): every output bit for bit"""
-    o = ops()
-    dff, gate = rnd((M, D), gpu, seed=500, scale=0.5), rnd((M, F), gpu, seed=501)
-    W2t, W1t, Wpt = rnd((F, D), gpu, seed=502, scale=0.05), rnd((D, F), gpu, seed=503, scale=0.05), rnd((D, D), gpu, seed=520, scale=0.06)
-    x = rnd((M, D), gpu, seed=505)
-    gam = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=506)
-    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
-    seedp = torch.tensor([91, 0, 0, 0], dtype=torch.int64, device=gpu)
-    drop = dict(dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=2) if mode else {}
-    dyin, xin = rnd((M, D), gpu, seed=507), rnd((M, D), gpu, seed=508, scale=1.5)
-    gin = 1 + 0.1 * rnd((D,), gpu, dtype=torch.float32, seed=509)
-    mean_in, rstd_in = xin.float().mean(1), 1.0 / torch.sqrt(xin.float().var(1, unbiased=False) + 1e-5)
-    parts = o.gemm_nt_ln_parts(M)
-    res = []
-    for fused in (False, True):
-        dh, dhm = torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
-        dpre, dx, dxm = torch.zeros(M, F, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu), torch.zeros(M, D, dtype=BF, device=gpu)
-        datt = torch.zeros(M, D, dtype=BF, device=gpu)
-        dg, db = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
-        part, pin = torch.zeros(parts, 2 * D, device=gpu), torch.zeros(parts, 2 * D, device=gpu)
-        kw = dict(alpha=1.25, dx_masked=dxm if mode == 1 else None, mask_mode=mode, partials=part, **drop)
-        if lead:
-            kw.update(resid=dh, lead=dict(dy=dyin, x=xin, gamma=gin, mean=mean_in, rstd=rstd_in, dx=dh, dx_masked=dhm, partials=pin,
-                                          dropout_p=0.2, dropout_seed_ptr=seedp, dropout_site=7))
-        a_op = dhm if lead else dff
-        if fused:
-            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, tail=(Wpt, datt), **kw)
-        else:
-            o.ffn_ln_bwd(a_op, W2t, dpre, gate, W1t, dx, x, gam, mean, rstd, dg, db, **kw)
-            o.gemm_nt(dxm if mode == 1 else dx, Wpt, datt, N=D, K=D)
-        torch.cuda.synchronize()
-        res.append((dpre, dx, dxm, datt, part, pin, dh, dhm))
-    for name, u, v in zip(("dpre", "dx", "dx masked", "datt", "partials", "lead partials", "lead dx", "lead dx masked"), res[0], res[1]):
-        assert torch.equal(u, v), name
-    assert res[1][3].float().abs().max().item() > 0
 
 
 @pytest.mark.parametrize("M,D,F,mode,with_resid", [(16384, 256, 1024, 1, True), (16448, 128, 512, 2, False), (200, 256, 512, 0, True),
@@ -1156,50 +1197,6 @@ def test_group_colsum(gpu, B, T, D, s_off):
 
 
 # ------------------------------------------------------------------------------------------ latent
-@pytest.mark.parametrize("B,T,De,Z,Dd,dtype", [(64, 256, 256, 64, 128, BF), (8, 128, 256, 256, 128, torch.float16), (3, 128, 64, 16, 128, BF)])
-def test_latent_fwd_qkv_equals_latent_fwd_then_the_projection(gpu, B, T, De, Z, Dd, dtype):
-    """mst_latent_fwd_qkv (the decoder's first K | Q | V projection on the latent block's launch: rows 1..T of every sample as GEMM
-    tiles beside the latent workgroups, row 0 by its latent workgroup) against mst_latent_fwd followed by the projection GEMM
-    over all B * (T + 1) rows: the latent outputs and rows 1..T bit for bit (same MFMA order per element), row 0 to fp32
-    summation order (dot products instead of an MFMA chain, same 16-bit operands, fp32 accumulation, one rounding)"""
-    o = ops()
-    assert o.can_latent_fwd_qkv(B, T, De, Z, Dd)
-    Sd, Cn = T + 1, 3
-    enc = rnd((B, 4, De), gpu, 1.0, dtype, seed=60)
-    Wl = rnd((2 * Z, De), gpu, dtype=torch.float32, seed=61, scale=0.2)
-    bl = rnd((2 * Z,), gpu, dtype=torch.float32, seed=62, scale=0.5) + 1.0
-    Wh = rnd((Dd, Z), gpu, dtype=torch.float32, seed=63, scale=0.3)
-    bh = rnd((Dd,), gpu, dtype=torch.float32, seed=64, scale=0.1)
-    cls_d = rnd((Cn, Dd), gpu, dtype=torch.float32, seed=65)
-    pos_d = rnd((Sd, Dd), gpu, dtype=torch.float32, seed=66)
-    eps = rnd((B, Z), gpu, dtype=torch.float32, seed=67)
-    classes = (torch.arange(B, dtype=torch.int32) % Cn).to(gpu)
-    Wq = rnd((3 * Dd, Dd), gpu, 0.1, dtype, seed=68)
-    bq = rnd((3 * Dd,), gpu, 0.1, torch.float32, seed=69)
-    x_rows = rnd((B, T, Dd), gpu, 1.0, dtype, seed=70)
-    outs = []
-    for fused in (False, True):
-        mu = torch.zeros(B, Z, device=gpu); sigma = torch.zeros(B, Z, device=gpu); z = torch.zeros(B, Z, device=gpu)
-        kl = torch.zeros(B, device=gpu)
-        x0_d = torch.zeros(B * Sd, Dd, dtype=dtype, device=gpu)
-        x0_d.view(B, Sd, Dd)[:, 1:] = x_rows  # rows 1..T: the embedding GEMM's output
-        qkv = torch.zeros(B * Sd, 3 * Dd, dtype=dtype, device=gpu)
-        lat = (enc, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, math.sqrt(Dd), mu, sigma, z, kl, x0_d.view(B, Sd, Dd))
-        if fused:
-            o.latent_fwd_qkv(*lat, x0_d, Wq, bq, qkv)
-        else:
-            o.latent_fwd(*lat)
-            o.gemm_nt(x0_d, Wq, qkv, K=Dd, bias=bq)
-        torch.cuda.synchronize()
-        outs.append((mu, sigma, z, kl, x0_d, qkv))
-    for a_, b_, name in zip(outs[0][:5], outs[1][:5], ("mu", "sigma", "z", "kl", "decoder input")):
-        assert torch.equal(a_, b_), name
-    q0, q1 = outs[0][5].view(B, Sd, -1), outs[1][5].view(B, Sd, -1)
-    assert torch.equal(q0[:, 1:], q1[:, 1:]), "rows 1..T of the projection"
-    close(q1[:, 0], q0[:, 0].float(), 1e-2, 2e-2, "row 0 of the projection")
-    assert q1[:, 0].abs().sum() > 0
-
-
 def test_latent_fwd_bwd(gpu):
     o = ops()
     B, S, De, Z, Dd, Cn, Sd = 5, 6, 64, 16, 32, 3, 7

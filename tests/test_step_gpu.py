@@ -417,27 +417,6 @@ def test_graph_replay_matches_eager(gpu):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-3)
 
 
-def test_projection_on_the_latent_launch_matches_the_separate_gemm(gpu, monkeypatch):
-    """MST_LATENT_QKV=1 (the decoder's first K | Q | V projection on the latent block's launch, an opt-in switch: measured at
-    parity) against the default sequence on the same weights, batch and eps: same losses, same updated weights to the rounding
-    of row 0's projection (fp32 dot products there instead of an MFMA chain)"""
-    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (128, 128, 3, 32, 256, 2, 8, 128, 1, 8), 4, 128, 33, ragged=False)
-    res = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("MST_LATENT_QKV", on)
-        store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
-        plan = E.StepPlan(store, 4, 128, lr=1e-3)
-        plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
-        for _ in range(2):
-            plan.step_kernels(True)
-        torch.cuda.synchronize()
-        assert plan._dec_qkv_done == (on == "1")
-        res.append((store.w.cpu().numpy().copy(), plan.total.cpu().numpy().copy(), plan.dec[0].qkv.float().cpu().numpy().copy()))
-    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-4)
-    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=3e-2)
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-3)
-
-
 def test_overlapped_data_parallel_schedule_matches_single_graph(gpu):
     """capture(split_optimizer, overlap): forward + early backward | late backward | optimizer, with the gradient
     bucket handed to the reducer in two ranges (top encoder layer .. decoder first). With a recording stand-in for the

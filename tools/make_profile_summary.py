@@ -72,8 +72,18 @@ with open(os.path.join(out, f"{tag}_hbm_traffic.csv"), "w", newline="") as f:
         fm, wm = 2 * fetch[k] * 1024 / 1e6, write.get(k, 0.0) * 1024 / 1e6
         w.writerow([k[0], k[1], f"{fm:.2f}", f"{wm:.2f}", f"{fm + wm:.2f}"])
         traffic[f"{k[0]}@{k[1]}"] = (fm + wm) * 1e6
+# keyed by BASELINE config (MST_PROFILE_CONFIG, default 1): bench.py --config N reads configs[N]; only the library's own kernels are kept
+cfg = os.environ.get("MST_PROFILE_CONFIG", "1")
 path = os.path.join(out, "roofline_traffic.json")
-json.dump({"source": f"profiles/{tag}_hbm_traffic.csv", "bytes_per_launch": traffic}, open(path, "w"), indent=1, sort_keys=True)
+try:
+    doc = json.load(open(path))
+except (OSError, ValueError):
+    doc = {}
+if "configs" not in doc:
+    doc = {"configs": {}}
+own = {k: v for k, v in traffic.items() if not k.startswith(("at::", "__amd", "void at::"))}
+doc["configs"][cfg] = {"source": f"profiles/{tag}_hbm_traffic.csv", "bytes_per_launch": own}
+json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
 if len(sys.argv) > 5:
     shutil.copy(sys.argv[5], os.path.join(out, f"{tag}_bench.json"))
 print("wrote", tag, "files;", len(traffic), "kernels with traffic")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag> [bench args...]
+# usage (on the GPU box, from the repo root): [MST_PROFILE_CONFIG=N] tools/profile_round.sh <tag> [bench args... e.g. --config N]
 # rocprofv3 kernel stats of `python3 bench.py <args>` plus the two PMC passes for HBM traffic (separate --pmc runs, as
 # MI355X_MICROARCH.md's HBM section prescribes), then tools/make_profile_summary.py -> profiles/<tag>_* and
 # gpurun_out/<tag>/profiles/ (copied back by gpurun).
