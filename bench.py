@@ -185,18 +185,23 @@ def kernel_families(plan, o, iters=30):
     # in, qkv (kept for the backward pass) and the attention output out
     Hd, Sd, Md = cfg.d_heads, T + 1, plan.Md
     qkv_flops = lambda M_, D_: 2.0 * M_ * 3 * D_ * D_
+    # PMC keys (tools/make_profile_summary.py names; alternatives '|' by the form the library picks for the shape): resident kernels at
+    # T <= 512, beyond that the projection as a GEMM + the chunked forward, the streaming dV / dK kernel + the chunked dQ kernel
+    dh_e = De // H
+    fwd_key = f"attn_fwd_res_kernel<{dh_e},1,0>@*|gemm_nt_kernel<128,128,2,2,64>@{(M // 128) * (3 * De // 128) * 256}+attn_fwd_res_kernel<{dh_e},0,1>@*"
+    bwd_key = f"attn_bwd_res_kernel<{dh_e},%(sp)d>@*|attn_bwd_kv_kernel<{dh_e},%(sp)d>@*+attn_bwd_q_chunk_kernel<{dh_e},4>@*"
     if full_e:
         fams.append(dict(
             kernel=f"attention fwd with the K,Q,V projection inside [B*H={B * H}, S={T}, dh={De // H}, D={De}]",
             fn=lambda: o.attn_qkv_fwd(plan.x0_e, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, plan.keymask_e, L.lse, L.att,
                                       B, T, H, De // H, 0, De, 2 * De),
             flops=4.0 * B * T * T * De + qkv_flops(M, De), bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + M * De),
-            launches_per_step=full_e, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+            launches_per_step=full_e, pmc_key=fwd_key))
         fams.append(dict(
             kernel=f"attention bwd [B*H={B * H}, S={T}, dh={De // H}]",
             fn=lambda: o.attn_bwd(L.qkv, plan.keymask_e, L.lse, t.datt, t.dqkv, t.delta, B, T, H, De // H, 0, De, 2 * De),
             flops=2.0 * 4 * B * T * T * De, bytes=2.0 * M * (3 * De + De + 3 * De), launches_per_step=full_e,
-            pmc_key="attn_bwd_res_kernel<%d,0>@%d" % (De // H, B * H * 512)))
+            pmc_key=bwd_key % dict(sp=0)))
     if cfg.e_layers >= 1:
         # the top encoder layer is read at position 0 only (model.py:97): projection and key-row statistics over every query, the
         # output for ONE query per sample; backward with dO zero beyond it. Algorithmic work = the reference's dense layer.
@@ -207,22 +212,24 @@ def kernel_families(plan, o, iters=30):
             fn=lambda: o.attn_qkv_fwd(x_top, st.fused(st.w16, pt, "weight"), st.fused(st.w, pt, "bias"), Lt.qkv, plan.keymask_e, Lt.lse, Lt.att,
                                       B, T, H, De // H, 0, De, 2 * De, q_limit=1),
             flops=4.0 * B * T * T * De + qkv_flops(M, De), bytes=2.0 * (M * De + 3 * De * De + M * 3 * De + B * De),
-            launches_per_step=1, pmc_key="attn_fwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+            launches_per_step=1, pmc_key=fwd_key))
         fams.append(dict(
             kernel=f"attention bwd, top encoder layer (dO zero beyond query 0) [B*H={B * H}, S={T}, dh={De // H}]",
             fn=lambda: o.attn_bwd(Lt.qkv, plan.keymask_e, Lt.lse, plan.sp_datt, tt.dqkv, tt.delta, B, T, H, De // H, 0, De, 2 * De, q_limit=1),
             flops=2.0 * 4 * B * T * T * De, bytes=2.0 * (M * 3 * De + B * De + M * 3 * De), launches_per_step=1,
-            pmc_key="attn_bwd_res_kernel<%d,1>@%d" % (De // H, B * H * 512)))
+            pmc_key=bwd_key % dict(sp=1)))
     if cfg.d_layers >= 1:
         Ld, td = plan.dec[0], plan.bd_l[0]
         fams.append(dict(
             kernel=f"attention fwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}] (its projection is a GEMM launch)",
             fn=lambda: o.attn_fwd(Ld.qkv, plan.keymask_d, Ld.lse, Ld.att, B, Sd, Hd, Dd // Hd, 0, Dd, 2 * Dd),
-            flops=4.0 * B * Sd * Sd * Dd, bytes=2.0 * (Md * 3 * Dd + Md * Dd), launches_per_step=cfg.d_layers, pmc_key=None))
+            flops=4.0 * B * Sd * Sd * Dd, bytes=2.0 * (Md * 3 * Dd + Md * Dd), launches_per_step=cfg.d_layers,
+            pmc_key="attn_fwd_res_kernel<%d,0,0>@*" % (Dd // Hd)))
         fams.append(dict(
             kernel=f"attention bwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}]",
             fn=lambda: o.attn_bwd(Ld.qkv, plan.keymask_d, Ld.lse, td.datt, td.dqkv, td.delta, B, Sd, Hd, Dd // Hd, 0, Dd, 2 * Dd),
-            flops=2.0 * 4 * B * Sd * Sd * Dd, bytes=2.0 * Md * (3 * Dd + Dd + 3 * Dd), launches_per_step=cfg.d_layers, pmc_key=None))
+            flops=2.0 * 4 * B * Sd * Sd * Dd, bytes=2.0 * Md * (3 * Dd + Dd + 3 * Dd), launches_per_step=cfg.d_layers,
+            pmc_key="attn_bwd_res_kernel<%d,0>@*" % (Dd // Hd)))
     wg, ps = plan.last_wgrad_launch
     if wg:
         fl = sum(2.0 * w.M * w.N * w.K for w in wg)

@@ -108,6 +108,8 @@ typedef struct mst_gemm_args {
   int32_t a_u8; /* 1: A is uint8 [M, lda bytes] (piano-roll frames as they arrive from the batcher), widened to the
                  * activation type while the tile is staged into LDS: the frames are never stored in 16 bits. Offered
                  * for the embedding GEMMs' form: 16-bit C, no dropout / self_resid, lda % 8 == 0. */
+  int32_t resid_phys; /* 1: the residual shares C's PHYSICAL rows (it follows the C row remap); 0: it is indexed by the logical row m,
+                       * as a strided view would be */
 } mst_gemm_args;
 
 int mst_gemm_nt(const mst_gemm_args* args, mst_stream_t stream);
@@ -404,6 +406,20 @@ int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const float* pos_d, float alpha_d,
                    float* mu, float* sigma, float* z, float* kl,
                    void* dec_in, int64_t dec_sample_stride, mst_stream_t stream);
+/* ... and, on the same launch, the decoder's first K | Q | V projection of THAT row (transformer.py:88-93 on position 0):
+ * qkv0[b * qkv_sample_stride + j] = dec_in[b, 0, :] . Wq[j, :] + bq[j], j < nq (Wq: the 16-bit weight, [nq, ld_wq]; fp32 dot products
+ * over the row as stored). The other B T rows of that projection do not depend on the latent block: the step computes them as a
+ * rider of the forward position-0 tail (mst_row_tail_fwd_ride). Dd must be 64, 128 or 256. */
+int mst_latent_fwd_proj(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
+                        const void* enc_out, int64_t enc_sample_stride,
+                        const float* Wl, const float* bl, const float* eps,
+                        const float* Wh, const float* bh,
+                        const int32_t* classes, const float* cls_d, int64_t ld_cls,
+                        const float* pos_d, float alpha_d,
+                        float* mu, float* sigma, float* z, float* kl,
+                        void* dec_in, int64_t dec_sample_stride,
+                        const void* Wq, int64_t ld_wq, const float* bq, void* qkv0, int64_t qkv_sample_stride, int64_t nq,
+                        mst_stream_t stream);
 
 int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd,
                    const void* enc_out, int64_t enc_sample_stride,
@@ -424,6 +440,17 @@ int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, 
                        const int32_t* classes, const float* mu, const float* sigma, const void* d_dec_in, int64_t dec_sample_stride,
                        float alpha_d, float kl_weight, float gscale, float enc_scale, float* dcls_d, int64_t ld_cls,
                        void* d_enc_out, int64_t denc_sample_stride, float* scratch, mst_stream_t stream);
+/* mst_latent_bwd_vec with d(dec_in[b, 0, :]) COMPUTED instead of read: dq0[b * dq_sample_stride + k] (k < nq: the gradient of the
+ * decoder's first K | Q | V projection at position 0) against Wt [Dd, ld_wt >= nq] (the TRANSPOSED 16-bit weight, the operand of the
+ * input-gradient GEMM) plus resid0[b * resid_sample_stride + :] (the residual branch's gradient row, may be NULL), rounded to the
+ * activation type as that GEMM rounds it — whose other B T rows the step computes as a rider of the backward position-0 tail
+ * (mst_row_tail_bwd_ride). nq must be 384 or 768 (decoder width 128 or 256). */
+int mst_latent_bwd_vec_proj(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps, const float* Wh,
+                            const int32_t* classes, const float* mu, const float* sigma,
+                            const void* dq0, int64_t dq_sample_stride, const void* Wt, int64_t ld_wt, int64_t nq,
+                            const void* resid0, int64_t resid_sample_stride,
+                            float alpha_d, float kl_weight, float gscale, float enc_scale, float* dcls_d, int64_t ld_cls,
+                            void* d_enc_out, int64_t denc_sample_stride, float* scratch, mst_stream_t stream);
 
 /* standalone reparameterisation + KL (loss.VariationalKLLoss, loss.py:4-12; model.py:292) */
 int mst_reparam_kl_fwd(int64_t B, int64_t Z, const float* mu, const float* sigma, const float* eps,
@@ -460,6 +487,15 @@ typedef struct mst_row_tail_args {
   uint32_t* status;  /* optional sticky device word: MST_TAIL_* flags are OR-ed into it when the launch could not do its work */
 } mst_row_tail_args;
 int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
+/* RIDERS: the chain above keeps ONE XCD busy for ~26 us while seven idle. mst_row_tail_*_ride launch the same kernel with enough
+ * workgroups for every CU; those that land on another XCD than the chain's compute the 128 x 128 tiles of `rider` — ONE
+ * mst_gemm_nt problem that nothing in the chain reads (M, N multiples of 128, K of 64; 16-bit C; bias, alpha, a residual and
+ * row remaps in whole tiles only) — from a work queue (`queue`: ONE zeroed device word, in another cache line than `sync`);
+ * the chain's own workgroups pass by the queue when they are done, so every tile is computed by the end of the launch wherever
+ * the workgroups land. The training step rides the decoder's K | Q | V projection of rows 1..T (transformer.py:88-93; its input
+ * rows exist since the step's first launch) on the forward tail and that projection's input gradient on the backward tail:
+ * two launches (12 + 10 us) less in the step's dependent chain. Same results as mst_gemm_nt, bit for bit. */
+int mst_row_tail_fwd_ride(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream);
 /* The same rows on the way back: autograd of mst_row_tail_fwd's chain for the gradient `dy` of the layer's output rows —
  *     mst_layernorm_bwd (LayerNorm-2; dh, its dropout-masked copy dhm, dgamma2 / dbeta2 +=)
  *  -> mst_gemm_nt(dhm, W2t, gate = a, alpha = 1 / (1 - p))   d(pre)                 [B, 4 D]
@@ -491,6 +527,7 @@ typedef struct mst_row_tail_bwd_args {
   uint32_t* status;  /* optional, as above */
 } mst_row_tail_bwd_args;
 int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream);
+int mst_row_tail_bwd_ride(const mst_row_tail_bwd_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Incremental decode (inference; model.py:259-272, transformer.py:70-77,242-249): the new position's query against the

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("self_resid", c_i32),
         ("dropout_seed_ptr", vp),
         ("a_u8", c_i32),
+        ("resid_phys", c_i32),
     ]
 
 
@@ -171,7 +172,9 @@ SIGNATURES = {
     "mst_gemm_sigmoid_bce": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), vp]),
     "mst_gemm_sigmoid_bce_dgrad_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
+    "mst_row_tail_fwd_ride": (C.c_int, [C.POINTER(RowTailArgs), C.POINTER(GemmArgs), vp, vp]),
     "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),
+    "mst_row_tail_bwd_ride": (C.c_int, [C.POINTER(RowTailBwdArgs), C.POINTER(GemmArgs), vp, vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_ffn_ln_bwd_lead": (C.c_int, [C.POINTER(LnBwdIn), C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
@@ -189,6 +192,8 @@ SIGNATURES = {
     "mst_outer_jobs": (C.c_int, [C.POINTER(OuterJob), C.c_int, vp]),
     "mst_latent_bwd_vec": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_f32,
                                      c_f32, vp, c_i64, vp, c_i64, vp, vp]),
+    "mst_latent_bwd_vec_proj": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, c_i64,
+                                          c_f32, c_f32, c_f32, c_f32, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_embed_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_f32,
                                 vp, c_i64, c_i64, c_i64, vp, vp]),
     "mst_embed_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, vp, vp, c_i64, vp, vp, c_i64, c_f32,
@@ -207,6 +212,8 @@ SIGNATURES = {
                                     vp, c_i64, vp, vp, C.c_int, c_f32, c_u64, c_u32, vp, c_i64, vp, vp]),
     "mst_latent_fwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
                                  vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp]),
+    "mst_latent_fwd_proj": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i64,
+                                      vp, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, vp]),
     "mst_latent_bwd": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp,
                                  vp, c_i64, c_f32, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp, vp]),
     "mst_reparam_kl_fwd": (C.c_int, [c_i64, c_i64, vp, vp, vp, vp, vp, vp]),

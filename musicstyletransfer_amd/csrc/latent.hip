@@ -107,6 +107,41 @@ __device__ __forceinline__ f32x4 strided_col_dot4(const float* v, const float* _
   return acc;
 }
 
+// out[j] = sum_k x[k] * W[j, k] for 16-bit rows of W with n_in = 64 * VEC (VEC even: 4-byte pieces), U outputs per wave and pass with
+// all U * VEC / 2 loads of a lane in flight before the first is consumed
+template <typename T, int U, int VEC, typename F>
+__device__ __forceinline__ void wave_dots_row(const float* x, const T* __restrict__ W, int64_t ldw, int n_out, int wave, int n_waves, int lane,
+                                              F&& emit) {
+  static_assert(VEC % 2 == 0, "a lane's piece of a row is whole 4-byte words");
+  float xs[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) xs[e] = x[lane * VEC + e];
+  for (int j0 = wave * U; j0 < n_out; j0 += n_waves * U) {
+    uint32_t w[U][VEC / 2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(W + (int64_t)(j0 + u < n_out ? j0 + u : n_out - 1) * ldw + lane * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC / 2; ++e) w[u][e] = row[e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC / 2; ++e) {
+        acc = fmaf(xs[2 * e], bits_to_f32<T>((uint16_t)(w[u][e] & 0xffffu)), acc);
+        acc = fmaf(xs[2 * e + 1], bits_to_f32<T>((uint16_t)(w[u][e] >> 16)), acc);
+      }
+      const float v = wave_sum(acc);
+      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
+    }
+  }
+}
+
+struct LatentDx0 {  // (optional) what latent_bwd_vec_kernel computes d(dec_in[b, 0, :]) from instead of reading it
+  const void* dq; int64_t dq_stride; const void* Wq; int64_t ld_wq; int nq; const void* resid; int64_t resid_stride;
+};
+
 template <typename T, bool PRE>
 __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int Z, int Dd, const float* __restrict__ Wl,
                                                                      const float* __restrict__ eps,
@@ -118,7 +153,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
                                                                      float enc_scale, float* __restrict__ tvec,
                                                                      float* __restrict__ dlat, T* __restrict__ d_enc_out,
                                                                      int64_t denc_stride, const int32_t* __restrict__ classes,
-                                                                     float* __restrict__ dcls, int64_t ld_cls) {
+                                                                     float* __restrict__ dcls, int64_t ld_cls, LatentDx0 x0) {
   extern __shared__ float sm[];
   float* t = sm;             // [Dd]
   float* dl = sm + Dd;       // [2Z]
@@ -132,6 +167,34 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
   const int zc = Z < LAT_THREADS ? Z : LAT_THREADS, np_h = LAT_THREADS / zc > 0 ? LAT_THREADS / zc : 1;
   const int dc = De < LAT_THREADS ? De : LAT_THREADS, np_l = LAT_THREADS / dc > 0 ? LAT_THREADS / dc : 1;
   constexpr bool pre = PRE;  // host: latent_bwd_pre_shape
+  // (the computed form of d(dec_in) runs BEFORE the weight preloads below: with both live the kernel spilled 15 registers, and a
+  // dispatch that needs scratch memory costs ~15 us more on this stack)
+  if (x0.dq) {
+    // d(dec_in[b, 0, :]) is not read but COMPUTED: dq[b, 0, :] (the gradient of the decoder's first K | Q | V projection at position 0,
+    // nq values) against Wt [Dd, nq] (the TRANSPOSED 16-bit weight: row j holds what output j contracts, contiguous) plus the
+    // residual branch's row, rounded to the activation type as the GEMM launch this replaces rounds it (mst_latent_bwd_vec_proj:
+    // that launch's other B T rows ride on the backward tail). A wave per 8 outputs, a lane owns nq / 64 consecutive inputs
+    // (12-byte pieces of a row at the decoder's width 128), every weight load of the pass in flight before the first is used.
+    const T* __restrict__ dq = reinterpret_cast<const T*>(x0.dq) + b * x0.dq_stride;
+    for (int k = tid; k < x0.nq; k += LAT_THREADS) part[k] = to_f32(dq[k]);  // (`part` is free until the dz product below)
+    // (the residual row waits in t[]: a load per OUTPUT inside emit was a chain of dependent round trips on lane 0)
+    const T* __restrict__ rs = x0.resid ? reinterpret_cast<const T*>(x0.resid) + b * x0.resid_stride : nullptr;
+    for (int j = tid; j < Dd; j += LAT_THREADS) t[j] = rs ? to_f32(rs[j]) : 0.f;
+    __syncthreads();
+    // (emit only fills t[]: tvec and the class table's atomics go out below as whole-wave instructions — as 128 single-lane
+    // atomics per workgroup on the same eight cache lines they serialised in the L2 for 16 us)
+    auto emit = [&](int j, float a) { t[j] = alpha_d * to_f32(from_f32<T>(a + t[j])); };
+    const T* Wt = reinterpret_cast<const T*>(x0.Wq);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (x0.nq == 6 * 64) wave_dots_row<T, 8, 6>(part, Wt, x0.ld_wq, Dd, wave, LAT_THREADS / 64, lane, emit);
+    else wave_dots_row<T, 8, 12>(part, Wt, x0.ld_wq, Dd, wave, LAT_THREADS / 64, lane, emit);  // (host: nq is 384 or 768)
+    __syncthreads();
+    for (int j = tid; j < Dd; j += LAT_THREADS) {
+      const float v = t[j];
+      tvec[b * Dd + j] = v;
+      if (dcls) atomicAdd(dcls + (int64_t)classes[b] * ld_cls + j, v);
+    }
+  }
   float wh[PRE_H], wl[PRE_L], m_r = 0.f, s_r = 0.f, e_r = 0.f;
   if constexpr (pre) {
     const int i = tid % zc, pt = tid / zc;
@@ -148,6 +211,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_vec_kernel(int De, int
     }
     if (tid < Z) { m_r = mu[b * Z + tid]; s_r = sigma[b * Z + tid]; e_r = eps[b * Z + tid]; }
   }
+  if (!x0.dq)
   for (int j = tid; j < Dd; j += LAT_THREADS) {
     const float v = alpha_d * to_f32(d_dec_in[b * dec_stride + j]);
     t[j] = v;
@@ -256,15 +320,18 @@ __global__ __launch_bounds__(256) void latent_param_grads_kernel(int64_t B, int 
 
 using namespace mst;
 
-extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out,
-                              int64_t enc_sample_stride, const float* Wl, const float* bl, const float* eps,
-                              const float* Wh, const float* bh, const int32_t* classes, const float* cls_d,
-                              int64_t ld_cls, const float* pos_d, float alpha_d, float* mu, float* sigma, float* z,
-                              float* kl, void* dec_in, int64_t dec_sample_stride, mst_stream_t stream) {
+static int latent_fwd_impl(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out,
+                           int64_t enc_sample_stride, const float* Wl, const float* bl, const float* eps,
+                           const float* Wh, const float* bh, const int32_t* classes, const float* cls_d,
+                           int64_t ld_cls, const float* pos_d, float alpha_d, float* mu, float* sigma, float* z,
+                           float* kl, void* dec_in, int64_t dec_sample_stride, const void* Wq, int64_t ld_wq, const float* bq, void* qkv0,
+                           int64_t qkv_sample_stride, int64_t nq, mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_fwd: sizes must be positive");
   MST_CHECK_ARG(enc_out && Wl && bl && eps && Wh && bh && classes && cls_d && pos_d && mu && sigma && z && kl && dec_in,
                 "mst_latent_fwd: null pointer");
-  const size_t lds = sizeof(float) * (De + 3 * Z);
+  MST_CHECK_ARG(!Wq || (qkv0 && nq > 0 && (Dd == 64 || Dd == 128 || Dd == 256) && ld_wq >= Dd && ((uintptr_t)Wq % 8) == 0 && ld_wq % 4 == 0),
+                "mst_latent_fwd_proj: the row-0 projection takes a decoder width of 64, 128 or 256 and an 8-byte aligned weight");
+  const size_t lds = sizeof(float) * (De + 3 * Z + (Wq ? Dd + nq : 0));
   MST_CHECK_ARG(lds <= 60000, "mst_latent_fwd: De + 3Z too large for one workgroup");
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
@@ -273,11 +340,30 @@ extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
     la.Wl = Wl; la.bl = bl; la.eps = eps; la.Wh = Wh; la.bh = bh; la.classes = classes; la.cls_d = cls_d; la.ld_cls = ld_cls;
     la.pos_d = pos_d; la.alpha_d = alpha_d; la.mu = mu; la.sigma = sigma; la.z = z; la.kl = kl; la.dec_in = dec_in;
     la.dec_stride = dec_sample_stride;
+    la.Wq = Wq; la.ld_wq = ld_wq; la.bq = bq; la.qkv0 = qkv0; la.qkv_stride = qkv_sample_stride; la.nq = (int)nq;
     if (latent_fwd_pre_shape(De, Z, Dd)) hipLaunchKernelGGL((latent_fwd_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, la);
     else hipLaunchKernelGGL((latent_fwd_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, la);
     MST_CHECK_LAUNCH("latent_fwd_kernel");
     return MST_OK;
   });
+}
+extern "C" int mst_latent_fwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out,
+                              int64_t enc_sample_stride, const float* Wl, const float* bl, const float* eps,
+                              const float* Wh, const float* bh, const int32_t* classes, const float* cls_d,
+                              int64_t ld_cls, const float* pos_d, float alpha_d, float* mu, float* sigma, float* z,
+                              float* kl, void* dec_in, int64_t dec_sample_stride, mst_stream_t stream) {
+  return latent_fwd_impl(dtype, B, De, Z, Dd, enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d, alpha_d, mu, sigma, z,
+                         kl, dec_in, dec_sample_stride, nullptr, 0, nullptr, nullptr, 0, 0, stream);
+}
+extern "C" int mst_latent_fwd_proj(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out,
+                                   int64_t enc_sample_stride, const float* Wl, const float* bl, const float* eps,
+                                   const float* Wh, const float* bh, const int32_t* classes, const float* cls_d,
+                                   int64_t ld_cls, const float* pos_d, float alpha_d, float* mu, float* sigma, float* z,
+                                   float* kl, void* dec_in, int64_t dec_sample_stride, const void* Wq, int64_t ld_wq, const float* bq,
+                                   void* qkv0, int64_t qkv_sample_stride, int64_t nq, mst_stream_t stream) {
+  MST_CHECK_ARG(Wq != nullptr, "mst_latent_fwd_proj: null projection weight");
+  return latent_fwd_impl(dtype, B, De, Z, Dd, enc_out, enc_sample_stride, Wl, bl, eps, Wh, bh, classes, cls_d, ld_cls, pos_d, alpha_d, mu, sigma, z,
+                         kl, dec_in, dec_sample_stride, Wq, ld_wq, bq, qkv0, qkv_sample_stride, nq, stream);
 }
 
 extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const void* enc_out,
@@ -303,11 +389,11 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
     if (latent_bwd_pre_shape(De, Z, Dd))
       hipLaunchKernelGGL((latent_bwd_vec_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
                          eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
-                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0, LatentDx0{});
     else
       hipLaunchKernelGGL((latent_bwd_vec_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, s, (int)De, (int)Z, (int)Dd, Wl,
                          eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale, tvec,
-                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+                         dlat, (T*)d_enc_out, denc_sample_stride, (const int32_t*)nullptr, (float*)nullptr, (int64_t)0, LatentDx0{});
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     hipLaunchKernelGGL((latent_param_grads_kernel<T>), dim3((unsigned)(n_wl + n_wh + n_cls)), dim3(256), 0, s, B, (int)De, (int)Z,
                        (int)Dd, dlat, (const T*)enc_out, enc_sample_stride, tvec, z, classes, dWl, dbl, dWh, dbh, dcls_d, ld_cls,
@@ -317,28 +403,50 @@ extern "C" int mst_latent_bwd(int dtype, int64_t B, int64_t De, int64_t Z, int64
   });
 }
 
-extern "C" int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps,
-                                  const float* Wh, const int32_t* classes, const float* mu, const float* sigma,
-                                  const void* d_dec_in, int64_t dec_sample_stride, float alpha_d, float kl_weight, float gscale,
-                                  float enc_scale, float* dcls_d, int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride,
-                                  float* scratch, mst_stream_t stream) {
+static int latent_bwd_vec_impl(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps,
+                               const float* Wh, const int32_t* classes, const float* mu, const float* sigma,
+                               const void* d_dec_in, int64_t dec_sample_stride, float alpha_d, float kl_weight, float gscale,
+                               float enc_scale, float* dcls_d, int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride,
+                               float* scratch, const LatentDx0& x0, mst_stream_t stream) {
   MST_CHECK_ARG(B > 0 && De > 0 && Z > 0 && Dd > 0, "mst_latent_bwd_vec: sizes must be positive");
-  MST_CHECK_ARG(Wl && eps && Wh && classes && mu && sigma && d_dec_in && dcls_d && d_enc_out && scratch, "mst_latent_bwd_vec: null pointer");
+  MST_CHECK_ARG(Wl && eps && Wh && classes && mu && sigma && (d_dec_in || x0.dq) && dcls_d && d_enc_out && scratch, "mst_latent_bwd_vec: null pointer");
   MST_CHECK_ARG(Z <= LAT_THREADS, "mst_latent_bwd_vec: latent size above %d", LAT_THREADS);
+  MST_CHECK_ARG(!x0.dq || (x0.Wq && (x0.nq == 384 || x0.nq == 768) && x0.ld_wq >= x0.nq && x0.ld_wq % 2 == 0 && ((uintptr_t)x0.Wq % 4) == 0),
+                "mst_latent_bwd_vec_proj: the projection must have 384 or 768 outputs (decoder width 128 or 256) and a 4-byte aligned transposed weight");
   const size_t lds = sizeof(float) * (Dd + 2 * Z + (latent_bwd_pre_shape(De, Z, Dd) ? 1 : 4) * LAT_THREADS + 4);  // (+ 4: the float4 view's alignment)
   return dispatch_act(dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
     if (latent_bwd_pre_shape(De, Z, Dd))
       hipLaunchKernelGGL((latent_bwd_vec_kernel<T, true>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
                          (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
-                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
+                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls, x0);
     else
       hipLaunchKernelGGL((latent_bwd_vec_kernel<T, false>), dim3((unsigned)B), dim3(LAT_THREADS), lds, (hipStream_t)stream, (int)De, (int)Z,
                          (int)Dd, Wl, eps, Wh, mu, sigma, (const T*)d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
-                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls);
+                         scratch, scratch + B * Dd, (T*)d_enc_out, denc_sample_stride, classes, dcls_d, ld_cls, x0);
     MST_CHECK_LAUNCH("latent_bwd_vec_kernel");
     return MST_OK;
   });
+}
+extern "C" int mst_latent_bwd_vec(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps,
+                                  const float* Wh, const int32_t* classes, const float* mu, const float* sigma,
+                                  const void* d_dec_in, int64_t dec_sample_stride, float alpha_d, float kl_weight, float gscale,
+                                  float enc_scale, float* dcls_d, int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride,
+                                  float* scratch, mst_stream_t stream) {
+  MST_CHECK_ARG(d_dec_in != nullptr, "mst_latent_bwd_vec: null pointer");
+  return latent_bwd_vec_impl(dtype, B, De, Z, Dd, Wl, eps, Wh, classes, mu, sigma, d_dec_in, dec_sample_stride, alpha_d, kl_weight, gscale, enc_scale,
+                             dcls_d, ld_cls, d_enc_out, denc_sample_stride, scratch, LatentDx0{}, stream);
+}
+extern "C" int mst_latent_bwd_vec_proj(int dtype, int64_t B, int64_t De, int64_t Z, int64_t Dd, const float* Wl, const float* eps,
+                                       const float* Wh, const int32_t* classes, const float* mu, const float* sigma,
+                                       const void* dq0, int64_t dq_sample_stride, const void* Wq, int64_t ld_wq, int64_t nq,
+                                       const void* resid0, int64_t resid_sample_stride, float alpha_d, float kl_weight, float gscale,
+                                       float enc_scale, float* dcls_d, int64_t ld_cls, void* d_enc_out, int64_t denc_sample_stride,
+                                       float* scratch, mst_stream_t stream) {
+  MST_CHECK_ARG(dq0 != nullptr && Wq != nullptr, "mst_latent_bwd_vec_proj: null pointer");
+  LatentDx0 x0 = {dq0, dq_sample_stride, Wq, ld_wq, (int)nq, resid0, resid_sample_stride};
+  return latent_bwd_vec_impl(dtype, B, De, Z, Dd, Wl, eps, Wh, classes, mu, sigma, nullptr, 0, alpha_d, kl_weight, gscale, enc_scale, dcls_d, ld_cls,
+                             d_enc_out, denc_sample_stride, scratch, x0, stream);
 }
 
 namespace mst {

@@ -23,6 +23,7 @@
 // from earlier launches and are read with plain loads. The G workgroups are co-resident by construction (G <= 16 << 256).
 #include <math.h>
 #include "common.hpp"
+#include "gemm_tile.hpp"
 
 namespace mst {
 
@@ -171,15 +172,46 @@ __device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
     uint32_t seen = 0u;
     __hip_atomic_compare_exchange_strong(sync + 1, &seen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t claimed = seen == 0u ? xcc : seen;
-    int r = -1;
+    int r = -1;  // -1: another XCD (free to do riding work), -2: the claimed XCD without a role (leaves: its L2 is the chain's)
     if (claimed == xcc) {
       const uint32_t k = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k < (uint32_t)G) r = (int)k;
+      r = k < (uint32_t)G ? (int)k : -2;
     }
     role = r;
   }
   __syncthreads();
   return role;
+}
+
+// RIDERS. A tail launch keeps ONE XCD busy for ~26 us of dependent round trips while seven idle. Work that nothing in the chain
+// waits for can use them: the workgroups that join on another XCD, instead of leaving, take 128 x 128 tiles of ONE GEMM
+// (mst_gemm_args `g`: the decoder's K | Q | V projection of rows 1..T behind the forward tail, the input gradient of that
+// projection behind the backward tail — both were launches of their own in the step's dependent chain, 12 and 10 us) from a
+// work queue (`counter`: a zeroed device word in a cache line of its OWN — next to the barrier words, the riders' first 224 ticket
+// atomics queued in front of the chain's barrier arrivals: +3 us on the launch) until it is empty. 16 waves as a 2 x 8 grid of 64 x 16 wave tiles, the
+// tile code of gemm_nt.hip (gemm_tile.hpp); the tails' own participants never touch it. A tile's result does not depend on who
+// computes it or when, so the launch stays deterministic; and the chain's own participants pass by the queue when they are done
+// (normally empty by then), so every tile is computed by the end of the launch even if NO workgroup landed on another XCD.
+// BM = 256 (4 x 4 waves of 64 x 32, the epilogue staged one 64-row block at a time): for GEMMs with more 128 x 128 tiles than riders —
+// a tile is a chain of dependent latencies (~9 us whatever its size) and a 16-wave workgroup has a CU to itself, so ONE round of
+// bigger tiles ends long before two rounds of small ones (the decoder projection: 192 tiles on 224 riders instead of 384).
+template <typename T, int BM>
+__device__ __forceinline__ void tail_ride_bm(const mst_gemm_args& g, int n_tiles, uint32_t* counter, unsigned char* smem) {
+  constexpr int BN = 128, WGM = BM == 256 ? 4 : 2, WGN = 16 / WGM, PATH = BM == 256 ? 4 : 1;
+  __shared__ int s_tile;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile >= n_tiles) return;
+    f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
+    int64_t m0, n0;
+    float bias_pre[8];
+    gemm_bias_preload<BM, BN>(g, bias_pre, tile);
+    gemm_mainloop<T, BM, BN, WGM, WGN, 64, true, false>(g, smem, acc, m0, n0, tile);
+    gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(g, smem, acc, m0, n0, bias_pre);
+    __syncthreads();  // (the epilogue's staging tile is the next tile's first K stage; s_tile is rewritten)
+  }
 }
 __device__ __forceinline__ void store8_l2(void* p, u32x2 v) {
   asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
@@ -203,6 +235,22 @@ __device__ __forceinline__ void l2_wait(V (&r)[N]) {  // the *_nowait destinatio
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : : "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : : "memory");
+}
+
+// The chain's participants at the end of their kernel: every tile of the rider must have been HANDED OUT by then (whoever took one
+// finishes it before the launch ends). The queue counter is looked at with a load requested at the START of the chain's last stage
+// (`seen`, thread 0; sc1: the riders' atomics live behind the L2s) — normally it already shows an empty queue and the participants
+// leave without another round trip (an atomic here cost the launch ~2 us); if it does not — or if no workgroup ever landed on
+// another XCD, so that nobody rode — they take tiles themselves until the queue is empty.
+template <typename T, int BM>
+__device__ __forceinline__ void tail_drain(const mst_gemm_args& g, int n_tiles, uint32_t* counter, uint32_t& seen, unsigned char* smem) {
+  __shared__ int s_drain;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
+    s_drain = seen < (uint32_t)n_tiles;
+  }
+  __syncthreads();
+  if (s_drain) tail_ride_bm<T, BM>(g, n_tiles, counter, smem);
 }
 
 // LayerNorm of one row held as 4 elements per lane (D = 256) or 2 (D = 128): layernorm_fwd_kernel's arithmetic
@@ -261,8 +309,9 @@ __device__ __forceinline__ f32x4 quarter_sum(float* sP, const f32x4& part, int w
   return acc;
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q) {
+// RIDE: 0, or the rider tile's rows (128 / 256) — one rider form per kernel: both in one made the register allocator spill
+template <typename T, int D, int RIDE = 0>
+__global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q, mst_gemm_args ride, int ride_tiles, uint32_t* ride_queue) {
   constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64;
   constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;  // k-steps per K quarter of the two 16-column stages
   __shared__ __attribute__((aligned(16))) T sX1[64 * LDX];  // LayerNorm-1 output of every row (FFN1's operand, FFN2's residual)
@@ -275,7 +324,13 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
   const int g = tail_join(q.sync, G);
-  if (g < 0) return;
+  if (g < 0) {
+    if constexpr (RIDE != 0) {
+      extern __shared__ __attribute__((aligned(16))) unsigned char ride_smem[];
+      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, ride_smem);
+    }
+    return;
+  }
   for (int i = tid; i < D; i += TAIL_WAVES * 64) {
     sPar[i] = q.bp[i]; sPar[D + i] = q.g1[i]; sPar[2 * D + i] = q.be1[i];
     sPar[3 * D + i] = q.b2[i]; sPar[4 * D + i] = q.g2[i]; sPar[5 * D + i] = q.be2[i];
@@ -454,6 +509,8 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
   TAIL_STAMP(5);
   grid_sync(q.sync, 3 * G, q.status, MST_TAIL_SPIN_FWD);
   TAIL_STAMP(6);
+  uint32_t ride_seen = 0u;  // (riders) the tile queue's counter as of now: tail_drain
+  if constexpr (RIDE != 0) { if (tid == 0) load4_sc1_nowait(ride_seen, ride_queue); }
 
   // ---------------- stage 4: x2 = LN2(h2), rows dealt to the workgroups
   for (int r = g + G * wave; r < B; r += TAIL_WAVES * G) {
@@ -468,6 +525,11 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
     if (lane == 0) { q.mean2[(int64_t)r * q.stat_stride] = mean; q.rstd2[(int64_t)r * q.stat_stride] = rstd; }
   }
   TAIL_STAMP(7);
+  if constexpr (RIDE != 0) {  // the chain is done: whatever the riders left in the queue (normally nothing)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ride_smem[];
+    __syncthreads();
+    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, ride_smem);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -477,8 +539,8 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q)
 // columns of the FFN2 dgrad and 16 output columns of the FFN1 and W_proj dgrads; both LayerNorm backward passes are
 // recomputed by every workgroup on all rows (their results are the next GEMM's operand, kept in LDS), so only two results
 // cross a grid barrier: d(pre-activation) and the FFN1 dgrad's output. The workgroup's FFN2-dgrad weights wait in LDS.
-template <typename T, int D>
-__global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_args q) {
+template <typename T, int D, int RIDE = 0>
+__global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_args q, mst_gemm_args ride, int ride_tiles, uint32_t* ride_queue) {
   constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64, RPW = 4;
   constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
@@ -492,7 +554,12 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 3, wq = wave >> 2;
   const int g = tail_join(q.sync, G);
-  if (g < 0) return;
+  if (g < 0) {
+    if constexpr (RIDE != 0) {
+      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, tail_smem);
+    }
+    return;
+  }
   const int li = lane & 15, lq = lane >> 4;
   const int B = (int)q.B;
   const int m = mi * 16 + li;
@@ -682,6 +749,8 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   TAIL_STAMP(4);
   grid_sync(q.sync, 2 * G, q.status, MST_TAIL_SPIN_BWD);
   TAIL_STAMP(5);
+  uint32_t ride_seen = 0u;  // (riders) the tile queue's counter as of now: tail_drain
+  if constexpr (RIDE != 0) { if (tid == 0) load4_sc1_nowait(ride_seen, ride_queue); }
 
   // ---------------- stage 4: LayerNorm-1 backward of every row (operand of stage 5 in LDS)
   {
@@ -715,6 +784,10 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
     }
   }
   TAIL_STAMP(7);
+  if constexpr (RIDE != 0) {  // the chain is done: whatever the riders left in the queue (normally nothing)
+    __syncthreads();
+    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, tail_smem);
+  }
 }
 
 }  // namespace mst
@@ -727,7 +800,34 @@ extern "C" int mst_debug_tail_stamps(uint32_t* host_out) {  // diagnostic builds
 }
 #endif
 
-extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream) {
+// a rider GEMM: what tail_ride's tile code takes — whole 128 x 128 tiles, 64-deep K stages, the fast epilogue (16-bit C, bias and / or
+// residual, row remaps whose groups are whole tiles)
+static int check_rider(const char* who, const mst_gemm_args& g, int dtype) {
+  MST_CHECK_ARG(g.dtype == dtype && g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "%s: rider: bad GEMM", who);
+  MST_CHECK_ARG(g.M % 128 == 0 && g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.M * (g.N / 128) < (1ll << 30),
+                "%s: rider: M and N must be multiples of 128, K of 64 (got %lld, %lld, %lld)", who, (long long)g.M, (long long)g.N, (long long)g.K);
+  MST_CHECK_ARG(!g.c_f32 && !g.a_u8 && !g.gate && !g.rowadd && !g.grpadd && g.act == MST_ACT_NONE && g.dropout_p == 0.f && !g.self_resid,
+                "%s: rider: bias, alpha, a residual and row remaps only", who);
+  MST_CHECK_ARG((g.a_rows_per_group <= 0 || g.a_rows_per_group % 128 == 0) && (g.c_rows_per_group <= 0 || g.c_rows_per_group % 128 == 0),
+                "%s: rider: row-remap groups must be whole 128-row tiles", who);
+  const int64_t phys_rows = g.c_rows_per_group > 0 ? (g.M / g.c_rows_per_group) * g.c_group_stride + g.c_group_offset : g.M;
+  MST_CHECK_ARG((uint64_t)phys_rows * (uint64_t)g.N < (1ull << 32) && (!g.resid || (g.ldr % 8 == 0 && (uintptr_t)g.resid % 16 == 0)) &&
+                ((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) % 16 == 0 && (!g.bias || (uintptr_t)g.bias % 16 == 0),
+                "%s: rider: operands must be 16-byte aligned and the output below 2^32 elements", who);
+  return MST_OK;
+}
+constexpr int RIDE_OVERSUBSCRIBE = 16;  // 32 workgroups per XCD: 16 roles on the claimed one, 32 riders on each of the other seven
+// (tile rows, dynamic LDS) of a rider: 256-row tiles when the 128-row ones would need a second round of the ~7 x 32 riding workgroups
+static void ride_shape(const mst_gemm_args& g, int& tiles_signed, size_t& lds) {
+  const int64_t t128 = (g.M / 128) * (g.N / 128);
+  const bool big = t128 > 7 * 32 - 16 && g.M % 256 == 0 && (g.a_rows_per_group <= 0 || g.a_rows_per_group % 256 == 0) &&
+                   (g.c_rows_per_group <= 0 || g.c_rows_per_group % 256 == 0);
+  if (big) { tiles_signed = -(int)((g.M / 256) * (g.N / 128)); lds = (size_t)2 * (256 + 128) * 64 * 2; }  // (the split epilogue stages 64 rows: 34 KB)
+  else { tiles_signed = (int)t128; lds = (size_t)128 * (128 + 4) * 4; }  // the epilogue's fp32 staging tile (> the 64 KB of the two K stages)
+  // (negative: 256-row tiles)
+}
+
+static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr, "mst_row_tail_fwd: null args");
   const mst_row_tail_args& q = *args;
   MST_CHECK_ARG(q.B > 0 && q.B <= 64, "mst_row_tail_fwd: 1..64 rows (got %lld)", (long long)q.B);
@@ -740,17 +840,42 @@ extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stre
                   (uintptr_t)q.a | (uintptr_t)q.h2 | (uintptr_t)q.x2 | (uintptr_t)q.bp | (uintptr_t)q.b1 | (uintptr_t)q.b2) % 16) == 0,
                 "mst_row_tail_fwd: operands must be 16-byte aligned");
   MST_CHECK_ARG(q.dropout_p >= 0.f && q.dropout_p < 1.f && q.phys_stride > 0 && q.stat_stride > 0, "mst_row_tail_fwd: bad dropout / strides");
+  if (rider) {
+    const int rc = check_rider("mst_row_tail_fwd_ride", *rider, q.dtype);
+    if (rc) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
+  const mst_gemm_args none = {};
   return dispatch_act(q.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q);
-    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q);
+    if (rider) {
+      int tiles;
+      size_t rlds;
+      ride_shape(*rider, tiles, rlds);
+      const int wi = (q.D == 256 ? 0 : 1) + (tiles < 0 ? 2 : 0);
+      typedef void (*kern_t)(mst_row_tail_args, mst_gemm_args, int, uint32_t*);
+      const kern_t fns[4] = {&row_tail_fwd_kernel<T, 256, 128>, &row_tail_fwd_kernel<T, 128, 128>, &row_tail_fwd_kernel<T, 256, 256>, &row_tail_fwd_kernel<T, 128, 256>};
+      static size_t opted[4] = {0, 0, 0, 0};
+      if (rlds > opted[wi]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[wi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+        if (e != hipSuccess) { set_error("row_tail_fwd_kernel (riders): LDS opt-in of %zu bytes: %s", rlds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
+        opted[wi] = rlds;
+      }
+      const unsigned grid = (unsigned)(q.D / 16) * RIDE_OVERSUBSCRIBE;
+      hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), rlds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue);
+    } else if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
     MST_CHECK_LAUNCH("row_tail_fwd_kernel");
     return MST_OK;
   });
 }
+extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream) { return row_tail_fwd_impl(args, nullptr, nullptr, stream); }
+extern "C" int mst_row_tail_fwd_ride(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
+  MST_CHECK_ARG(rider != nullptr && queue != nullptr, "mst_row_tail_fwd_ride: null rider / queue word");
+  return row_tail_fwd_impl(args, rider, queue, stream);
+}
 
-extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream) {
+static int row_tail_bwd_impl(const mst_row_tail_bwd_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
   MST_CHECK_ARG(args != nullptr, "mst_row_tail_bwd: null args");
   const mst_row_tail_bwd_args& q = *args;
   MST_CHECK_ARG(q.B > 0 && q.B <= 64, "mst_row_tail_bwd: 1..64 rows (got %lld)", (long long)q.B);
@@ -763,21 +888,42 @@ extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t 
                   (uintptr_t)q.dh | (uintptr_t)q.dhm | (uintptr_t)q.dx1 | (uintptr_t)q.dh1m | (uintptr_t)q.dpre | (uintptr_t)q.dh1 | (uintptr_t)q.datt) % 16) == 0,
                 "mst_row_tail_bwd: operands must be 16-byte aligned");
   MST_CHECK_ARG(q.dropout_p >= 0.f && q.dropout_p < 1.f && q.phys_stride > 0 && q.stat_stride > 0, "mst_row_tail_bwd: bad dropout / strides");
+  if (rider) {
+    const int rc = check_rider("mst_row_tail_bwd_ride", *rider, q.dtype);
+    if (rc) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
+  const mst_gemm_args none = {};
   return dispatch_act(q.dtype, [&](auto tag) -> int {
     typedef decltype(tag) T;
-    const size_t lds = (size_t)2 * 64 * ((size_t)q.D + 8) * 2 + (size_t)16 * 2 * q.D * 4 + (size_t)4 * 64 * 16 * 4 + (size_t)2 * q.D * 4;
-    static size_t opted[2] = {64 * 1024, 64 * 1024};
-    const int wi = q.D == 256 ? 0 : 1;
-    const void* fn = wi == 0 ? reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 256>) : reinterpret_cast<const void*>(&row_tail_bwd_kernel<T, 128>);
+    size_t lds = (size_t)2 * 64 * ((size_t)q.D + 8) * 2 + (size_t)16 * 2 * q.D * 4 + (size_t)4 * 64 * 16 * 4 + (size_t)2 * q.D * 4;
+    int tiles = 0;
+    if (rider) {  // (a workgroup is a participant or a rider: one region)
+      size_t rlds;
+      ride_shape(*rider, tiles, rlds);
+      if (rlds > lds) lds = rlds;
+    }
+    static size_t opted[6] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};
+    const int wi = (q.D == 256 ? 0 : 1) + (rider ? (tiles < 0 ? 4 : 2) : 0);
+    typedef void (*kern_t)(mst_row_tail_bwd_args, mst_gemm_args, int, uint32_t*);
+    const kern_t fns[6] = {&row_tail_bwd_kernel<T, 256>, &row_tail_bwd_kernel<T, 128>, &row_tail_bwd_kernel<T, 256, 128>, &row_tail_bwd_kernel<T, 128, 128>,
+                           &row_tail_bwd_kernel<T, 256, 256>, &row_tail_bwd_kernel<T, 128, 256>};
     if (lds > opted[wi]) {
-      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[wi]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("row_tail_bwd_kernel: LDS opt-in of %zu bytes: %s", lds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
       opted[wi] = lds;
     }
-    if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q);
-    else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q);
+    if (rider) {
+      const unsigned grid = (unsigned)(q.D / 16) * RIDE_OVERSUBSCRIBE;
+      hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), lds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue);
+    } else if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q, none, 0, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q, none, 0, (uint32_t*)nullptr);
     MST_CHECK_LAUNCH("row_tail_bwd_kernel");
     return MST_OK;
   });
+}
+extern "C" int mst_row_tail_bwd(const mst_row_tail_bwd_args* args, mst_stream_t stream) { return row_tail_bwd_impl(args, nullptr, nullptr, stream); }
+extern "C" int mst_row_tail_bwd_ride(const mst_row_tail_bwd_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
+  MST_CHECK_ARG(rider != nullptr && queue != nullptr, "mst_row_tail_bwd_ride: null rider / queue word");
+  return row_tail_bwd_impl(args, rider, queue, stream);
 }

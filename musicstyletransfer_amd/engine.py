@@ -586,9 +586,12 @@ class StepPlan:
         # per-sample reconstruction sums: accumulated with atomics, cleared by the step's first launch (size padded to 16 B);
         # the same zero list clears the grid-barrier words of the one-launch position-0 tails (mst_row_tail_*)
         nb4 = (B + 3) // 4 * 4
-        self._recon_buf = torch.zeros(nb4 + 8, **f32)  # (+ 8 sync words of the position-0 tail launches, zeroed with it by step_begin)
+        # (+ 8 sync words of the position-0 tail launches, zeroed with it by step_begin; + the two tile queues of the tails' riders,
+        # each in a 128-byte line of its own: next to the barrier words their ticket atomics delayed the chain's barriers)
+        self._recon_buf = torch.zeros(nb4 + 8 + 24 + 64, **f32)
         self.recon = self._recon_buf[:B]
-        self.sync_words = self._recon_buf[nb4:].view(torch.int32)
+        self.sync_words = self._recon_buf[nb4: nb4 + 8].view(torch.int32)
+        self.ride_queues = self._recon_buf[nb4 + 32:].view(torch.int32)  # [0]: forward tail's riders, [32]: backward tail's
         self.metric_acc = store.metric_acc  # [sum kl, sum total, count]  (trainer.py:115-116)
         self.track_token_metrics = False  # Trainer: accumulate ppl / acc / topk sums on the device in the CE launch
         # output layer + BCE in one launch when a tile can hold whole rows of pitches of one sample (configs[1]: P 128, T 256)
@@ -606,6 +609,14 @@ class StepPlan:
         # (256 tiles) where B (T + 1) rows were 257 (measured: forward 22.8 -> 18.9 us, backward 24.6 -> 20.3).
         self.skip_row0 = (cfg.d_layers > 0 and T % 64 == 0 and o.ffn_fusion_pays(Dd, 4 * Dd) and
                           os.environ.get("MST_SKIP_ROW0", "1") != "0")
+        # RIDERS on the one-launch position-0 tails (which keep ONE XCD busy for ~26 us each while seven idle): the decoder's first
+        # K | Q | V projection of rows 1..T — its input exists since the step's first launch — is computed by the forward tail
+        # launch's workgroups on the other XCDs (row 0 by the latent block's launch), and the input gradient of that projection for
+        # rows 1..T — which only the decoder embedding's weight gradient reads — by the backward tail's (row 0 inside the latent
+        # block's backward launch): two GEMM launches (12 + 10 us at configs[1]) leave the step's dependent chain. Piano-roll ends.
+        self.ride = (cfg.kind != "token" and cfg.d_layers >= 1 and cfg.e_layers >= 1 and Dd in (128, 256) and
+                     o.can_ride(B * T, 3 * Dd, Dd, T) and o.can_ride(B * T, Dd, 3 * Dd, T) and os.environ.get("MST_TAIL_RIDERS", "1") != "0")
+        self._ride_fwd = self._ride_bwd = False
         self.logits = None if self.fuse_bce else act(B * T, cfg.out_dim)
         self.dlogits = act(B * T, cfg.out_dim)
         if cfg.kind == "token":
@@ -812,13 +823,20 @@ class StepPlan:
         o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, self.keymask_e, L.lse, L.att, B, S, H,
                        D // H, 0, D, 2 * D, q_limit=1)
         self._tail_used["fwd"] = self._tail_on(D)
+        self._ride_fwd = self.ride and self._tail_used["fwd"]
         if self._tail_used["fwd"]:  # W_proj, LN1, FFN1, FFN2, LN2 on the B position-0 rows in one launch (mst_row_tail_fwd)
+            rider = None
+            if self._ride_fwd:  # the decoder's first K | Q | V projection, rows 1..T of every sample (see __init__: ride)
+                Dd, Sd = cfg.d_model, S + 1
+                rider = dict(A=self.x0_d, B=st.fused(st.w16, "decoder.layer0", "weight"), C_out=self.dec[0].qkv, M=B * S, N=3 * Dd, K=Dd,
+                             bias=st.fused(st.w, "decoder.layer0", "bias"), a_remap=(S, Sd, 1), c_remap=(S, Sd, 1))
             o.row_tail_fwd(row0(L.att), row0(x_in), st.h(f"{pre}.att.W_proj.weight"), st.p(f"{pre}.att.W_proj.bias"),
                            st.p(f"{pre}.ln1.gamma"), st.p(f"{pre}.ln1.beta"), st.h(f"{pre}.ff1.weight"), st.p(f"{pre}.ff1.bias"),
                            st.h(f"{pre}.ff2.weight"), st.p(f"{pre}.ff2.bias"), st.p(f"{pre}.ln2.gamma"), st.p(f"{pre}.ln2.beta"),
                            row0(L.h1), row0(L.x1), row0(L.a), row0(L.h2), row0(L.x2), L.mean1, L.rstd1, L.mean2, L.rstd2,
                            self.sync_words[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
-                           dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0, status=st.step_status[0:1])
+                           dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0, status=st.step_status[0:1], rider=rider,
+                           queue=self.ride_queues[0:1])
             return L.x2
         rows = (1, S, 0)  # output row b -> physical row b*S
         o.gemm_nt(row0(L.att), st.h(f"{pre}.att.W_proj.weight"), L.h1, M=B, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
@@ -839,8 +857,11 @@ class StepPlan:
         dh = D // H
         if side == "encoder" and i == self.cfg.e_layers - 1:
             return self._top_encoder_layer_fwd(i, L, x_in)
-        o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
-                       0, D, 2 * D)
+        if side == "decoder" and i == 0 and self._ride_fwd:  # (projected by the forward tail's riders + the latent block's launch)
+            o.attn_fwd(L.qkv, keymask, L.lse, L.att, self.B, S, H, dh, 0, D, 2 * D)
+        else:
+            o.attn_qkv_fwd(x_in, st.fused(st.w16, pre, "weight"), st.fused(st.w, pre, "bias"), L.qkv, keymask, L.lse, L.att, self.B, S, H, dh,
+                           0, D, 2 * D)
         # (Dense + LayerNorm in one launch, ops.gemm_nt_ln_fwd, does not pay in the forward pass: graph-replay timings at
         # M = 16384 are 17.8 vs 19.9 us for N 256 K 256 but 30.3 vs 30.2 for K 1024 and 16.6 vs 13.0 / 21.3 vs 16.5 for
         # N 128, and nothing at step level — the forward LayerNorm is a 7 us launch and the full-row tile costs the GEMM
@@ -868,6 +889,10 @@ class StepPlan:
         o.gemm_nt(L.a, st.h(f"{pre}.ff2.weight"), L.h2, **ff2)
         o.layernorm_fwd(L.h2, st.p(f"{pre}.{ln}.gamma"), st.p(f"{pre}.{ln}.beta"), L.x2, L.mean2, L.rstd2, D=D)
         return L.x2
+
+    def _ride_bwd_planned(self):
+        """the backward tail will run as one launch in this step and can take a rider (decided before it is issued)"""
+        return self.ride and self._tail_on(self.cfg.e_model) and self.fuse_tail_bwd and self.defer_latent_grads
 
     def _row0_groups(self, side, i):
         """row groups of the last decoder layer's row-wise launches (skip_row0): rows 1..T of every T + 1, else None"""
@@ -924,7 +949,10 @@ class StepPlan:
                self.x0_d.view(B, Sd, -1))
         # (the decoder's first K | Q | V projection riding on this launch — rows 1..T exist since the step's first launch — was
         # built and measured at parity: 16-wave workgroups make poor GEMM tiles at K = 128; removed, docs/kernel_notes.md)
-        o.latent_fwd(*lat)
+        proj0 = None
+        if self._ride_fwd:  # ... and position 0 of that projection, on the launch that produces the row
+            proj0 = (st.fused(st.w16, "decoder.layer0", "weight"), st.fused(st.w, "decoder.layer0", "bias"), self.dec[0].qkv.view(B, Sd, -1))
+        o.latent_fwd(*lat, proj=proj0)
         # ---- decoder positions 1..T (model.py:241-245, transformer.py:237)
         if cfg.kind == "token":
             o.embed_fwd(self.tokens, st.p("decoder.embedding.weight"), self.pos_d, self.x0_d.view(B, Sd, -1), 1, sq_d)
@@ -1074,6 +1102,13 @@ class StepPlan:
         if next_ln is not None:  # the layer below starts its backward pass with a LayerNorm backward: run it here
             kw, t_below = next_ln
             o.gemm_nt_ln_bwd(t.dqkv, st.t(f"{pre}.att.W_kqv"), t_below.dh, N=D, K=3 * D, resid=t.dh1, **kw)
+        elif side == "decoder" and i == 0 and self._ride_bwd_planned():
+            # rows 1..T ride on the backward tail's launch (only the decoder embedding's weight gradient reads them), row 0 is
+            # computed inside the latent block's backward launch: backward_early / _top_encoder_layer_bwd
+            T_ = self.T
+            self._bwd_rider = dict(A=t.dqkv, B=st.t(f"{pre}.att.W_kqv"), C_out=dx_in, M=self.B * T_, N=D, K=3 * D, resid=t.dh1, resid_phys=True,
+                                   a_remap=(T_, T_ + 1, 1), c_remap=(T_, T_ + 1, 1))
+            self._bwd_dx0 = (t.dqkv.view(self.B, S, -1), st.t(f"{pre}.att.W_kqv"), t.dh1.view(self.B, S, -1))
         else:
             o.gemm_nt(t.dqkv, st.t(f"{pre}.att.W_kqv"), dx_in, N=D, K=3 * D, resid=t.dh1)
         # the layer's four weight gradients: deferred to the ONE wgrad launch at the end of backward() (their operands
@@ -1106,7 +1141,7 @@ class StepPlan:
                            c.dh, c.dhm, c.dx1, c.dh1m, c.dpre, row0(self.sp_dh1), row0(self.sp_datt), st.grad(f"{pre}.ln1.gamma"),
                            st.grad(f"{pre}.ln1.beta"), st.grad(f"{pre}.ln2.gamma"), st.grad(f"{pre}.ln2.beta"), self.sync_words[4:7],
                            stat_stride=S, phys_stride=S, dropout_p=p, dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0,
-                           status=st.step_status[0:1])
+                           status=st.step_status[0:1], rider=getattr(self, "_bwd_rider", None), queue=self.ride_queues[32:33])
             dff, dproj = c.dhm, c.dh1m
             return self._top_encoder_layer_bwd_rest(i, L, x_in, dx_in, t, next_ln, dff, dproj)
         if p > 0:
@@ -1197,6 +1232,7 @@ class StepPlan:
         self._wgrads.append(o.wgrad_problem(self.dlogits, self.dec_out, st.grad("decoder.output_layer.weight"),
                                             st.grad("decoder.output_layer.bias"), M=B * T, N=cfg.out_dim, K=Dd, b_remap=(T, Sd, 1)))
         dy, tgt, nxt = self.d_dec_out, self.bd_l[0].dx_a, self.bd_l[0].dx_b
+        self._bwd_rider = self._bwd_dx0 = None
         for i in reversed(range(cfg.d_layers)):
             x_in = self.dec[i - 1].x2 if i > 0 else self.x0_d
             below = (self._out_ln_bwd("decoder", i - 1, self.dec[i - 1], Dd, cfg.d_dropout, site_d + 3 * (i - 1), self.bd_l[i - 1], self.Md),
@@ -1219,7 +1255,7 @@ class StepPlan:
             o.latent_bwd_vec(st.p("encoder.latent_proj.weight"), self.eps, st.p("decoder.latent2hid.weight"), self.classes, self.mu,
                              self.sigma, d_x0_d.view(B, Sd, -1), sq_d, self.kl_weight, self.gscale_enc,
                              st.grad("decoder.class2hid.weight"), d_enc.view(B, Se, -1), self.lat_scratch,
-                             enc_scale=self.gscale_enc / self.gscale)
+                             enc_scale=self.gscale_enc / self.gscale, proj=self._bwd_dx0)
             self._outers += o.latent_outer_jobs(self.lat_scratch, self.enc_out.view(B, Se, -1), self.z,
                                                 st.grad("encoder.latent_proj.weight"), st.grad("encoder.latent_proj.bias"),
                                                 st.grad("decoder.latent2hid.weight"), st.grad("decoder.latent2hid.bias"))

@@ -51,7 +51,7 @@ def ld(t):
 # --------------------------------------------------------------------------- GEMMs
 def _gemm_args(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=ACT_NONE, gate=None, alpha=1.0,
                rowadd=None, rowadd_period=0, grpadd=None, grp_index=None, a_remap=(0, 0, 0), c_remap=(0, 0, 0),
-               dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None):
+               dropout_p=0.0, dropout_seed=0, dropout_site=0, self_resid=False, dropout_seed_ptr=None, resid_phys=False):
     g = GemmArgs()
     g.a_u8 = 1 if A.dtype == torch.uint8 else 0  # piano-roll frames: widened to the activation type inside the kernel
     g.dtype = dt(B if g.a_u8 else A)
@@ -75,6 +75,7 @@ def _gemm_args(A, B, C_out, M=None, N=None, K=None, bias=None, resid=None, act=A
     g.c_rows_per_group, g.c_group_stride, g.c_group_offset = c_remap
     g.dropout_p, g.dropout_seed, g.dropout_site = dropout_p, dropout_seed, dropout_site
     g.self_resid = 1 if self_resid else 0
+    g.resid_phys = 1 if resid_phys else 0  # the residual shares C's physical rows (follows c_remap) instead of being indexed by m
     g.dropout_seed_ptr = ptr(dropout_seed_ptr)
     return g
 
@@ -94,18 +95,26 @@ def gemm_nt_pair(first, second, begin=None):
              stream())
 
 
+def can_ride(M, N, K, T=0):
+    """shapes a GEMM riding on a position-0 tail launch takes (mst_row_tail_*_ride): whole 128 x 128 tiles, 64-deep K stages,
+    row-remap groups (T rows) in whole tiles"""
+    return M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and (T == 0 or T % 128 == 0)
+
+
 def can_row_tail(B, D):
     """shapes the one-launch position-0 tail of the top encoder layer exists for (mst_row_tail_fwd)"""
     return D in (128, 256) and 0 < B <= 64
 
 
 def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a, h2, x2, mean1, rstd1, mean2, rstd2, sync, stat_stride,
-                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None):
+                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None, rider=None, queue=None):
     """att / resid / h1 / x1 / a / h2 / x2: [B, width] row views (stride(0) = the row stride in elements) of the layer's
     buffers; sync: THREE zeroed int32 device words (barrier counter — 3 * D / 16 after a complete launch —, claimed XCD,
     roles handed out); status: optional sticky int32 device word the kernel ORs _lib.TAIL_* flags into when it cannot
-    finish"""
-    assert sync.numel() >= 3
+    finish. rider: dict(A=, B=, C_out=, **gemm_nt keywords) — one GEMM nothing in the chain reads, computed by the launch's
+    workgroups on the other seven XCDs (mst_row_tail_fwd_ride); queue: its tile queue, ONE zeroed int32 device word in a
+    cache line of its own (not sync's)"""
+    assert sync.numel() >= 3 and (rider is None or queue is not None)
     q = _lib.RowTailArgs()
     q.dtype, q.B, q.D = dt(att), att.shape[0], Wp.shape[0]
     q.att, q.rs_att, q.resid, q.rs_res = ptr(att), att.stride(0), ptr(resid), resid.stride(0)
@@ -116,15 +125,18 @@ def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a
     q.mean1, q.rstd1, q.mean2, q.rstd2, q.stat_stride = ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2), stat_stride
     q.eps, q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = eps, dropout_p, 0, ptr(dropout_seed_ptr), site0
     q.phys_stride, q.sync, q.status = phys_stride, ptr(sync), ptr(status)
-    call("mst_row_tail_fwd", C.byref(q), stream())
+    if rider is not None:
+        call("mst_row_tail_fwd_ride", C.byref(q), C.byref(_gemm_args(**rider)), ptr(queue), stream())
+    else:
+        call("mst_row_tail_fwd", C.byref(q), stream())
 
 
 def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wpt, dh, dhm, dx1, dh1m, dpre, dh1, datt, dg1, db1, dg2, db2,
-                 sync, stat_stride, phys_stride, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None):
+                 sync, stat_stride, phys_stride, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None, rider=None, queue=None):
     """backward of row_tail_fwd's chain in one launch (mst_row_tail_bwd); dy / h2 / h1 / a / dh1 / datt: [B, width] row views,
     dh / dhm / dx1 / dh1m / dpre: compact [B, width] scratch; sync: THREE zeroed int32 device words (the barrier counter
-    ends at 2 * D / 16); status: as row_tail_fwd"""
-    assert sync.numel() >= 3
+    ends at 2 * D / 16); status, rider, queue: as row_tail_fwd"""
+    assert sync.numel() >= 3 and (rider is None or queue is not None)
     q = _lib.RowTailBwdArgs()
     q.dtype, q.B, q.D = dt(dy), dy.shape[0], Wpt.shape[0]
     q.dy, q.rs_dy = ptr(dy), dy.stride(0)
@@ -139,7 +151,10 @@ def row_tail_bwd(dy, h2, h1, a, mean1, rstd1, mean2, rstd2, g1, g2, W2t, W1t, Wp
     q.dg1, q.db1, q.dg2, q.db2 = ptr(dg1), ptr(db1), ptr(dg2), ptr(db2)
     q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = dropout_p, 0, ptr(dropout_seed_ptr), site0
     q.phys_stride, q.sync, q.status = phys_stride, ptr(sync), ptr(status)
-    call("mst_row_tail_bwd", C.byref(q), stream())
+    if rider is not None:
+        call("mst_row_tail_bwd_ride", C.byref(q), C.byref(_gemm_args(**rider)), ptr(queue), stream())
+    else:
+        call("mst_row_tail_bwd", C.byref(q), stream())
 
 
 def can_fuse_bce(P, T, downweight=False):
@@ -522,12 +537,19 @@ def mask_from_lengths(lens, add, keymask):
 
 
 # --------------------------------------------------------------------------- latent block
-def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in3):
+def latent_fwd(enc_out3, Wl, bl, eps, Wh, bh, classes, cls_d, pos_d, alpha_d, mu, sigma, z, kl, dec_in3, proj=None):
+    """proj = (Wq [nq, Dd] 16-bit, bq, qkv3 [B, S, >= nq]): the decoder's first K | Q | V projection of the row this launch
+    produces (position 0) on the same launch (mst_latent_fwd_proj)"""
     B = enc_out3.shape[0]
     De, Z, Dd = Wl.shape[1], Wh.shape[1], Wh.shape[0]
-    call("mst_latent_fwd", dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
-         ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
-         ptr(kl), ptr(dec_in3), dec_in3.stride(0), stream())
+    args = (dt(enc_out3), B, De, Z, Dd, ptr(enc_out3), enc_out3.stride(0), ptr(Wl), ptr(bl), ptr(eps),
+            ptr(Wh), ptr(bh), ptr(classes), ptr(cls_d), cls_d.stride(0), ptr(pos_d), alpha_d, ptr(mu), ptr(sigma), ptr(z),
+            ptr(kl), ptr(dec_in3), dec_in3.stride(0))
+    if proj is None:
+        call("mst_latent_fwd", *args, stream())
+    else:
+        Wq, bq, qkv3 = proj
+        call("mst_latent_fwd_proj", *args, ptr(Wq), ld(Wq), ptr(bq), ptr(qkv3), qkv3.stride(0), Wq.shape[0], stream())
 
 
 def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d, kl_weight, gscale, dWl, dbl, dWh, dbh,
@@ -540,10 +562,19 @@ def latent_bwd(enc_out3, Wl, eps, Wh, classes, mu, sigma, z, d_dec_in3, alpha_d,
          ptr(scratch), stream())
 
 
-def latent_bwd_vec(Wl, eps, Wh, classes, mu, sigma, d_dec_in3, alpha_d, kl_weight, gscale, dcls_d, d_enc_out3, scratch, enc_scale=1.0):
+def latent_bwd_vec(Wl, eps, Wh, classes, mu, sigma, d_dec_in3, alpha_d, kl_weight, gscale, dcls_d, d_enc_out3, scratch, enc_scale=1.0,
+                   proj=None):
     """latent_bwd's first launch with the decoder class table's gradient folded in (mst_latent_bwd_vec); the other parameter
-    gradients are latent_outer_jobs(...) of the caller's weight-gradient flush"""
+    gradients are latent_outer_jobs(...) of the caller's weight-gradient flush.
+    proj = (dqkv3 [B, S, >= nq], Wt [Dd, nq] the transposed 16-bit weight, resid3 [B, S, Dd] or None): d(dec_in[:, 0, :]) is computed
+    here from the projection's gradient at position 0 instead of being read from d_dec_in3 (mst_latent_bwd_vec_proj)"""
     B, De, Z, Dd = d_dec_in3.shape[0], Wl.shape[1], Wh.shape[1], Wh.shape[0]
+    if proj is not None:
+        dq3, Wt, r3 = proj
+        call("mst_latent_bwd_vec_proj", dt(dq3), B, De, Z, Dd, ptr(Wl), ptr(eps), ptr(Wh), ptr(classes), ptr(mu), ptr(sigma),
+             ptr(dq3), dq3.stride(0), ptr(Wt), ld(Wt), 3 * Dd, ptr(r3), (r3.stride(0) if r3 is not None else 0), alpha_d, kl_weight,
+             gscale, enc_scale, ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3), d_enc_out3.stride(0), ptr(scratch), stream())
+        return
     call("mst_latent_bwd_vec", dt(d_dec_in3), B, De, Z, Dd, ptr(Wl), ptr(eps), ptr(Wh), ptr(classes), ptr(mu), ptr(sigma),
          ptr(d_dec_in3), d_dec_in3.stride(0), alpha_d, kl_weight, gscale, enc_scale, ptr(dcls_d), dcls_d.stride(0), ptr(d_enc_out3),
          d_enc_out3.stride(0), ptr(scratch), stream())

@@ -31,8 +31,40 @@ def close(a, b, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------------------------------ position-0 tail
+def _rider_problem(gpu, dtype, Bg, T, N, K, with_resid, seed):
+    """a GEMM of the kind the training step rides on the tails: rows 1..T of every T + 1 on both sides, bias or residual"""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *sh, sc=1.0, dt=dtype: (torch.randn(*sh, generator=g) * sc).to(dt).to(gpu)
+    Md = Bg * (T + 1)
+    A, W = r(Md, K), r(N, K, sc=0.08)
+    kw = dict(M=Bg * T, N=N, K=K, a_remap=(T, T + 1, 1), c_remap=(T, T + 1, 1))
+    if with_resid:
+        kw.update(resid=r(Md, N), resid_phys=True)  # the residual shares C's physical rows, as in the step
+    else:
+        kw["bias"] = r(N, sc=0.1, dt=torch.float32)
+    return A, W, kw, Md
+
+
+def _check_rider(o, gpu, dtype, A, W, kw, Md, C_ride, sync_word):
+    ref = torch.full((Md, kw["N"]), 3.0, dtype=dtype, device=gpu)
+    o.gemm_nt(A, W, ref, **kw)
+    torch.cuda.synchronize()
+    T = kw["a_remap"][0]
+    assert torch.equal(C_ride, ref), "the riding GEMM must equal mst_gemm_nt bit for bit (row 0 of every sample untouched)"
+    want = A.float() @ W.float().t() + (kw["resid"].float() if "resid" in kw else kw["bias"])  # physical rows on every operand
+    T_ = kw["a_remap"][0]
+    close(C_ride.view(-1, T_ + 1, kw["N"])[:, 1:], want.view(-1, T_ + 1, kw["N"])[:, 1:], 2e-2, 2e-2, "riding GEMM vs torch fp32")
+    tiles = (kw["M"] // 128) * (kw["N"] // 128)
+    if tiles > 7 * 32 - 16 and kw["M"] % 256 == 0 and T % 256 == 0:
+        tiles //= 2  # (row_tail.hip ride_shape: 256-row tiles when the 128-row ones would need a second round of riders)
+    assert int(sync_word.item()) >= tiles  # every tile was handed out (each workgroup that finds the queue empty adds one more)
+    assert (C_ride.view(-1, T + 1, kw["N"])[:, 0] == 3.0).all()
+
+
+@pytest.mark.parametrize("rider", [None, (6, 128, 384, 128), (64, 256, 384, 128), (40, 128, 1024, 256)],
+                         ids=["plain", "rider-small", "rider-step", "rider-many-tiles"])
 @pytest.mark.parametrize("B,S,D,p,dtype", [(64, 8, 256, 0.2, BF), (5, 3, 128, 0.0, BF), (33, 4, 256, 0.2, torch.float16), (16, 2, 128, 0.2, BF)])
-def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
+def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype, rider):
     """mst_row_tail_fwd (W_proj + LN1 + FFN1 + FFN2 + LN2 on the B position-0 rows, one launch with three grid barriers)
     against the five launches it replaces on the same strided rows: the same dropout counters and rounding points; the K
     sums and the LayerNorm sums run in another order (an ulp here and there)"""
@@ -61,11 +93,21 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     o.layernorm_fwd(row0(u["h2"]), g2, be2, row0(u["x2"]), u["m2"], u["r2"], D=D, M=B, row_id_stride=S)
     f = bufs()
     sync = torch.zeros(8, dtype=torch.int32, device=gpu)
+    queue = torch.zeros(64, dtype=torch.int32, device=gpu)[32:]
+    ride = None
+    if rider is not None:
+        # mst_row_tail_fwd_ride: the workgroups on the other seven XCDs compute a GEMM of their own (the decoder's K | Q | V
+        # projection in the step); "many tiles" outlasts the chain, so its participants drain the queue at the end
+        rA, rW, rkw, rMd = _rider_problem(gpu, dtype, *rider, with_resid=False, seed=17)
+        rC = torch.full((rMd, rkw["N"]), 3.0, dtype=dtype, device=gpu)
+        ride = dict(A=rA, B=rW, C_out=rC, **rkw)
     o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(f["h1"]), row0(f["x1"]), row0(f["a"]), row0(f["h2"]),
-                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
-                   dropout_seed_ptr=seedp if p > 0 else None, site0=6)
+                   row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:3], stat_stride=S, phys_stride=S,
+                   dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6, rider=ride, queue=queue[0:1])
     torch.cuda.synchronize()
     assert int(sync[0].item()) == 3 * (D // 16)  # three barriers, every workgroup arrived at each
+    if ride:
+        _check_rider(o, gpu, dtype, rA, rW, rkw, rMd, rC, queue[0])
     # (the 16-column stages sum their K range in four quarters, one per group of waves: another order of the same fp32 sums)
     ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
     for k in ("h1", "x1", "a", "h2", "x2"):
@@ -79,8 +121,10 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     assert (f["h1"].view(B, S, -1)[:, 1:] == 0).all() and (f["a"].view(B, S, -1)[:, 1:] == 0).all()
 
 
+@pytest.mark.parametrize("rider", [None, (6, 128, 128, 384), (64, 256, 128, 384), (40, 128, 1024, 256)],
+                         ids=["plain", "rider-small", "rider-step", "rider-many-tiles"])
 @pytest.mark.parametrize("B,S,D,p,dtype", [(64, 256, 256, 0.2, BF), (64, 8, 128, 0.2, BF), (37, 4, 256, 0.0, BF), (64, 16, 256, 0.1, torch.float16)])
-def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
+def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype, rider):
     """mst_row_tail_bwd (LayerNorm-2 backward, FFN2 / FFN1 dgrads, LayerNorm-1 backward, W_proj dgrad on the B position-0 rows in
     one launch with two grid barriers) against the five launches it replaces on the same strided rows: the same dropout counters
     and MFMA order; the LayerNorm sums run in another order, so results agree to a rounding of the activation type"""
@@ -119,11 +163,19 @@ def test_row_tail_bwd_equals_the_five_launches(gpu, B, S, D, p, dtype):
     o.gemm_nt(dproj, Wpt, u["datt"], M=B, N=D, K=D, c_remap=(1, S, 0))
     f = bufs()
     sync = torch.zeros(8, dtype=torch.int32, device=gpu)
+    queue = torch.zeros(64, dtype=torch.int32, device=gpu)[32:]
+    ride = None
+    if rider is not None:  # (mst_row_tail_bwd_ride: in the step, the input gradient of the decoder's K | Q | V projection, + residual)
+        rA, rW, rkw, rMd = _rider_problem(gpu, dtype, *rider, with_resid=True, seed=19)
+        rC = torch.full((rMd, rkw["N"]), 3.0, dtype=dtype, device=gpu)
+        ride = dict(A=rA, B=rW, C_out=rC, **rkw)
     o.row_tail_bwd(row0(dy), row0(h2), row0(h1), row0(a), m1, r1, m2, r2, g1, g2, W2t, W1t, Wpt, f["dh"], f["dhm"], f["dx1"], f["dh1m"], f["dpre"],
-                   row0(f["dh1"]), row0(f["datt"]), f["dg1"], f["db1"], f["dg2"], f["db2"], sync[4:7], stat_stride=S, phys_stride=S,
-                   dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6)
+                   row0(f["dh1"]), row0(f["datt"]), f["dg1"], f["db1"], f["dg2"], f["db2"], sync[4:7], stat_stride=S,
+                   phys_stride=S, dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6, rider=ride, queue=queue[0:1])
     torch.cuda.synchronize()
     assert int(sync[4].item()) == 2 * (D // 16)  # two barriers, every participating workgroup arrived at each
+    if ride:
+        _check_rider(o, gpu, dtype, rA, rW, rkw, rMd, rC, queue[0])
     assert 1 <= int(sync[5].item()) <= 8 and int(sync[6].item()) >= D // 16  # one XCD claimed, enough workgroups found on it
     keys = ["dh", "dpre", "dx1", "dh1", "datt"] + (["dhm", "dh1m"] if p > 0 else [])
     for k in keys:
