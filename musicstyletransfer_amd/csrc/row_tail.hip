@@ -816,7 +816,15 @@ static int check_rider(const char* who, const mst_gemm_args& g, int dtype) {
                 "%s: rider: operands must be 16-byte aligned and the output below 2^32 elements", who);
   return MST_OK;
 }
-constexpr int RIDE_OVERSUBSCRIBE = 16;  // 32 workgroups per XCD: 16 roles on the claimed one, 32 riders on each of the other seven
+// Grid of a launch with riders: G x over workgroups dealt round-robin over the 8 XCDs, 7/8 of them riders. As few as give every
+// tile a rider of its own (+ one per XCD to spare), at most 16 x G: the launch pays ~0.6 us per 16 extra 1024-thread workgroups
+// (measured: a one-tile rider costs the forward tail +0.6 / +1.3 / +3.5 us at over = 9 / 12 / 16).
+static unsigned ride_grid(int64_t G, int tiles) {
+  int64_t over = (((int64_t)tiles * 8 + 6) / 7 + G - 1) / G + 1;
+  if (over < 9) over = 9;
+  if (over > 16) over = 16;
+  return (unsigned)(G * over);
+}
 // (tile rows, dynamic LDS) of a rider: 256-row tiles when the 128-row ones would need a second round of the ~7 x 32 riding workgroups
 static void ride_shape(const mst_gemm_args& g, int& tiles_signed, size_t& lds) {
   const int64_t t128 = (g.M / 128) * (g.N / 128);
@@ -861,7 +869,7 @@ static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args*
         if (e != hipSuccess) { set_error("row_tail_fwd_kernel (riders): LDS opt-in of %zu bytes: %s", rlds, hipGetErrorString(e)); return MST_ERR_LAUNCH; }
         opted[wi] = rlds;
       }
-      const unsigned grid = (unsigned)(q.D / 16) * RIDE_OVERSUBSCRIBE;
+      const unsigned grid = ride_grid(q.D / 16, tiles < 0 ? -tiles : tiles);
       hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), rlds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue);
     } else if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
     else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
@@ -914,7 +922,7 @@ static int row_tail_bwd_impl(const mst_row_tail_bwd_args* args, const mst_gemm_a
       opted[wi] = lds;
     }
     if (rider) {
-      const unsigned grid = (unsigned)(q.D / 16) * RIDE_OVERSUBSCRIBE;
+      const unsigned grid = ride_grid(q.D / 16, tiles < 0 ? -tiles : tiles);
       hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), lds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue);
     } else if (q.D == 256) hipLaunchKernelGGL((row_tail_bwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q, none, 0, (uint32_t*)nullptr);
     else hipLaunchKernelGGL((row_tail_bwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), lds, s, q, none, 0, (uint32_t*)nullptr);
