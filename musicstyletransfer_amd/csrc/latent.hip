@@ -124,17 +124,17 @@ __device__ __forceinline__ void wave_dots_row(const float* x, const T* __restric
 #pragma unroll
       for (int e = 0; e < VEC / 2; ++e) w[u][e] = row[e];
     }
+    float acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float acc = 0.f;
+      acc[u] = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC / 2; ++e) {
-        acc = fmaf(xs[2 * e], bits_to_f32<T>((uint16_t)(w[u][e] & 0xffffu)), acc);
-        acc = fmaf(xs[2 * e + 1], bits_to_f32<T>((uint16_t)(w[u][e] >> 16)), acc);
+        acc[u] = fmaf(xs[2 * e], bits_to_f32<T>((uint16_t)(w[u][e] & 0xffffu)), acc[u]);
+        acc[u] = fmaf(xs[2 * e + 1], bits_to_f32<T>((uint16_t)(w[u][e] >> 16)), acc[u]);
       }
-      const float v = wave_sum(acc);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
     }
+    reduce_emit<U>(acc, j0, n_out, lane, emit);
   }
 }
 

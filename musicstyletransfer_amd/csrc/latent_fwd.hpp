@@ -12,8 +12,23 @@ constexpr int LAT_THREADS = 1024;  // 16 waves: these kernels are B workgroups o
 constexpr int OPW = 8;             // outputs a wave works on at once
 constexpr int PRE_C = 4;           // 64-lane chunks of a contraction whose weights the forward keeps in registers (De <= 256)
 
+// The U cross-lane sums of a pass, then ONE emit from lanes 0 .. U-1 (lane u: output j0 + u). Reducing and emitting output by output
+// made every reduction wait for the previous emit's memory operation (the swizzle / permute levels and LDS writes share a counter):
+// ~300 cycles x U in a dependent chain — 3 us for the 24 outputs per wave of the latent block's K | Q | V projection.
+template <int U, typename F>
+__device__ __forceinline__ void reduce_emit(const float (&acc)[U], int j0, int n_out, int lane, F&& emit) {
+  static_assert(U <= 64, "one lane per output of the pass");
+  float mine = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float v = wave_sum(acc[u]);
+    if (lane == u) mine = v;
+  }
+  if (lane < U && j0 + lane < n_out) emit(j0 + lane, mine);
+}
+
 // out[j] = sum_d x[d] * W[j, d] for j < n_out: wave w takes outputs [w*U, w*U+U), then strides by n_waves*U;
-// `emit(j, value)` runs on lane 0
+// `emit(j, value)` runs on lane j - j0 of the wave that owns the pass
 template <int U, typename F>
 __device__ __forceinline__ void wave_dots(const float* x, int n_in, const float* __restrict__ W, int n_out, int wave, int n_waves,
                                           int lane, F&& emit) {
@@ -27,11 +42,7 @@ __device__ __forceinline__ void wave_dots(const float* x, int n_in, const float*
       for (int u = 0; u < U; ++u)
         if (j0 + u < n_out) acc[u] = fmaf(xv, W[(int64_t)(j0 + u) * n_in + d], acc[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
-    }
+    reduce_emit<U>(acc, j0, n_out, lane, emit);
   }
 }
 
@@ -67,11 +78,7 @@ __device__ __forceinline__ void wave_dots_pre(const float* x, int n_in, const fl
       for (int k = 0; k < CH; ++k)
         if (lane + 64 * k < n_in) acc[u] = fmaf(xs[k], w[u][k], acc[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
-    }
+    reduce_emit<U>(acc, j0, n_out, lane, emit);
   };
   int j0 = wave * U;
   if (j0 >= n_out) return;
@@ -135,11 +142,7 @@ __device__ __forceinline__ void wave_dots_t(const float* x, const T* __restrict_
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[u] = fmaf(xs[e], bits_to_f32<T>(h[e]), acc[u]);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == 0 && j0 + u < n_out) emit(j0 + u, v);
-    }
+    reduce_emit<U>(acc, j0, n_out, lane, emit);
   }
 }
 
@@ -206,10 +209,14 @@ __device__ __forceinline__ void latent_fwd_wg(const LatentFwdArgs& A, int64_t b,
       for (int k = 0; k < PRE_C; ++k)
         if (lane + k * 64 < De) acc[u] = fmaf(h0[lane + k * 64], w1[u][k], acc[u]);  // same order as wave_dots
     }
+    {  // (all reductions first, ONE write from lanes 0 .. OPW-1: reduce_emit's note)
+      float mine = 0.f;
 #pragma unroll
-    for (int u = 0; u < OPW; ++u) {
-      const float v = wave_sum(acc[u]);
-      if (lane == u && j1 + u < 2 * Z) lat[j1 + u] = v + b1;
+      for (int u = 0; u < OPW; ++u) {
+        const float v = wave_sum(acc[u]);
+        if (lane == u) mine = v;
+      }
+      if (lane < OPW && j1 + lane < 2 * Z) lat[j1 + lane] = mine + b1;
     }
   } else {
     if (De <= 64 * PRE_C) wave_dots_pre<OPW, PRE_C>(h0, De, Wl, 2 * Z, wave, NW, lane, [&](int j, float acc) { lat[j] = acc + bl[j]; });
@@ -237,14 +244,16 @@ __device__ __forceinline__ void latent_fwd_wg(const LatentFwdArgs& A, int64_t b,
   }
   if constexpr (pre2) {
     const float zv = lane < Z ? zs[lane] : 0.f;
+    float mine = 0.f;
 #pragma unroll
     for (int u = 0; u < OPW; ++u) {
       const float v = wave_sum(zv * w2[u]);  // (fmaf(zv, w, 0) of wave_dots)
-      if (lane == u && j1 + u < Dd) {
-        const T o = from_f32<T>(alpha_d * (v + bh2 + cls2) + pos2);
-        dec_in[b * dec_stride + j1 + u] = o;
-        if (proj) x0s[j1 + u] = to_f32(o);
-      }
+      if (lane == u) mine = v;
+    }
+    if (lane < OPW && j1 + lane < Dd) {
+      const T o = from_f32<T>(alpha_d * (mine + bh2 + cls2) + pos2);
+      dec_in[b * dec_stride + j1 + lane] = o;
+      if (proj) x0s[j1 + lane] = to_f32(o);
     }
   } else {
     auto emit2 = [&](int j, float acc) {
