@@ -469,6 +469,18 @@ def run_decode(args):
             e1.sync()
             dev_us = e0.elapsed_ms(e1) * 1e3 / max(len(ts), 1)
     tok_s = n_tok / elapsed
+    # the decode step's roof: a position streams the cache rows it re-gathers (K and V of every hypothesis, positions 0..t, read +
+    # written), attends over them (read once more) and reads the layer's weights; everything else is per-hypothesis rows
+    dcfg = bs.plan.cfg
+    Dd, V = dcfg.d_model, dcfg.out_dim
+    t_avg = (max(ts) + 1) / 2.0 if ts else 1.0
+    cache_bytes = dcfg.d_layers * B * K * t_avg * 2 * Dd * 2 * 3           # gather read + write + attention read, 16-bit K | V
+    weight_bytes = 2.0 * (dcfg.d_layers * 12 * Dd * Dd + V * Dd * 2)        # the layers' 16-bit shadows + embedding and output tables
+    pos_bytes = cache_bytes + weight_bytes + B * K * (V * 4 * 2 + Dd * 2 * 12)
+    roof = {"bound": "hbm", "kernel": "one decoded position (decode step + beam ranking + cache gather: one captured graph)",
+            "achieved": pos_bytes / (dev_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pos_bytes / (dev_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+            "traffic": None, "algorithmic_bytes_per_position": pos_bytes,
+            "note": "latency-bound: ~20 dependent launches of 4-64 workgroups per position (profiles/README.md, decode)"}
     out = {"metric": "decoded tokens/s (beam search, KV-cache decode step)", "value": tok_s, "unit": "tokens/s", "n_gpus": 1,
            "steps": n_pos, "warmup": warm, "ms_per_step": elapsed / n_pos * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -480,7 +492,7 @@ def run_decode(args):
                       "tokens_counted": "live continuations per position (device counters); PAD continuations of finished hypotheses excluded"},
            "hypothesis_positions_per_s": B * K * n_pos / elapsed,
            "device_us_per_position": dev_us, "host_share": 1.0 - dev_us * 1e-6 * n_pos / elapsed,
-           "graphs_captured": len(bs._graphs), "ranking": "device" if smp.on_device else "host"}
+           "graphs_captured": len(bs._graphs), "ranking": "device" if smp.on_device else "host", "roofline": roof}
     print(json.dumps(out), flush=True)
     return 0
 
