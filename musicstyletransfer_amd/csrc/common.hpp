@@ -191,6 +191,44 @@ __host__ __device__ __forceinline__ uint32_t dropout_keep4k(uint32_t key, uint64
   return (uint32_t)((x0 & 0xFFFFu) >= thr) | ((uint32_t)((x0 >> 16) >= thr) << 1) | ((uint32_t)((x1 & 0xFFFFu) >= thr) << 2) |
          ((uint32_t)((x1 >> 16) >= thr) << 3);
 }
+// The four decisions of dropout_keep4k applied in place: t[e] <- keep(4 idx4 + e) ? t[e] * inv_keep : 0. Same words, same fields; what
+// it saves is packing the four comparisons into a nibble and testing its bits again (~15 of the ~58 vector instructions a group of four
+// values costs in an epilogue — the FFN1 chunk epilogue is VALU-issue-bound: SQ_ACTIVE_INST_VALU is 42 % of that launch's SIMD cycles).
+__host__ __device__ __forceinline__ void dropout_apply4(uint32_t key, uint64_t idx4, uint32_t thr, float inv_keep, float (&t)[4]) {
+  const uint32_t x0 = dropout_word(key, 2 * idx4), x1 = dropout_word(key, 2 * idx4 + 1);
+  t[0] = (x0 & 0xFFFFu) >= thr ? t[0] * inv_keep : 0.f;
+  t[1] = (x0 >> 16) >= thr ? t[1] * inv_keep : 0.f;
+  t[2] = (x1 & 0xFFFFu) >= thr ? t[2] * inv_keep : 0.f;
+  t[3] = (x1 >> 16) >= thr ? t[3] * inv_keep : 0.f;
+}
+__host__ __device__ __forceinline__ void dropout_apply4_32(uint32_t key, uint32_t idx4, uint32_t thr, float inv_keep, float (&t)[4]) {
+  const uint32_t x0 = dropout_word32(key, 2 * idx4), x1 = dropout_word32(key, 2 * idx4 + 1);
+  t[0] = (x0 & 0xFFFFu) >= thr ? t[0] * inv_keep : 0.f;
+  t[1] = (x0 >> 16) >= thr ? t[1] * inv_keep : 0.f;
+  t[2] = (x1 & 0xFFFFu) >= thr ? t[2] * inv_keep : 0.f;
+  t[3] = (x1 >> 16) >= thr ? t[3] * inv_keep : 0.f;
+}
+// ... with the index's multiplication done by the caller: premul = (2 idx4) * 0x9E3779B1 mod 2^32 (indices below 2^32). A thread that
+// walks a tile visits indices base + constant, so premul is ONE multiplication plus additions of constants where dropout_word32 spends
+// a quarter-rate v_mul_lo_u32 per word.
+constexpr uint32_t DROPOUT_MUL = 0x9E3779B1u;
+__host__ __device__ __forceinline__ void dropout_apply4_pre(uint32_t key, uint32_t premul, uint32_t thr, float inv_keep, float (&t)[4]) {
+  uint32_t x0 = premul ^ key, x1 = (premul + DROPOUT_MUL) ^ key;
+  x0 ^= x0 >> 16; x0 *= 0x7FEB352Du; x0 ^= x0 >> 15;
+  x1 ^= x1 >> 16; x1 *= 0x7FEB352Du; x1 ^= x1 >> 15;
+  t[0] = (x0 & 0xFFFFu) >= thr ? t[0] * inv_keep : 0.f;
+  t[1] = (x0 >> 16) >= thr ? t[1] * inv_keep : 0.f;
+  t[2] = (x1 & 0xFFFFu) >= thr ? t[2] * inv_keep : 0.f;
+  t[3] = (x1 >> 16) >= thr ? t[3] * inv_keep : 0.f;
+}
+// ... and the same decisions as multipliers: k[e] = keep ? inv_keep : 0
+__host__ __device__ __forceinline__ void dropout_scale4(uint32_t key, uint64_t idx4, uint32_t thr, float inv_keep, float (&k)[4]) {
+  const uint32_t x0 = dropout_word(key, 2 * idx4), x1 = dropout_word(key, 2 * idx4 + 1);
+  k[0] = (x0 & 0xFFFFu) >= thr ? inv_keep : 0.f;
+  k[1] = (x0 >> 16) >= thr ? inv_keep : 0.f;
+  k[2] = (x1 & 0xFFFFu) >= thr ? inv_keep : 0.f;
+  k[3] = (x1 >> 16) >= thr ? inv_keep : 0.f;
+}
 __host__ __device__ __forceinline__ uint32_t dropout_keep4(uint64_t seed, uint32_t site, uint64_t idx4, float p) {
   return dropout_keep4k(dropout_key(seed, site), idx4, dropout_thr(p));
 }

@@ -184,15 +184,16 @@ __device__ __forceinline__ void gemm_epilogue_ln(const mst_gemm_args& a, const m
 #pragma unroll
       for (int e = 0; e < 8; ++e) t[e] = (t[e] + bias8[e]) * a.alpha;
       if (MODE == 1 && (has_drop || a.self_resid)) {
-        uint32_t keep8 = 0xFFu;
+        float u0[4] = {t[0], t[1], t[2], t[3]}, u1[4] = {t[4], t[5], t[6], t[7]};
         if (has_drop) {
           const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;
-          keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
+          dropout_apply4(dkey, w, dthr, inv_keep, u0);
+          dropout_apply4(dkey, w + 1, dthr, inv_keep, u1);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
-          t[e] = a.self_resid ? t[e] + u : u;
+        for (int e = 0; e < 4; ++e) {
+          t[e] = a.self_resid ? t[e] + u0[e] : u0[e];
+          t[4 + e] = a.self_resid ? t[4 + e] + u1[e] : u1[e];
         }
       }
       if (resid || lds_resid) {
@@ -778,11 +779,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc2[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float p1 = g1.dropout_p;
-  const bool drop1 = p1 > 0.f;
+  const bool drop1 = MODE == 1 && p1 > 0.f;  // (the backward form takes neither dropout nor an activation: host check)
   const uint64_t seed1 = g1.dropout_seed ^ ((drop1 && g1.dropout_seed_ptr) ? g1.dropout_seed_ptr[0] : 0ull);
   const uint32_t dkey1 = dropout_key(seed1, g1.dropout_site), dthr1 = dropout_thr(p1);
   const float inv_keep1 = dropout_inv_keep(p1);
-  const bool relu1 = g1.act == MST_ACT_RELU;
+  const bool idx32 = (uint64_t)g1.M * (uint64_t)F < (1ull << 32);  // every element index of the hidden tensor fits 32 bits (uniform)
+  const bool relu1 = MODE == 1 && g1.act == MST_ACT_RELU;
+  const bool step_form1 = MODE == 1 && relu1 && drop1 && idx32 && g1.alpha == 1.f;  // (x * 1.0f == x bit for bit)
+  // dropout counters of this thread's rows, premultiplied (dropout_apply4_pre): ((m0 + row) F / 2) * DROPOUT_MUL mod 2^32 (F % 4 == 0: host check)
+  uint32_t rowmul[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rowmul[i] = (uint32_t)(m0 + wm * WTM + i * 16 + frow) * (uint32_t)(F >> 1) * DROPOUT_MUL;
   T* Aout = reinterpret_cast<T*>(g1.C);
 
   // the KST stages of the extra GEMM (stream position `cx` = -1: in front of the chunks) into acc1
@@ -885,28 +892,44 @@ __global__ __launch_bounds__(WGM * WGN * 64) void ffn_ln_kernel(mst_gemm_args g1
         if constexpr (s == KST - 1) {
           // ---- chunk epilogue of GEMM 1, in registers: bias, ReLU, dropout, rounding (the order of gemm_epilogue) -> sH.
           // (The previous chunk's GEMM-2 stages, which read sH, ended with a barrier.)
+          // Two bodies behind ONE uniform branch: the training step's form (ReLU, alpha 1, dropout, 32-bit counters) without a
+          // select or a multiplication per optional feature, and the general one. (Run-time feature flags inside the element loop
+          // are if-converted into a v_cndmask each: this epilogue is VALU-issue-bound — 592 vector instructions per chunk and wave
+          // before, ~300 in the first body.)
+          auto chunk_epilogue = [&](auto step_form) {
+            constexpr bool STEP = decltype(step_form)::value;
+            const uint32_t cmul = ((uint32_t)pc * (BN / 2) + (uint32_t)((wn * WTN + fq * 4) / 2)) * DROPOUT_MUL;  // this chunk, this lane's columns
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = wn * WTN + j * 16 + fq * 4;   // column within the chunk
-            const int64_t col = (int64_t)pc * BN + n;    // hidden unit
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias1 + col);
+            for (int j = 0; j < TN; ++j) {
+              const int n = wn * WTN + j * 16 + fq * 4;   // column within the chunk
+              const int64_t col = (int64_t)pc * BN + n;    // hidden unit
+              const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias1 + col);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              const int row = wm * WTM + i * 16 + frow;
-              uint32_t keep = 0xFu;
-              if (drop1) keep = dropout_keep4k(dkey1, (uint64_t)((m0 + row) * F + col) >> 2, dthr1);
-              uint16_t hb[4];
+              for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + frow;
+                float tv[4];
+                if constexpr (STEP) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float t = (acc1[j][i][e] + b4[e]) * g1.alpha;
-                if (relu1) t = fmaxf(t, 0.f);
-                if (drop1) t = ((keep >> e) & 1u) ? t * inv_keep1 : 0.f;
-                hb[e] = f32_to_bits<T>(t);
+                  for (int e = 0; e < 4; ++e) tv[e] = fmaxf(acc1[j][i][e] + b4[e], 0.f);
+                  // element index (m0 + row) F + col; the word pair of its group of four = dropout_word32(index / 2), + 1
+                  dropout_apply4_pre(dkey1, rowmul[i] + cmul + (uint32_t)(j * 8) * DROPOUT_MUL, dthr1, inv_keep1, tv);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    tv[e] = (acc1[j][i][e] + b4[e]) * g1.alpha;
+                    if (relu1) tv[e] = fmaxf(tv[e], 0.f);
+                  }
+                  if (drop1) dropout_apply4(dkey1, (uint64_t)((m0 + row) * F + col) >> 2, dthr1, inv_keep1, tv);
+                }
+                uint16_t hb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hb[e] = f32_to_bits<T>(tv[e]);
+                *reinterpret_cast<u32x2*>(sH + row * LDA + n) =
+                    u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
               }
-              *reinterpret_cast<u32x2*>(sH + row * LDA + n) =
-                  u32x2{(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
             }
-          }
+          };
+          if (step_form1) chunk_epilogue(std::true_type()); else chunk_epilogue(std::false_type());
         }
         // the next stage of the stream (requested AHEAD iterations ago) -> the other LDS buffer
         if (!IL && !MST_FFN_EARLY_STORE && more) store_stage((s + 1) & 1, ring[(s + 1) % RING]);

@@ -152,12 +152,15 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
           for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
         }
         if (DROP && (has_drop || a.self_resid)) {
-          uint32_t keep8 = 0xFFu;
-          if (has_drop) keep8 = dropout_keep4k32(dkey, w, dthr) | (dropout_keep4k32(dkey, w + 1, dthr) << 4);
+          float u0[4] = {t[0], t[1], t[2], t[3]}, u1[4] = {t[4], t[5], t[6], t[7]};
+          if (has_drop) {
+            dropout_apply4_32(dkey, w, dthr, inv_keep, u0);
+            dropout_apply4_32(dkey, w + 1, dthr, inv_keep, u1);
+          }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
-            t[e] = a.self_resid ? t[e] + u : u;
+          for (int e = 0; e < 4; ++e) {
+            t[e] = a.self_resid ? t[e] + u0[e] : u0[e];
+            t[4 + e] = a.self_resid ? t[4 + e] + u1[e] : u1[e];
           }
         }
         if (rap) {
@@ -214,15 +217,16 @@ __device__ __forceinline__ void gemm_epilogue(const mst_gemm_args& a, unsigned c
           for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
         }
         if (DROP && (has_drop || a.self_resid)) {
-          uint32_t keep8 = 0xFFu;  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
-          if (has_drop) {
+          float u0[4] = {t[0], t[1], t[2], t[3]}, u1[4] = {t[4], t[5], t[6], t[7]};
+          if (has_drop) {  // N % 4 == 0 when dropout is on: (row*N + nc) starts a 4-decision word
             const uint64_t w = (uint64_t)(pm * a.N + nc) >> 2;  // counter = PHYSICAL output row: survives row remaps
-            keep8 = dropout_keep4k(dkey, w, dthr) | (dropout_keep4k(dkey, w + 1, dthr) << 4);
+            dropout_apply4(dkey, w, dthr, inv_keep, u0);
+            dropout_apply4(dkey, w + 1, dthr, inv_keep, u1);
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float u = ((keep8 >> e) & 1u) ? t[e] * inv_keep : 0.f;
-            t[e] = a.self_resid ? t[e] + u : u;
+          for (int e = 0; e < 4; ++e) {
+            t[e] = a.self_resid ? t[e] + u0[e] : u0[e];
+            t[4 + e] = a.self_resid ? t[4 + e] + u1[e] : u1[e];
           }
         }
         if (has_rowops && a.rowadd) {

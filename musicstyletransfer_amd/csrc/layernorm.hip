@@ -197,13 +197,13 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(int64_t M, int D, c
         const int c = lane + i * 64;
         if (c < nvec) {
           float o[4], om[4];
-          uint32_t keep4 = 0xFu;  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
-          if (mask_mode != 0 && p > 0.f) keep4 = dropout_keep4(seed, site, (uint64_t)(rid * D + c * 4) >> 2, p);
+          float k4[4] = {1.f, 1.f, 1.f, 1.f};  // D % 4 == 0, so (m*D + c*4) is the first element of one 4-decision word
+          if (mask_mode != 0 && p > 0.f) dropout_scale4(dropout_key(seed, site), (uint64_t)(rid * D + c * 4) >> 2, dropout_thr(p), inv_keep, k4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             o[e] = rstd[r] * (g[r][i][e] - s1[r] - xh[r][i][e] * s2[r]);
             if (mask_mode != 0) {
-              const float k = (p > 0.f) ? (((keep4 >> e) & 1u) ? inv_keep : 0.f) : 1.f;
+              const float k = k4[e];
               if (mask_mode == 1) om[e] = o[e] * k; else o[e] = o[e] * (1.f + k);
             }
           }
