@@ -28,7 +28,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(mst_gemm_args a
   int64_t m0, n0;
   float bias_pre[8];
   gemm_bias_preload<BM, BN>(a, bias_pre);
-  gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS, AU8>(a, smem, acc, m0, n0);
+  gemm_mainloop<T, BM, BN, WGM, WGN, BK, ROWOPS, AU8, false, PATH == 1 || PATH == 4>(a, smem, acc, m0, n0);  // (PATH 1, 4: whole tiles, whole K stages)
   // (the launch allocates max(K-loop tiles, BM x (BN+4) fp32 staging) bytes of LDS: launch_gemm)
   gemm_epilogue<T, BM, BN, WGM, WGN, C_F32, ROWOPS, PATH, DROP>(a, smem, acc, m0, n0, bias_pre);
 }
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_pair_kernel(mst_gemm_a
   // (two straight-line copies of the tile, each reading its own argument block from the kernel arguments)
   if (tile < tiles0) {
     gemm_bias_preload<BM, BN>(a0, bias_pre, tile);
-    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a0, smem, acc, m0, n0, tile);
+    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true, false, true>(a0, smem, acc, m0, n0, tile);  // (whole tiles, whole K stages: host check)
     gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a0, smem, acc, m0, n0, bias_pre);
   } else {
     const int64_t bid = tile - tiles0;
     gemm_bias_preload<BM, BN>(a1, bias_pre, bid);
-    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true>(a1, smem, acc, m0, n0, bid);
+    gemm_mainloop<T, BM, BN, WGM, WGN, BK, true, true, false, true>(a1, smem, acc, m0, n0, bid);
     gemm_epilogue<T, BM, BN, WGM, WGN, false, true, PATH, false>(a1, smem, acc, m0, n0, bias_pre);
   }
 }
@@ -1067,7 +1067,7 @@ static int launch_gemm(const mst_gemm_args& a, hipStream_t s) {
   dim3 grid((unsigned)tiles), block(WGM * WGN * 64);
   // ("row ops" in the kernel choice: row-indexed adds or a row remap of A or C)
   const bool rowops = a.rowadd || a.grpadd || a.a_rows_per_group > 0 || a.c_rows_per_group > 0;
-  const bool fast = gemm_fast_form<BM, BN>(a);
+  const bool fast = gemm_fast_form<BM, BN>(a) && a.K % BK == 0;  // (the fast kernels' K loop is unguarded too)
   const bool drop = a.dropout_p > 0.f || a.self_resid;
   // kernels: [row-ops][fast without dropout | fast with dropout | general 16-bit | general fp32]
   // (an epilogue finished in accumulator layout — 8-byte accesses, no LDS round trip — measured +4 us per step and was removed)
@@ -1367,7 +1367,7 @@ extern "C" int mst_gemm_nt_pair_begin(const mst_gemm_args* args0, const mst_gemm
     return a.a_u8 && !a.c_f32 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc >= a.N &&
            a.A && a.B && a.C && (uintptr_t)a.A % 16 == 0 && (uintptr_t)a.B % 16 == 0 && (uintptr_t)a.C % 16 == 0 && !a.resid && !a.gate &&
            a.act == 0 && a.dropout_p == 0.f && !a.self_resid && ((!a.rowadd && !a.grpadd) || a.rowadd_period > 0) &&
-           (!a.grpadd || a.grp_index) && gemm_fast_form<64, 64>(a) && cdiv(a.M, 64) * cdiv(a.N, 64) < (1 << 20);
+           (!a.grpadd || a.grp_index) && gemm_fast_form<64, 64>(a) && a.K % 64 == 0 && cdiv(a.M, 64) * cdiv(a.N, 64) < (1 << 20);
   };
   static const bool off = getenv("MST_GEMM_PAIR") && getenv("MST_GEMM_PAIR")[0] == '0';
   if (off || a0.dtype != a1.dtype || !plain(a0) || !plain(a1) || (begin && begin->sh_w && begin->sh_dtype != a0.dtype)) {

@@ -309,7 +309,11 @@ __device__ __forceinline__ void gemm_bias_preload(const mst_gemm_args& a, float 
 // AU8: A holds uint8 elements (mst_gemm_args.a_u8): a chunk is an 8-byte load, widened when it is written to LDS.
 // A_IN_LDS: both K stages of the A tile already sit in the stage buffers (K == 2 * BK: stage t in buffer t, the layout store_tile
 // writes) — the operand was produced by this workgroup (gemm_bce_dgrad_ln_kernel); only B is loaded.
-template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false, bool A_IN_LDS = false>
+// FULL: every tile of the launch is interior and K is a multiple of BK (host check): the stage loads carry no row / K guards. A
+// guarded load is a compare, an exec-mask branch and a zero fill of its four registers — 33 vector instructions per stage of 8
+// MFMAs per wave in the 64 x 64 form, as many issue cycles as the MFMAs themselves (SQ counters: the K = 768 input-gradient
+// launches kept the vector ALUs busy 65 % of the time).
+template <typename T, int BM, int BN, int WGM, int WGN, int BK, bool AREMAP = true, bool AU8 = false, bool A_IN_LDS = false, bool FULL = false>
 __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned char* smem,
                                               f32x4 (&acc)[(BN / WGN) / 16][(BM / WGM) / 16], int64_t& m0, int64_t& n0,
                                               int64_t bid_in = -1) {
@@ -362,7 +366,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   for (int i = 0; i < A_CH; ++i) {
     int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
     int64_t m = m0 + row;
-    a_ok[i] = m < a.M && c < BM * CHUNKS;
+    a_ok[i] = (FULL || m < a.M) && c < BM * CHUNKS;
     int64_t pm = a_tile_remap ? (a_ok[i] ? a_pm0 + row : 0)
                               : (AREMAP ? remap_row(a_ok[i] ? m : 0, a.a_rows_per_group, a.a_group_stride, a.a_group_offset) : (a_ok[i] ? m : 0));
     a_ptr[i] = A + pm * a.lda + ch * 8;
@@ -376,7 +380,7 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
   for (int i = 0; i < B_CH; ++i) {
     int c = tid + i * NT, row = c / CHUNKS, ch = c % CHUNKS;
     int64_t n = n0 + row;
-    b_ok[i] = n < a.N;
+    b_ok[i] = FULL || n < a.N;
     b_ptr[i] = B + (b_ok[i] ? n : 0) * a.ldb + ch * 8;
     b_ch[i] = ch * 8;
     b_lds[i] = row * CHUNKS + (ch ^ swz(row));
@@ -389,12 +393,19 @@ __device__ __forceinline__ void gemm_mainloop(const mst_gemm_args& a, unsigned c
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       if constexpr (A_IN_LDS) continue;
-      if constexpr (AU8) ra8[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x2*>(a_ptr[i] + k0) : u32x2{0u, 0u};
-      else ra[i] = (a_ok[i] && (k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
+      if constexpr (FULL && BM * CHUNKS % NT == 0) {
+        if constexpr (AU8) ra8[i] = *reinterpret_cast<const u32x2*>(a_ptr[i] + k0);
+        else ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + k0);
+        continue;
+      }
+      if constexpr (AU8) ra8[i] = (a_ok[i] && (FULL || k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x2*>(a_ptr[i] + k0) : u32x2{0u, 0u};
+      else ra[i] = (a_ok[i] && (FULL || k0 + a_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k0) : zero4;
     }
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i)
-      rb[i] = (b_ok[i] && (k0 + b_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(b_ptr[i] + k0) : zero4;
+    for (int i = 0; i < B_CH; ++i) {
+      if constexpr (FULL) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + k0);
+      else rb[i] = (b_ok[i] && (k0 + b_ch[i] < a.K)) ? *reinterpret_cast<const u32x4*>(b_ptr[i] + k0) : zero4;
+    }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
