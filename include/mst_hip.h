@@ -496,6 +496,13 @@ int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
  * rows exist since the step's first launch) on the forward tail and that projection's input gradient on the backward tail:
  * two launches (12 + 10 us) less in the step's dependent chain. Same results as mst_gemm_nt, bit for bit. */
 int mst_row_tail_fwd_ride(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream);
+/* ... with the step's transposed-shadow refresh (mst_transpose_shadows' list, in the tail's activation type) BEHIND the rider's tiles in
+ * the same queue, four 32 x 32 tiles per ticket: the 16-bit transposed copies that only the backward pass reads (nothing in this launch
+ * does) are rebuilt on compute units that idle until the chain ends, instead of 4.9 us on the step's first launch
+ * (mst_step_begin_args.sh_*). The weights they are built from must be final (the previous step's optimizer launch precedes). */
+int mst_row_tail_fwd_ride_shadows(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, int sh_dtype,
+                                  const float* sh_w, void* sh_wt16, const int64_t* sh_desc, const int64_t* sh_prefix, int64_t sh_n_mat,
+                                  int64_t sh_tiles, mst_stream_t stream);
 /* The same rows on the way back: autograd of mst_row_tail_fwd's chain for the gradient `dy` of the layer's output rows —
  *     mst_layernorm_bwd (LayerNorm-2; dh, its dropout-masked copy dhm, dgamma2 / dbeta2 +=)
  *  -> mst_gemm_nt(dhm, W2t, gate = a, alpha = 1 / (1 - p))   d(pre)                 [B, 4 D]

@@ -173,6 +173,7 @@ SIGNATURES = {
     "mst_gemm_sigmoid_bce_dgrad_ln": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(BceArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),
     "mst_row_tail_fwd": (C.c_int, [C.POINTER(RowTailArgs), vp]),
     "mst_row_tail_fwd_ride": (C.c_int, [C.POINTER(RowTailArgs), C.POINTER(GemmArgs), vp, vp]),
+    "mst_row_tail_fwd_ride_shadows": (C.c_int, [C.POINTER(RowTailArgs), C.POINTER(GemmArgs), vp, C.c_int, vp, vp, vp, vp, c_i64, c_i64, vp]),
     "mst_row_tail_bwd": (C.c_int, [C.POINTER(RowTailBwdArgs), vp]),
     "mst_row_tail_bwd_ride": (C.c_int, [C.POINTER(RowTailBwdArgs), C.POINTER(GemmArgs), vp, vp]),
     "mst_ffn_ln_fwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(LnArgs), vp]),

@@ -24,6 +24,7 @@
 #include <math.h>
 #include "common.hpp"
 #include "gemm_tile.hpp"
+#include "shadows.hpp"
 
 namespace mst {
 
@@ -195,15 +196,29 @@ __device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
 // BM = 256 (4 x 4 waves of 64 x 32, the epilogue staged one 64-row block at a time): for GEMMs with more 128 x 128 tiles than riders —
 // a tile is a chain of dependent latencies (~9 us whatever its size) and a 16-wave workgroup has a CU to itself, so ONE round of
 // bigger tiles ends long before two rounds of small ones (the decoder projection: 192 tiles on 224 riders instead of 384).
+// ... and BEHIND the GEMM's tiles in the same queue (forward tail only): the step's transposed 16-bit shadow refresh (shadows.hpp; the
+// matrices only the backward pass reads — nothing in this launch reads them), four 32 x 32 tiles per ticket, one per 256 threads. On the
+// step's first launch they were 4.9 us of its 24; here they run on compute units that have nothing else to do until the chain ends.
+struct TailShadow {
+  const float* w; void* wt16; const int64_t* desc; const int64_t* prefix; int n_mat; int n_groups; int64_t tiles;
+};
 template <typename T, int BM>
-__device__ __forceinline__ void tail_ride_bm(const mst_gemm_args& g, int n_tiles, uint32_t* counter, unsigned char* smem) {
+__device__ __forceinline__ void tail_ride_bm(const mst_gemm_args& g, int n_tiles, uint32_t* counter, unsigned char* smem, const TailShadow& sh) {
   constexpr int BN = 128, WGM = BM == 256 ? 4 : 2, WGN = 16 / WGM, PATH = BM == 256 ? 4 : 1;
   __shared__ int s_tile;
   for (;;) {
     if (threadIdx.x == 0) s_tile = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = s_tile;
-    if (tile >= n_tiles) return;
+    if (tile >= n_tiles) {
+      const int grp = tile - n_tiles;
+      if (grp >= sh.n_groups) return;
+      const int64_t tb = (int64_t)grp * 4 + (threadIdx.x >> 8);
+      shadow_tile_wg<T>(sh.w, reinterpret_cast<T*>(sh.wt16), sh.desc, sh.prefix, sh.n_mat, tb, reinterpret_cast<float(*)[33]>(smem) + 32 * (threadIdx.x >> 8),
+                        tb < sh.tiles, threadIdx.x & 255);
+      __syncthreads();  // (the tile buffers and s_tile are rewritten)
+      continue;
+    }
     f32x4 acc[(BN / WGN) / 16][(BM / WGM) / 16];
     int64_t m0, n0;
     float bias_pre[8];
@@ -243,14 +258,15 @@ __device__ __forceinline__ void l2_wait(V (&r)[N]) {  // the *_nowait destinatio
 // leave without another round trip (an atomic here cost the launch ~2 us); if it does not — or if no workgroup ever landed on
 // another XCD, so that nobody rode — they take tiles themselves until the queue is empty.
 template <typename T, int BM>
-__device__ __forceinline__ void tail_drain(const mst_gemm_args& g, int n_tiles, uint32_t* counter, uint32_t& seen, unsigned char* smem) {
+__device__ __forceinline__ void tail_drain(const mst_gemm_args& g, int n_tiles, uint32_t* counter, uint32_t& seen, unsigned char* smem,
+                                           const TailShadow& sh) {
   __shared__ int s_drain;
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
-    s_drain = seen < (uint32_t)n_tiles;
+    s_drain = seen < (uint32_t)(n_tiles + sh.n_groups);
   }
   __syncthreads();
-  if (s_drain) tail_ride_bm<T, BM>(g, n_tiles, counter, smem);
+  if (s_drain) tail_ride_bm<T, BM>(g, n_tiles, counter, smem, sh);
 }
 
 // LayerNorm of one row held as 4 elements per lane (D = 256) or 2 (D = 128): layernorm_fwd_kernel's arithmetic
@@ -311,7 +327,8 @@ __device__ __forceinline__ f32x4 quarter_sum(float* sP, const f32x4& part, int w
 
 // RIDE: 0, or the rider tile's rows (128 / 256) — one rider form per kernel: both in one made the register allocator spill
 template <typename T, int D, int RIDE = 0>
-__global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q, mst_gemm_args ride, int ride_tiles, uint32_t* ride_queue) {
+__global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q, mst_gemm_args ride, int ride_tiles, uint32_t* ride_queue,
+                                                            TailShadow ride_sh) {
   constexpr int G = D / 16, F = 4 * D, LDX = D + 8, E = D / 64;
   constexpr int KQ1 = D / 32 / 4, KQ2 = F / 32 / 4;  // k-steps per K quarter of the two 16-column stages
   __shared__ __attribute__((aligned(16))) T sX1[64 * LDX];  // LayerNorm-1 output of every row (FFN1's operand, FFN2's residual)
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q,
   if (g < 0) {
     if constexpr (RIDE != 0) {
       extern __shared__ __attribute__((aligned(16))) unsigned char ride_smem[];
-      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, ride_smem);
+      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, ride_smem, ride_sh);
     }
     return;
   }
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(1024) void row_tail_fwd_kernel(mst_row_tail_args q,
   if constexpr (RIDE != 0) {  // the chain is done: whatever the riders left in the queue (normally nothing)
     extern __shared__ __attribute__((aligned(16))) unsigned char ride_smem[];
     __syncthreads();
-    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, ride_smem);
+    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, ride_smem, ride_sh);
   }
 }
 
@@ -556,7 +573,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   const int g = tail_join(q.sync, G);
   if (g < 0) {
     if constexpr (RIDE != 0) {
-      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, tail_smem);
+      if (g == -1) tail_ride_bm<T, RIDE>(ride, ride_tiles, ride_queue, tail_smem, TailShadow{});
     }
     return;
   }
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(1024) void row_tail_bwd_kernel(mst_row_tail_bwd_arg
   TAIL_STAMP(7);
   if constexpr (RIDE != 0) {  // the chain is done: whatever the riders left in the queue (normally nothing)
     __syncthreads();
-    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, tail_smem);
+    tail_drain<T, RIDE>(ride, ride_tiles, ride_queue, ride_seen, tail_smem, TailShadow{});
   }
 }
 
@@ -835,7 +852,8 @@ static void ride_shape(const mst_gemm_args& g, int& tiles_signed, size_t& lds) {
   // (negative: 256-row tiles)
 }
 
-static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
+static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream,
+                             const TailShadow& shadow = TailShadow{}) {
   MST_CHECK_ARG(args != nullptr, "mst_row_tail_fwd: null args");
   const mst_row_tail_args& q = *args;
   MST_CHECK_ARG(q.B > 0 && q.B <= 64, "mst_row_tail_fwd: 1..64 rows (got %lld)", (long long)q.B);
@@ -861,7 +879,7 @@ static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args*
       size_t rlds;
       ride_shape(*rider, tiles, rlds);
       const int wi = (q.D == 256 ? 0 : 1) + (tiles < 0 ? 2 : 0);
-      typedef void (*kern_t)(mst_row_tail_args, mst_gemm_args, int, uint32_t*);
+      typedef void (*kern_t)(mst_row_tail_args, mst_gemm_args, int, uint32_t*, TailShadow);
       const kern_t fns[4] = {&row_tail_fwd_kernel<T, 256, 128>, &row_tail_fwd_kernel<T, 128, 128>, &row_tail_fwd_kernel<T, 256, 256>, &row_tail_fwd_kernel<T, 128, 256>};
       static size_t opted[4] = {0, 0, 0, 0};
       if (rlds > opted[wi]) {
@@ -870,9 +888,9 @@ static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args*
         opted[wi] = rlds;
       }
       const unsigned grid = ride_grid(q.D / 16, tiles < 0 ? -tiles : tiles);
-      hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), rlds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue);
-    } else if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
-    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(fns[wi], dim3(grid), dim3(1024), rlds, s, q, *rider, tiles < 0 ? -tiles : tiles, queue, shadow);
+    } else if (q.D == 256) hipLaunchKernelGGL((row_tail_fwd_kernel<T, 256>), dim3(16 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr, TailShadow{});
+    else hipLaunchKernelGGL((row_tail_fwd_kernel<T, 128>), dim3(8 * TAIL_OVERSUBSCRIBE), dim3(1024), 0, s, q, none, 0, (uint32_t*)nullptr, TailShadow{});
     MST_CHECK_LAUNCH("row_tail_fwd_kernel");
     return MST_OK;
   });
@@ -881,6 +899,17 @@ extern "C" int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stre
 extern "C" int mst_row_tail_fwd_ride(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {
   MST_CHECK_ARG(rider != nullptr && queue != nullptr, "mst_row_tail_fwd_ride: null rider / queue word");
   return row_tail_fwd_impl(args, rider, queue, stream);
+}
+extern "C" int mst_row_tail_fwd_ride_shadows(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, int sh_dtype,
+                                             const float* sh_w, void* sh_wt16, const int64_t* sh_desc, const int64_t* sh_prefix, int64_t sh_n_mat,
+                                             int64_t sh_tiles, mst_stream_t stream) {
+  MST_CHECK_ARG(args != nullptr && rider != nullptr && queue != nullptr, "mst_row_tail_fwd_ride_shadows: null args / rider / queue word");
+  MST_CHECK_ARG(sh_w && sh_wt16 && sh_desc && sh_prefix && sh_n_mat > 0 && sh_tiles > 0 && sh_tiles < (1ll << 30) && sh_dtype == args->dtype,
+                "mst_row_tail_fwd_ride_shadows: bad shadow list (mst_transpose_shadows' arguments, in the tail's activation type)");
+  TailShadow sh;
+  sh.w = sh_w; sh.wt16 = sh_wt16; sh.desc = sh_desc; sh.prefix = sh_prefix; sh.n_mat = (int)sh_n_mat; sh.tiles = sh_tiles;
+  sh.n_groups = (int)((sh_tiles + 3) / 4);
+  return row_tail_fwd_impl(args, rider, queue, stream, sh);
 }
 
 static int row_tail_bwd_impl(const mst_row_tail_bwd_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream) {

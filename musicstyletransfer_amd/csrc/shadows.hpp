@@ -7,10 +7,13 @@
 
 namespace mst {
 
-// 256 threads; tile: 32 x 33 floats of LDS; tb: tile index within the list
+// 256 threads (t: the thread's index among them — a wider workgroup runs one tile per 256 threads, every thread reaching the barrier;
+// live: this group has a tile); tile: 32 x 33 floats of LDS; tb: tile index within the list
 template <typename T>
 __device__ __forceinline__ void shadow_tile_wg(const float* __restrict__ w, T* __restrict__ wt16, const int64_t* __restrict__ desc,
-                                               const int64_t* __restrict__ tile_prefix, int n_mat, int64_t tb, float (*tile)[33]) {
+                                               const int64_t* __restrict__ tile_prefix, int n_mat, int64_t tb, float (*tile)[33],
+                                               bool live = true, int t = (int)threadIdx.x) {
+  if (!live) { __syncthreads(); return; }
   int mi = 0;
   for (int i = 1; i < n_mat; ++i)
     if (tb >= tile_prefix[i]) mi = i;
@@ -19,7 +22,7 @@ __device__ __forceinline__ void shadow_tile_wg(const float* __restrict__ w, T* _
   const int64_t local = tb - tile_prefix[mi];
   const int64_t tiles_c = (cols + 31) / 32;
   const int64_t r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int tx = t & 31, ty = t >> 5;  // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     const int64_t r = r0 + j, c = c0 + tx;
     tile[j][tx] = (r < rows && c < cols) ? w[src_off + r * cols + c] : 0.f;

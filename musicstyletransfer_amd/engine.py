@@ -836,7 +836,8 @@ class StepPlan:
                            row0(L.h1), row0(L.x1), row0(L.a), row0(L.h2), row0(L.x2), L.mean1, L.rstd1, L.mean2, L.rstd2,
                            self.sync_words[0:3], stat_stride=S, phys_stride=S, dropout_p=p,
                            dropout_seed_ptr=self.rng_state if p > 0 else None, site0=site0, status=st.step_status[0:1], rider=rider,
-                           queue=self.ride_queues[0:1])
+                           queue=self.ride_queues[0:1], shadows=self._tail_shadows if rider is not None else None)
+            assert self._tail_shadows is None or rider is not None, "the shadow refresh was planned onto a tail without riders"
             return L.x2
         rows = (1, S, 0)  # output row b -> physical row b*S
         o.gemm_nt(row0(L.att), st.h(f"{pre}.att.W_proj.weight"), L.h1, M=B, N=D, K=D, bias=st.p(f"{pre}.att.W_proj.bias"),
@@ -921,8 +922,15 @@ class StepPlan:
                      eps_index0=self.sample_offset * cfg.latent_dim, lens=self.seq_lens,
                      mask_e=self.keymask_e if cfg.kind != "token" else None, add_e=0, mask_d=self.keymask_d, add_d=1,
                      zero_a=self._recon_buf, zero_b=st.g if tick else None)
+        self._tail_shadows = None
         if st.shadows_deferred and cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0":
-            begin["shadows"] = dict(w=st.w, wt16=st.wt16, desc=st.t_desc_late, prefix=st.t_prefix_late, n_mat=st.t_n_late, tiles=st.t_tiles_late)
+            late = dict(w=st.w, wt16=st.wt16, desc=st.t_desc_late, prefix=st.t_prefix_late, n_mat=st.t_n_late, tiles=st.t_tiles_late)
+            # the refresh of the transposed shadows (read by the backward pass only): behind the forward tail's riders where that launch
+            # has them — compute units that idle until the position-0 chain ends — else behind the tiles of the step's first launch (+4.9 us)
+            if self.ride and self._tail_on(cfg.e_model) and cfg.e_layers >= 1 and os.environ.get("MST_SHADOW_TAIL", "1") != "0":
+                self._tail_shadows = late
+            else:
+                begin["shadows"] = late
         # (piano-roll ends: nothing in the embedding GEMMs reads what the bookkeeping writes — it rides on their launch)
         ride = cfg.kind != "token" and os.environ.get("MST_BEGIN_RIDE", "1") != "0"
         if not ride:

@@ -107,14 +107,15 @@ def can_row_tail(B, D):
 
 
 def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a, h2, x2, mean1, rstd1, mean2, rstd2, sync, stat_stride,
-                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None, rider=None, queue=None):
+                 phys_stride, eps=1e-5, dropout_p=0.0, dropout_seed_ptr=None, site0=0, status=None, rider=None, queue=None, shadows=None):
     """att / resid / h1 / x1 / a / h2 / x2: [B, width] row views (stride(0) = the row stride in elements) of the layer's
     buffers; sync: THREE zeroed int32 device words (barrier counter — 3 * D / 16 after a complete launch —, claimed XCD,
     roles handed out); status: optional sticky int32 device word the kernel ORs _lib.TAIL_* flags into when it cannot
     finish. rider: dict(A=, B=, C_out=, **gemm_nt keywords) — one GEMM nothing in the chain reads, computed by the launch's
     workgroups on the other seven XCDs (mst_row_tail_fwd_ride); queue: its tile queue, ONE zeroed int32 device word in a
-    cache line of its own (not sync's)"""
-    assert sync.numel() >= 3 and (rider is None or queue is not None)
+    cache line of its own (not sync's); shadows: dict(w=, wt16=, desc=, prefix=, n_mat=, tiles=) — transpose_shadows' list, rebuilt by
+    the riders behind the GEMM's tiles (mst_row_tail_fwd_ride_shadows; needs a rider)"""
+    assert sync.numel() >= 3 and (rider is None or queue is not None) and (shadows is None or rider is not None)
     q = _lib.RowTailArgs()
     q.dtype, q.B, q.D = dt(att), att.shape[0], Wp.shape[0]
     q.att, q.rs_att, q.resid, q.rs_res = ptr(att), att.stride(0), ptr(resid), resid.stride(0)
@@ -125,7 +126,10 @@ def row_tail_fwd(att, resid, Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, h1, x1, a
     q.mean1, q.rstd1, q.mean2, q.rstd2, q.stat_stride = ptr(mean1), ptr(rstd1), ptr(mean2), ptr(rstd2), stat_stride
     q.eps, q.dropout_p, q.dropout_seed, q.dropout_seed_ptr, q.site0 = eps, dropout_p, 0, ptr(dropout_seed_ptr), site0
     q.phys_stride, q.sync, q.status = phys_stride, ptr(sync), ptr(status)
-    if rider is not None:
+    if shadows is not None:
+        call("mst_row_tail_fwd_ride_shadows", C.byref(q), C.byref(_gemm_args(**rider)), ptr(queue), dt(shadows["wt16"]), ptr(shadows["w"]),
+             ptr(shadows["wt16"]), ptr(shadows["desc"]), ptr(shadows["prefix"]), shadows["n_mat"], shadows["tiles"], stream())
+    elif rider is not None:
         call("mst_row_tail_fwd_ride", C.byref(q), C.byref(_gemm_args(**rider)), ptr(queue), stream())
     else:
         call("mst_row_tail_fwd", C.byref(q), stream())

@@ -101,13 +101,40 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype, rider):
         rA, rW, rkw, rMd = _rider_problem(gpu, dtype, *rider, with_resid=False, seed=17)
         rC = torch.full((rMd, rkw["N"]), 3.0, dtype=dtype, device=gpu)
         ride = dict(A=rA, B=rW, C_out=rC, **rkw)
+    sh = None
+    if rider is not None and rider[0] != 6:
+        # ... and behind the GEMM's tiles, in the same queue, the transposed-shadow refresh (mst_row_tail_fwd_ride_shadows): 32 x 32
+        # tiles of three matrices, ragged ones included, four per ticket
+        sh_shapes = [(10, 32), (293, 128), (256, 1024)]
+        sh_offs, tot = [], 0
+        for rr, cc in sh_shapes:
+            sh_offs.append(tot)
+            tot += rr * cc
+        sh_w = (torch.randn(tot, generator=g)).to(gpu)
+        desc, prefix, doff = [], [0], 0
+        for (rr, cc), so in zip(sh_shapes, sh_offs):
+            desc += [so, doff, rr, cc]
+            doff += cc * o.roundup(rr, 8)
+            prefix.append(prefix[-1] + ((rr + 31) // 32) * ((cc + 31) // 32))
+        sh_wt = torch.full((doff,), 9.0, dtype=dtype, device=gpu)
+        sh = dict(w=sh_w, wt16=sh_wt, desc=torch.tensor(desc, dtype=torch.int64, device=gpu),
+                  prefix=torch.tensor(prefix, dtype=torch.int64, device=gpu), n_mat=len(sh_shapes), tiles=prefix[-1])
     o.row_tail_fwd(row0(att), row0(xin), Wp, bp, g1, be1, W1, b1, W2, b2, g2, be2, row0(f["h1"]), row0(f["x1"]), row0(f["a"]), row0(f["h2"]),
                    row0(f["x2"]), f["m1"], f["r1"], f["m2"], f["r2"], sync[0:3], stat_stride=S, phys_stride=S,
-                   dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6, rider=ride, queue=queue[0:1])
+                   dropout_p=p, dropout_seed_ptr=seedp if p > 0 else None, site0=6, rider=ride, queue=queue[0:1], shadows=sh)
     torch.cuda.synchronize()
     assert int(sync[0].item()) == 3 * (D // 16)  # three barriers, every workgroup arrived at each
     if ride:
         _check_rider(o, gpu, dtype, rA, rW, rkw, rMd, rC, queue[0])
+    if sh is not None:
+        d0 = 0
+        for (rr, cc), so in zip(sh_shapes, sh_offs):
+            ldt = o.roundup(rr, 8)
+            got = sh_wt[d0:d0 + cc * ldt].view(cc, ldt)
+            assert torch.equal(got[:, :rr], sh_w[so:so + rr * cc].view(rr, cc).t().to(dtype)), "shadow tiles behind the riding GEMM"
+            assert (got[:, rr:] == 0).all()
+            d0 += cc * ldt
+        assert int(queue[0].item()) >= (sh["tiles"] + 3) // 4  # (every ticket handed out)
     # (the 16-column stages sum their K range in four quarters, one per group of waves: another order of the same fp32 sums)
     ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
     for k in ("h1", "x1", "a", "h2", "x2"):

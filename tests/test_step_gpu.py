@@ -688,3 +688,46 @@ def test_transposed_shadows_follow_the_weights_without_their_own_launch(gpu):
     # the last bits from run to run whatever the path)
     from test_parallel_gpu import _close_after_adam
     _close_after_adam(res["1"], res["0"], 1e-2, 3)
+
+
+def test_shadow_refresh_rides_on_the_forward_tail(gpu):
+    """Widths at which the position-0 tails have riders (decoder width 128, T a multiple of 128): the backward-only transposed shadows are
+    rebuilt by the forward tail's riders behind their GEMM tiles (mst_row_tail_fwd_ride_shadows) instead of on the step's first launch —
+    after a forward pass every shadow equals its weights, and training equals the run that keeps the refresh on the first launch."""
+    import os
+    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (64, 64, 2, 16, 128, 2, 4, 128, 1, 4), 4, 128, 67)
+
+    def fresh(st, names):
+        ok = True
+        for n in names:
+            so, r, c = st.t_specs[n]
+            ok &= bool(torch.equal(st.t(n)[:, :r], st.w[so: so + r * c].view(r, c).t().to(st.act_dtype)))
+        return ok
+
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MST_SHADOW_TAIL"] = mode
+        try:
+            store = E.ParamStore(ecfg, gpu, torch.bfloat16, params_np=params)
+            plan = E.StepPlan(store, 4, 128, lr=1e-2)
+            plan.load_batch(batch["x"], batch["seq_lens"], batch["classes"], batch["labels"], eps)
+            assert store.shadows_deferred and plan.ride
+            for _ in range(3):
+                plan.step_kernels(True)
+            torch.cuda.synchronize()
+            assert (plan._tail_shadows is not None) == (mode == "1")
+            assert int(store.step_status.cpu()[0]) == 0
+            emb = ["encoder.embedding.weight", "decoder.embedding.weight"]
+            late = [n for n in store.t_specs if n not in emb]
+            assert fresh(store, emb) and not fresh(store, late)
+            plan._tick_adam = False
+            plan.forward()
+            torch.cuda.synchronize()
+            assert fresh(store, emb + late)
+        finally:
+            os.environ.pop("MST_SHADOW_TAIL", None)
+        res[mode] = store.w.cpu().numpy().copy()
+    # (three Adam steps at lr 1e-2 from gradients that differ in the order of their fp32 atomics: equal except where a near-zero
+    # gradient flips sign — 2.5 % of the weights at these widths; a stale shadow would move every weight)
+    d = np.abs(res["1"] - res["0"])
+    assert d.max() <= 2.1 * 1e-2 * 3 and (d > 2e-5).mean() < 0.05, (d.max(), (d > 2e-5).mean())
