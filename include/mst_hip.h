@@ -497,7 +497,7 @@ int mst_row_tail_fwd(const mst_row_tail_args* args, mst_stream_t stream);
  * two launches (12 + 10 us) less in the step's dependent chain. Same results as mst_gemm_nt, bit for bit. */
 int mst_row_tail_fwd_ride(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, mst_stream_t stream);
 /* ... with the step's transposed-shadow refresh (mst_transpose_shadows' list, in the tail's activation type) BEHIND the rider's tiles in
- * the same queue, four 32 x 32 tiles per ticket: the 16-bit transposed copies that only the backward pass reads (nothing in this launch
+ * the same queue, sixteen 32 x 32 tiles per ticket: the 16-bit transposed copies that only the backward pass reads (nothing in this launch
  * does) are rebuilt on compute units that idle until the chain ends, instead of 4.9 us on the step's first launch
  * (mst_step_begin_args.sh_*). The weights they are built from must be final (the previous step's optimizer launch precedes). */
 int mst_row_tail_fwd_ride_shadows(const mst_row_tail_args* args, const mst_gemm_args* rider, uint32_t* queue, int sh_dtype,

@@ -197,11 +197,21 @@ __device__ __forceinline__ int tail_join(uint32_t* sync, int G) {
 // a tile is a chain of dependent latencies (~9 us whatever its size) and a 16-wave workgroup has a CU to itself, so ONE round of
 // bigger tiles ends long before two rounds of small ones (the decoder projection: 192 tiles on 224 riders instead of 384).
 // ... and BEHIND the GEMM's tiles in the same queue (forward tail only): the step's transposed 16-bit shadow refresh (shadows.hpp; the
-// matrices only the backward pass reads — nothing in this launch reads them), four 32 x 32 tiles per ticket, one per 256 threads. On the
+// matrices only the backward pass reads — nothing in this launch reads them), sixteen 32 x 32 tiles per ticket, four per 256 threads with
+// their loads requested together (68 KB of the rider's LDS; at four tiles per ticket the refresh was two rounds of round trips and the
+// chain's participants met an unfinished queue). On the
 // step's first launch they were 4.9 us of its 24; here they run on compute units that have nothing else to do until the chain ends.
 struct TailShadow {
   const float* w; void* wt16; const int64_t* desc; const int64_t* prefix; int n_mat; int n_groups; int64_t tiles;
 };
+// (a function of its own, not inlined: inside the tail kernel its index arithmetic raised the kernel's register pressure and the
+// allocator spilled 49 registers instead of 18 — some of them in the chain's stages: forward tail 34 -> 42 us)
+template <typename T>
+__device__ __attribute__((noinline)) void tail_shadow_ticket(const TailShadow& sh, int grp, unsigned char* smem) {
+  const int quarter = threadIdx.x >> 8;
+  shadow_tile_quad<T>(sh.w, reinterpret_cast<T*>(sh.wt16), sh.desc, sh.prefix, sh.n_mat, (int64_t)grp * 16 + 4 * quarter, sh.tiles,
+                      reinterpret_cast<float(*)[32][33]>(smem) + 4 * quarter, threadIdx.x & 255);
+}
 template <typename T, int BM>
 __device__ __forceinline__ void tail_ride_bm(const mst_gemm_args& g, int n_tiles, uint32_t* counter, unsigned char* smem, const TailShadow& sh) {
   constexpr int BN = 128, WGM = BM == 256 ? 4 : 2, WGN = 16 / WGM, PATH = BM == 256 ? 4 : 1;
@@ -213,9 +223,7 @@ __device__ __forceinline__ void tail_ride_bm(const mst_gemm_args& g, int n_tiles
     if (tile >= n_tiles) {
       const int grp = tile - n_tiles;
       if (grp >= sh.n_groups) return;
-      const int64_t tb = (int64_t)grp * 4 + (threadIdx.x >> 8);
-      shadow_tile_wg<T>(sh.w, reinterpret_cast<T*>(sh.wt16), sh.desc, sh.prefix, sh.n_mat, tb, reinterpret_cast<float(*)[33]>(smem) + 32 * (threadIdx.x >> 8),
-                        tb < sh.tiles, threadIdx.x & 255);
+      tail_shadow_ticket<T>(sh, grp, smem);
       __syncthreads();  // (the tile buffers and s_tile are rewritten)
       continue;
     }
@@ -878,6 +886,7 @@ static int row_tail_fwd_impl(const mst_row_tail_args* args, const mst_gemm_args*
       int tiles;
       size_t rlds;
       ride_shape(*rider, tiles, rlds);
+      if (shadow.n_groups > 0 && rlds < (size_t)16 * 32 * 33 * 4) rlds = (size_t)16 * 32 * 33 * 4;  // sixteen shadow tiles per ticket
       const int wi = (q.D == 256 ? 0 : 1) + (tiles < 0 ? 2 : 0);
       typedef void (*kern_t)(mst_row_tail_args, mst_gemm_args, int, uint32_t*, TailShadow);
       const kern_t fns[4] = {&row_tail_fwd_kernel<T, 256, 128>, &row_tail_fwd_kernel<T, 128, 128>, &row_tail_fwd_kernel<T, 256, 256>, &row_tail_fwd_kernel<T, 128, 256>};
@@ -908,7 +917,7 @@ extern "C" int mst_row_tail_fwd_ride_shadows(const mst_row_tail_args* args, cons
                 "mst_row_tail_fwd_ride_shadows: bad shadow list (mst_transpose_shadows' arguments, in the tail's activation type)");
   TailShadow sh;
   sh.w = sh_w; sh.wt16 = sh_wt16; sh.desc = sh_desc; sh.prefix = sh_prefix; sh.n_mat = (int)sh_n_mat; sh.tiles = sh_tiles;
-  sh.n_groups = (int)((sh_tiles + 3) / 4);
+  sh.n_groups = (int)((sh_tiles + 15) / 16);
   return row_tail_fwd_impl(args, rider, queue, stream, sh);
 }
 

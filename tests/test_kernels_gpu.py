@@ -134,7 +134,7 @@ def test_row_tail_fwd_equals_the_five_launches(gpu, B, S, D, p, dtype, rider):
             assert torch.equal(got[:, :rr], sh_w[so:so + rr * cc].view(rr, cc).t().to(dtype)), "shadow tiles behind the riding GEMM"
             assert (got[:, rr:] == 0).all()
             d0 += cc * ldt
-        assert int(queue[0].item()) >= (sh["tiles"] + 3) // 4  # (every ticket handed out)
+        assert int(queue[0].item()) >= (sh["tiles"] + 15) // 16  # (every ticket handed out)
     # (the 16-column stages sum their K range in four quarters, one per group of waves: another order of the same fp32 sums)
     ulp = 2.0 ** -7 if dtype == BF else 2.0 ** -10
     for k in ("h1", "x1", "a", "h2", "x2"):
