@@ -695,7 +695,10 @@ def test_shadow_refresh_rides_on_the_forward_tail(gpu):
     rebuilt by the forward tail's riders behind their GEMM tiles (mst_row_tail_fwd_ride_shadows) instead of on the step's first launch —
     after a forward pass every shadow equals its weights, and training equals the run that keeps the refresh on the first launch."""
     import os
-    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (64, 64, 2, 16, 128, 2, 4, 128, 1, 4), 4, 128, 67)
+    # (full-length sequences: with padded keys this model sits in the reference's mask-flip regime — DESIGN section 4 —, where two runs one
+    # rounding apart part ways by whole grid steps of the -1e9 mask: 3 of 24 identical runs ended 35 % of the weights away from the others,
+    # whichever launch refreshed the shadows; tools/experiments/diag_sporadic.py, diag_shadow_grads.py)
+    O, E, ocfg, ecfg, params, batch, eps = _setup("pianoroll", (64, 64, 2, 16, 128, 2, 4, 128, 1, 4), 4, 128, 67, ragged=False)
 
     def fresh(st, names):
         ok = True
@@ -728,6 +731,6 @@ def test_shadow_refresh_rides_on_the_forward_tail(gpu):
             os.environ.pop("MST_SHADOW_TAIL", None)
         res[mode] = store.w.cpu().numpy().copy()
     # (three Adam steps at lr 1e-2 from gradients that differ in the order of their fp32 atomics: equal except where a near-zero
-    # gradient flips sign — 2.5 % of the weights at these widths; a stale shadow would move every weight)
+    # gradient flips sign; a stale shadow would move every weight)
     d = np.abs(res["1"] - res["0"])
     assert d.max() <= 2.1 * 1e-2 * 3 and (d > 2e-5).mean() < 0.05, (d.max(), (d > 2e-5).mean())
