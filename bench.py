@@ -222,7 +222,7 @@ def kernel_families(plan, o, iters=30):
     if cfg.d_layers >= 1:
         Ld, td = plan.dec[0], plan.bd_l[0]
         fams.append(dict(
-            kernel=f"attention fwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}] (its projection is a GEMM launch)",
+            kernel=f"attention fwd, decoder [B*H={B * Hd}, S={Sd}, dh={Dd // Hd}] (its projection: riders of the forward tail, or a GEMM launch)",
             fn=lambda: o.attn_fwd(Ld.qkv, plan.keymask_d, Ld.lse, Ld.att, B, Sd, Hd, Dd // Hd, 0, Dd, 2 * Dd),
             flops=4.0 * B * Sd * Sd * Dd, bytes=2.0 * (Md * 3 * Dd + Md * Dd), launches_per_step=cfg.d_layers,
             pmc_key="attn_fwd_res_kernel<%d,0,0>@*" % (Dd // Hd)))
