@@ -1,4 +1,8 @@
-"""Phases of one workgroup of mst_gemm_sigmoid_bce_dgrad_ln at configs[1]'s shape (-DMST_FFN_STAMPS build; temporary stamps)."""
+"""Phases of one workgroup of mst_gemm_sigmoid_bce_dgrad_ln at configs[1]'s shape. Needs a -DMST_FFN_STAMPS build with TEMPORARY stamps in
+gemm_nt.hip (not in the tree): gemm_bce_dgrad_ln_kernel — FFN_STAMP(0) + FFN_RT(190) at its start, (1) behind gemm_bce_tile, (2) behind the second
+K loop, (3) + FFN_RT(191) at its end; gemm_bce_tile<KEEP> — (8) behind its K loop, (9) / (10) around the sweep.
+Measured (r04): workgroup 14.7 us = K loop 3.5 (two cold stages), staging 0.4, BCE sweep 2.0, loss sum + barrier 2.3, second GEMM 1.6, LayerNorm
+epilogue 4.9 — nothing dominant; the launch is 23 us in the step."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
